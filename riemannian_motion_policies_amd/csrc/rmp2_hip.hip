@@ -1,0 +1,924 @@
+// rmp2_hip.hip -- kernels + C ABI of the MI355X RMP2 engine (see include/rmp2.h).
+//
+// One control step = ONE kernel launch: FK walk -> per-frame Jacobian columns and J-dot-qd ->
+// leaf (xdd, A) evaluation -> pull-back J^T A J / J^T A (xdd - c) -> sum over leaves (fp64) ->
+// resolve (fp64 LU, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
+// and step: q, qd in, qdd out (+ goal): 120 B for the Panda.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rmp2_device.h"
+#include "rmp2_solve.h"
+
+using namespace rmp2;
+
+namespace {
+
+// =========================================================================================
+// device: the fused control-step kernel
+// =========================================================================================
+// LDS layout per 64-robot block (floats):
+//   [0, 64*N)            q tile, robot-major (row r = lane r)   -- coalesced global load,
+//   [64*N, 128*N)        qd tile                                  stride-N lane reads: N odd -> no conflicts
+//   [128*N, 128*N+6*N*64) per-dof world axis z_j and joint origin o_j, component-major
+//                         ((j*6+c)*64 + lane): lane-private columns, conflict free
+template <int N>
+struct Lds {
+  static constexpr int kQ = 0;
+  static constexpr int kQd = kWave * N;
+  static constexpr int kZo = 2 * kWave * N;
+  static constexpr int kFloats = 2 * kWave * N + 6 * N * kWave;
+};
+
+template <int N, int SLOTS>
+__global__ void __launch_bounds__(kWave)
+rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const float* __restrict__ qd,
+                 const float* __restrict__ goal, int goal_stride, ObsArgs obs, OutArgs out, int R) {
+  __shared__ float lds[Lds<N>::kFloats];
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * kWave;
+  const int robot = r0 + lane;
+  const bool live = robot < R;
+  const int n_dof = prog->n_dof;
+
+  // ---- coalesced load of the q / qd tile (contiguous n_dof*64 floats), zero padded --------
+  {
+    const int tile = min(kWave, R - r0) * n_dof;
+    const float* gq = q + (size_t)r0 * n_dof;
+    const float* gqd = qd + (size_t)r0 * n_dof;
+    for (int i = lane; i < kWave * N; i += kWave) {
+      lds[Lds<N>::kQ + i] = 0.f;
+      lds[Lds<N>::kQd + i] = 0.f;
+    }
+    __syncthreads();
+    for (int i = lane; i < tile; i += kWave) {
+      const int rr = i / n_dof, jj = i - rr * n_dof;
+      lds[Lds<N>::kQ + rr * N + jj] = gq[i];
+      lds[Lds<N>::kQd + rr * N + jj] = gqd[i];
+    }
+    __syncthreads();
+  }
+  const float* my_q = &lds[Lds<N>::kQ + lane * N];
+  const float* my_qd = &lds[Lds<N>::kQd + lane * N];
+  float* zo = &lds[Lds<N>::kZo + lane];
+  const float* my_goal = goal ? goal + (size_t)(live ? robot : 0) * goal_stride : nullptr;
+  const uint32_t rev_mask = prog->rev_mask;
+  const int solve_mode = prog->solve_mode;
+
+  double x[N];        // resolved qdd
+  uint32_t status = 0u;
+  bool singular = false;
+
+  // pass 0: accumulate + LU.  pass 1 (only when some lane of the wave needs it, or in PINV
+  // mode): accumulate again + Jacobi pseudo-inverse.  The loop keeps ONE copy of the
+  // accumulation code.
+#pragma nounroll
+  for (int pass = (solve_mode == RMP2_SOLVE_PINV) ? 1 : 0; pass < 2; ++pass) {
+    double Ms[N * (N + 1) / 2];  // upper triangle of the FK-leaf part (always symmetric)
+    double fv[N];
+#pragma unroll
+    for (int i = 0; i < N * (N + 1) / 2; ++i) Ms[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) fv[i] = 0.0;
+
+    // ---- walk the kinematic tree -------------------------------------------------------
+    FrameState cur;
+    FrameState slot[SLOTS > 0 ? SLOTS : 1];
+    const int n_ops = prog->n_ops;
+    for (int k = 0; k < n_ops; ++k) {
+      const DevOp& op = prog->ops[k];
+      if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.restore == s) cur = slot[s];
+      }
+      const int qi = op.qidx;
+      const float qv = qi >= 0 ? my_q[qi] : 0.f;
+      const float qdv = qi >= 0 ? my_qd[qi] : 0.f;
+      float z[3];
+      visit_frame<true>(cur, op, qv, qdv, op.restore == -2, z);
+      if (qi >= 0 && op.jtype != RMP2_JOINT_FIXED) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          zo[(qi * 6 + c) * kWave] = z[c];
+          zo[(qi * 6 + 3 + c) * kWave] = cur.p[c];
+        }
+      }
+      if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.save == s) slot[s] = cur;
+      }
+      if (op.leaf_count == 0) continue;
+
+      // Jacobian columns of this frame's origin: z_j x (p - o_j) (revolute) or z_j (prismatic)
+      float col[N][3];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if ((op.anc_mask >> j) & 1u) {
+          const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
+          if ((rev_mask >> j) & 1u) {
+            const float d[3] = {cur.p[0] - zo[(j * 6 + 3) * kWave], cur.p[1] - zo[(j * 6 + 4) * kWave],
+                                cur.p[2] - zo[(j * 6 + 5) * kWave]};
+            cross3(zj, d, col[j]);
+          } else {
+            col[j][0] = zj[0];
+            col[j][1] = zj[1];
+            col[j][2] = zj[2];
+          }
+        } else {
+          col[j][0] = col[j][1] = col[j][2] = 0.f;
+        }
+      }
+
+      for (int li = 0; li < op.leaf_count; ++li) {
+        const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
+        float S[6], h[3];
+        if (lf.taskmap == RMP2_TASKMAP_FK_POSITION) {
+          // chain [FK(frame), 4x4 -> position]: x = p, xd = v, c = a_bias (taskmap.py:150-160)
+          float g[3], xdd[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g[c] = my_goal[lf.goal_offset + c];
+          if (lf.kind == RMP2_LEAF_TARGET_ATTRACTOR)
+            leaf_target_attractor(lf.P, cur.p, cur.v, g, xdd, S);
+          else
+            leaf_target_policy3(lf.P, cur.p, cur.v, g, xdd, S);
+          const float e[3] = {xdd[0] - cur.a[0], xdd[1] - cur.a[1], xdd[2] - cur.a[2]};
+          h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
+          h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
+          h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+        } else {
+          // chain [FK(frame), 4x4 -> distance] over this leaf's pairs.  Every pair pulls back
+          // through the SAME 3 x n Jacobian, so the per-pair rank-1 updates collapse into
+          //   S = sum_b a_b n_b n_b^T ,  h = sum_b a_b (xdd_b - c_b) n_b     (fp32, like the
+          // reference's reduce_sum over the pair axis, rmp.py:149-150)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) S[c] = 0.f;
+          h[0] = h[1] = h[2] = 0.f;
+          const float vv = dot3(cur.v, cur.v);
+          int count;
+          const float* pl = nullptr;
+          const float* po = nullptr;
+          const int32_t* ci = nullptr;
+          if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+            const int pb = obs.pair_begin[lf.index];
+            count = obs.pair_begin[lf.index + 1] - pb;
+            const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
+            pl = obs.p_link + base;
+            po = obs.p_obs + base;
+          } else if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
+            count = obs.n_spheres;
+          } else {
+            const int b0 = obs.csr_offset[live ? robot : 0];
+            count = live ? obs.csr_offset[robot + 1] - b0 : 0;
+            ci = obs.csr_index + b0;
+          }
+          const bool uniform_count = obs.mode != RMP2_OBS_RAGGED_SPHERES;
+          int max_count = count;
+          if (!uniform_count) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+          }
+          for (int b = 0; b < max_count; ++b) {
+            float diff[3], nh[3], d;
+            bool on = true;
+            if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+              // taskmap.py:124-129: rel = stop_gradient(p_link - p_joint); crit = p_joint + rel
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float rel = pl[3 * b + c] - cur.p[c];
+                const float crit = cur.p[c] + rel;
+                diff[c] = crit - po[3 * b + c];
+              }
+              d = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) nh[c] = diff[c] / d;
+            } else {
+              int sidx = b;
+              if (!uniform_count) {
+                on = b < count;
+                sidx = on ? ci[b] : 0;
+              }
+              const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[sidx];
+              diff[0] = cur.p[0] - sp.x;
+              diff[1] = cur.p[1] - sp.y;
+              diff[2] = cur.p[2] - sp.z;
+              const float dc = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+              d = dc - sp.w;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) nh[c] = diff[c] / dc;
+            }
+            const float xdot = dot3(nh, cur.v);
+            const float cd = (vv - xdot * xdot) / d + dot3(nh, cur.a);  // c2 + J2 c1 (taskmap.py:159)
+            float acc, met;
+            leaf_obstacle_avoidance(lf.P, d, xdot, acc, met);
+            if (!on) met = 0.f;
+            const float wgt = met * (acc - cd);
+            const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+            S[0] += mn[0] * nh[0];
+            S[1] += mn[0] * nh[1];
+            S[2] += mn[0] * nh[2];
+            S[3] += mn[1] * nh[1];
+            S[4] += mn[1] * nh[2];
+            S[5] += mn[2] * nh[2];
+            h[0] += wgt * nh[0];
+            h[1] += wgt * nh[1];
+            h[2] += wgt * nh[2];
+          }
+        }
+        pull_position<N>(col, op.anc_mask, S, h, Ms, fv);
+      }
+    }
+
+    // ---- identity-task-map leaves: x = q, xd = qd, J = I, c = 0 (taskmap.py:13-20) ----------
+    double A[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[i][j] = Ms[sym_idx<N>(i < j ? i : j, i < j ? j : i)];
+    float ql[N], qdl[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      ql[i] = my_q[i];
+      qdl[i] = my_qd[i];
+    }
+    const int n_id = prog->n_id_leaves;
+    for (int li = 0; li < n_id; ++li) {
+      const DevLeaf& lf = prog->leaves[prog->id_leaves[li]];
+      const float* __restrict__ P = lf.P;
+      float xdd[N];
+      if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {
+        // rmp2.py:127-137
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s2 += qdl[i] * qdl[i];
+        const float nrm = sqrtf(s2);
+        const float m = P[1] * nrm + P[2];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float acc = -(P[0] * nrm) * qdl[i];
+          A[i][i] += (double)m;
+          fv[i] += (double)(m * acc);
+        }
+      } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {
+        // rmp2.py:212-226
+        float e[N], s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          e[i] = ql[i] - lf.va[i];
+          s2 += e[i] * e[i];
+        }
+        const float en = sqrtf(s2);
+        const float m = P[0] + P[4];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float pos = (en < P[3]) ? (-e[i] * P[1]) : (-P[3] * (e[i] / en) * P[1]);
+          const float acc = pos + (-P[2] * qdl[i]);
+          A[i][i] += (double)m;
+          fv[i] += (double)(m * acc);
+        }
+      } else if (lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {
+        // rmp.py:330-347
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float acc = P[0] * (lf.va[i] - ql[i]) - P[1] * qdl[i];
+          A[i][i] += (double)P[2];
+          fv[i] += (double)(P[2] * acc);
+        }
+      } else if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+        // rmp2.py:100-112; metric = w / (1 - diag(ratio^2)) on the FULL matrix (quirk Q4)
+        const float cutoff = P[0] - P[1];
+        float dg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float dv = fabsf(qdl[i]) - cutoff;
+          const float sgn = (qdl[i] > 0.f) ? 1.f : (qdl[i] < 0.f ? -1.f : 0.f);
+          const float acc = -fabsf(P[2] * dv) * sgn;
+          xdd[i] = (fabsf(qdl[i]) < cutoff) ? 0.f : acc;
+          const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+          dg[i] = P[3] / (1.0f - ratio * ratio);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          if (i >= n_dof) continue;
+          float fi = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            if (j >= n_dof) continue;
+            const float a = (i == j) ? dg[i] : P[3] / 1.0f;
+            A[i][j] += (double)a;
+            fi += a * xdd[j];
+          }
+          fv[i] += (double)fi;
+        }
+      } else if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE || lf.kind == RMP2_LEAF_TARGET_POLICY) {
+        // dense metrics built from a stretched direction zeta:  A_ij = cw_j * (beta zeta_i zeta_j + (1-beta) d_ij) * w
+        float cw[N], zeta[N], beta, wsc;
+        if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+          // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
+          const float rr = 0.15f;
+          const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
+          const float qd_max = (float)(20.0 * (2.0 * 3.14159265358979323846) / 60.0);
+          float v[N], s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            const float range = lf.vb[i] - lf.va[i];
+            const float du = (lf.vb[i] - ql[i]) / range;
+            const float dl = (ql[i] - lf.va[i]) / range;
+            const float d = fminf(du, dl);
+            const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
+            cw[i] = (i < n_dof) ? (d > rr ? 0.f : spline) : 0.f;
+            v[i] = qdl[i] / qd_max;
+            s2 += v[i] * v[i];
+            xdd[i] = -P[0] * ql[i] - P[1] * qdl[i];
+          }
+          const float nrm = sqrtf(s2);
+          const float hh = nrm + 1.0f / 5.0f * logf(1.0f + expf(-2.0f * 5.0f * nrm));
+#pragma unroll
+          for (int i = 0; i < N; ++i) zeta[i] = v[i] / hh;
+          beta = 0.9f;
+          wsc = 1.0f;
+        } else {
+          // rmp.py:241-260 on the identity map (goal is an n-vector)
+          const float alpha = P[0], beta_d = P[1], c = P[2];
+          float v[N], s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            v[i] = (i < n_dof) ? my_goal[lf.goal_offset + i] - ql[i] : 0.f;
+            s2 += v[i] * v[i];
+          }
+          const float vn = sqrtf(s2);
+          const float hq = vn + c * logf(1.0f + expf(-2.0f * c * vn));
+          const float inv_h = 1.0f / hq;
+          float f2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            xdd[i] = alpha * (inv_h * v[i]) - beta_d * qdl[i];
+            f2 += xdd[i] * xdd[i];
+            cw[i] = 1.0f;
+          }
+          const float fn = sqrtf(f2);
+          const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+#pragma unroll
+          for (int i = 0; i < N; ++i) zeta[i] = xdd[i] / hs;
+          beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
+          wsc = expf(-vn / 3.0f);
+        }
+        const float omb = 1.0f - beta;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          if (i >= n_dof) continue;
+          float fi = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            if (j >= n_dof) continue;
+            const float Hij = beta * (zeta[i] * zeta[j]) + omb * (i == j ? 1.f : 0.f);
+            const float a = (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) ? cw[j] * Hij : wsc * Hij;
+            A[i][j] += (double)a;
+            fi += a * xdd[j];
+          }
+          fv[i] += (double)fi;
+        }
+      }
+    }
+
+    // optional debug outputs: the combined metric / force before the resolve
+    if (pass == ((solve_mode == RMP2_SOLVE_PINV) ? 1 : 0) && live) {
+      if (out.M) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+            if (i < n_dof && j < n_dof) out.M[((size_t)robot * n_dof + i) * n_dof + j] = A[i][j];
+      }
+      if (out.f) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (i < n_dof) out.f[(size_t)robot * n_dof + i] = fv[i];
+      }
+    }
+    // padding dofs of the template: identity rows so that they resolve to qdd = 0
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i >= n_dof) A[i][i] = 1.0;
+
+    // ---- resolve   rmp.py:153-154 -----------------------------------------------------
+    if (pass == 0) {
+      singular = lu_solve<N>(A, fv, x);
+      if (!__any(singular && live)) break;
+    } else {
+      double xp[N];
+      const int dropped = pinv_solve<N>(A, fv, n_dof, xp);
+      const bool use = (solve_mode == RMP2_SOLVE_PINV) || singular;
+      if (use) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = xp[i];
+        if (dropped) status |= RMP2_STATUS_RANK_DROP;
+        if (solve_mode != RMP2_SOLVE_PINV) status |= RMP2_STATUS_PINV_PATH;
+      }
+    }
+  }
+
+  // ---- coalesced store of the qdd tile through LDS -------------------------------------------
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n_dof) finite = finite && (fabs(x[i]) < 1.7e308);
+  if (!finite) status |= RMP2_STATUS_NONFINITE;
+  __syncthreads();
+  float* tile = &lds[Lds<N>::kQ];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n_dof) tile[lane * n_dof + i] = (float)x[i];
+  __syncthreads();
+  {
+    const int count = min(kWave, R - r0) * n_dof;
+    float* go = out.qdd + (size_t)r0 * n_dof;
+    for (int i = lane; i < count; i += kWave) go[i] = tile[i];
+  }
+  if (out.status && live) out.status[robot] = status;
+}
+
+// =========================================================================================
+// device: FK of all frames, and FK differentiation of one frame
+// =========================================================================================
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave)
+rmp2_fk_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, float* __restrict__ T, int R) {
+  const int robot = blockIdx.x * kWave + threadIdx.x;
+  if (robot >= R) return;
+  const int n_dof = prog->n_dof, F = prog->n_frames;
+  const float* my_q = q + (size_t)robot * n_dof;
+  FrameState cur;
+  FrameState slot[SLOTS > 0 ? SLOTS : 1];
+  for (int k = 0; k < prog->n_ops; ++k) {
+    const DevOp& op = prog->ops[k];
+    if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.restore == s) cur = slot[s];
+    }
+    float z[3];
+    visit_frame<false>(cur, op, op.qidx >= 0 ? my_q[op.qidx] : 0.f, 0.f, op.restore == -2, z);
+    if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.save == s) slot[s] = cur;
+    }
+    float* o = T + ((size_t)robot * F + op.frame) * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o[4 * i + j] = cur.R[3 * i + j];
+      o[4 * i + 3] = cur.p[i];
+    }
+    o[12] = o[13] = o[14] = 0.f;
+    o[15] = 1.f;
+  }
+}
+
+// x = vec(T_frame), xd = J qd, J = d vec(T)/dq, c = Jdot qd   (kinematics.py:250-270)
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave)
+rmp2_diff_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const float* __restrict__ qd,
+                 int frame, float* __restrict__ xo, float* __restrict__ xdo, float* __restrict__ Jo,
+                 float* __restrict__ co, float* __restrict__ zo_scratch, int R) {
+  const int robot = blockIdx.x * kWave + threadIdx.x;
+  if (robot >= R) return;
+  const int n = prog->n_dof;
+  const float* my_q = q + (size_t)robot * n;
+  const float* my_qd = qd + (size_t)robot * n;
+  float* zo = zo_scratch + (size_t)robot * 6 * RMP2_MAX_DOF;  // per-robot z_j, o_j (global scratch)
+  FrameState cur;
+  FrameState slot[SLOTS > 0 ? SLOTS : 1];
+  for (int k = 0; k < prog->n_ops; ++k) {
+    const DevOp& op = prog->ops[k];
+    if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.restore == s) cur = slot[s];
+    }
+    const int qi = op.qidx;
+    float z[3];
+    visit_frame<true>(cur, op, qi >= 0 ? my_q[qi] : 0.f, qi >= 0 ? my_qd[qi] : 0.f, op.restore == -2, z);
+    if (qi >= 0 && op.jtype != RMP2_JOINT_FIXED) {
+      for (int c = 0; c < 3; ++c) {
+        zo[qi * 6 + c] = z[c];
+        zo[qi * 6 + 3 + c] = cur.p[c];
+      }
+    }
+    if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.save == s) slot[s] = cur;
+    }
+    if (op.frame != frame) continue;
+    float* x = xo + (size_t)robot * 16;
+    float* xd = xdo + (size_t)robot * 16;
+    float* c = co + (size_t)robot * 16;
+    float* J = Jo + (size_t)robot * 16 * n;
+    for (int i = 0; i < 16 * n; ++i) J[i] = 0.f;
+    for (int i = 0; i < 16; ++i) x[i] = xd[i] = c[i] = 0.f;
+    x[15] = 1.f;
+    for (int col = 0; col < 3; ++col) {
+      const float Rc[3] = {cur.R[col], cur.R[3 + col], cur.R[6 + col]};
+      float wxR[3], alxR[3], wwR[3];
+      cross3(cur.w, Rc, wxR);
+      cross3(cur.al, Rc, alxR);
+      cross3(cur.w, wxR, wwR);
+      for (int row = 0; row < 3; ++row) {
+        x[4 * row + col] = Rc[row];
+        xd[4 * row + col] = wxR[row];
+        c[4 * row + col] = alxR[row] + wwR[row];
+      }
+      for (int j = 0; j < n; ++j) {
+        if (!((op.anc_mask >> j) & 1u) || !((prog->rev_mask >> j) & 1u)) continue;
+        const float zj[3] = {zo[j * 6], zo[j * 6 + 1], zo[j * 6 + 2]};
+        float zxR[3];
+        cross3(zj, Rc, zxR);
+        for (int row = 0; row < 3; ++row) J[(4 * row + col) * n + j] = zxR[row];
+      }
+    }
+    for (int j = 0; j < n; ++j) {
+      if (!((op.anc_mask >> j) & 1u)) continue;
+      const float zj[3] = {zo[j * 6], zo[j * 6 + 1], zo[j * 6 + 2]};
+      float cj[3] = {zj[0], zj[1], zj[2]};
+      if ((prog->rev_mask >> j) & 1u) {
+        const float d[3] = {cur.p[0] - zo[j * 6 + 3], cur.p[1] - zo[j * 6 + 4], cur.p[2] - zo[j * 6 + 5]};
+        cross3(zj, d, cj);
+      }
+      for (int row = 0; row < 3; ++row) J[(4 * row + 3) * n + j] = cj[row];
+    }
+    for (int row = 0; row < 3; ++row) {
+      x[4 * row + 3] = cur.p[row];
+      xd[4 * row + 3] = cur.v[row];
+      c[4 * row + 3] = cur.a[row];
+    }
+    return;
+  }
+}
+
+// =========================================================================================
+// host: handle, program compiler, launches
+// =========================================================================================
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct rmp2_handle {
+  int device = 0;
+  int n_dof = 0, n_frames = 0, n_slots = 0, n_leaves = 0, goal_floats = 0;
+  int n_template = 0;  // N of the kernel instantiation
+  bool has_distance = false;
+  std::vector<int> distance_leaves;
+  DevProgram* d_prog = nullptr;
+  int32_t* d_pair_begin = nullptr;
+  int32_t h_pair_begin[RMP2_MAX_LEAVES + 1];
+  bool pair_begin_valid = false;
+  float* d_scratch = nullptr;  // rmp2_differentiate scratch
+  size_t scratch_robots = 0;
+  std::string error;
+};
+
+namespace {
+
+int fail(rmp2_handle* h, int code, const std::string& msg) {
+  if (h)
+    h->error = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(h, RMP2_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+// depth-first schedule with save/restore slots (same algorithm as urdf.py:depth_first_schedule)
+int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string& err) {
+  const rmp2_robot& rb = d.robot;
+  const int F = rb.n_frames, n = rb.n_dof;
+  if (F < 0 || F > RMP2_MAX_FRAMES) return err = "n_frames out of range", RMP2_ERR_INVALID_ARGUMENT;
+  if (n < 1 || n > RMP2_MAX_DOF) return err = "n_dof out of range", RMP2_ERR_INVALID_ARGUMENT;
+  if (d.n_leaves < 0 || d.n_leaves > RMP2_MAX_LEAVES) return err = "n_leaves out of range", RMP2_ERR_INVALID_ARGUMENT;
+  std::memset(&P, 0, sizeof(P));
+  std::vector<std::vector<int>> children(F);
+  std::vector<int> roots;
+  for (int i = 0; i < F; ++i) {
+    const int p = rb.parent[i];
+    if (p >= i || p < -1) return err = "parent[] must be topologically ordered (parent < child)", RMP2_ERR_INVALID_ARGUMENT;
+    if (rb.joint_type[i] < 0 || rb.joint_type[i] > 2) return err = "bad joint_type", RMP2_ERR_INVALID_ARGUMENT;
+    if (rb.q_index[i] >= n) return err = "q_index out of range", RMP2_ERR_INVALID_ARGUMENT;
+    (p < 0 ? roots : children[p]).push_back(i);
+  }
+  std::vector<int> order, stack(roots.rbegin(), roots.rend());
+  while (!stack.empty()) {
+    const int i = stack.back();
+    stack.pop_back();
+    order.push_back(i);
+    for (auto it = children[i].rbegin(); it != children[i].rend(); ++it) stack.push_back(*it);
+  }
+  std::vector<int> pos(F), slot_of(F, -1), free_at;
+  for (int k = 0; k < F; ++k) pos[order[k]] = k;
+  uint32_t rev_mask = 0;
+  std::vector<int> dof_owner(n, -1);
+  for (int k = 0; k < F; ++k) {
+    const int f = order[k], p = rb.parent[f];
+    DevOp& op = P.ops[k];
+    op.frame = f;
+    op.restore = (p < 0) ? -2 : ((k > 0 && order[k - 1] == p) ? -1 : slot_of[p]);
+    op.save = -1;
+    int last_use = -1;
+    for (int c : children[f])
+      if (pos[c] != k + 1) last_use = std::max(last_use, pos[c]);
+    if (last_use >= 0) {
+      int s = -1;
+      for (size_t t = 0; t < free_at.size(); ++t)
+        if (free_at[t] < k) {
+          s = (int)t;
+          break;
+        }
+      if (s < 0) {
+        free_at.push_back(0);
+        s = (int)free_at.size() - 1;
+      }
+      free_at[s] = last_use;
+      slot_of[f] = s;
+      op.save = s;
+    }
+    op.jtype = rb.joint_type[f];
+    op.qidx = (op.jtype == RMP2_JOINT_FIXED) ? -1 : rb.q_index[f];
+    if (op.qidx >= 0) {
+      if (dof_owner[op.qidx] >= 0) return err = "two joints share one q index", RMP2_ERR_INVALID_ARGUMENT;
+      dof_owner[op.qidx] = f;
+      if (op.jtype == RMP2_JOINT_REVOLUTE) rev_mask |= 1u << op.qidx;
+    }
+    uint32_t mask = 0;
+    for (int j = f; j >= 0; j = rb.parent[j])
+      if (rb.joint_type[j] != RMP2_JOINT_FIXED && rb.q_index[j] >= 0) mask |= 1u << rb.q_index[j];
+    op.anc_mask = mask;
+    for (int c = 0; c < 3; ++c) op.axis[c] = rb.axis[f][c];
+    for (int c = 0; c < 12; ++c) op.Tc[c] = rb.T_const[f][c];
+  }
+  n_slots = (int)free_at.size();
+  P.n_ops = F;
+  P.n_dof = n;
+  P.n_frames = F;
+  P.n_leaves = d.n_leaves;
+  P.goal_floats = d.goal_floats;
+  P.solve_mode = d.solve_mode;
+  P.rev_mask = rev_mask;
+  if (d.solve_mode != RMP2_SOLVE_AUTO && d.solve_mode != RMP2_SOLVE_PINV)
+    return err = "unknown solve_mode", RMP2_ERR_INVALID_ARGUMENT;
+
+  // leaves: validate, copy, bucket by task map
+  int nfk = 0, nid = 0;
+  for (int l = 0; l < d.n_leaves; ++l) {
+    const rmp2_leaf& s = d.leaves[l];
+    DevLeaf& t = P.leaves[l];
+    t.kind = s.kind;
+    t.taskmap = s.taskmap;
+    t.frame = s.frame;
+    t.goal_offset = s.goal_offset;
+    t.index = l;
+    std::memcpy(t.P, s.params, sizeof(t.P));
+    std::memcpy(t.va, s.vec_a, sizeof(t.va));
+    std::memcpy(t.vb, s.vec_b, sizeof(t.vb));
+    int goal_len = 0;
+    bool ok = false;
+    switch (s.taskmap) {
+      case RMP2_TASKMAP_IDENTITY:
+        ok = s.kind == RMP2_LEAF_JOINT_VELOCITY_CAP || s.kind == RMP2_LEAF_JOINT_DAMPING ||
+             s.kind == RMP2_LEAF_CSPACE_BIASING || s.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE ||
+             s.kind == RMP2_LEAF_CONFIG_SPACE_BIASING || s.kind == RMP2_LEAF_TARGET_POLICY;
+        if (s.kind == RMP2_LEAF_TARGET_POLICY) goal_len = n;
+        break;
+      case RMP2_TASKMAP_FK_POSITION:
+        ok = s.kind == RMP2_LEAF_TARGET_ATTRACTOR || s.kind == RMP2_LEAF_TARGET_POLICY;
+        goal_len = 3;
+        break;
+      case RMP2_TASKMAP_FK_DISTANCE: ok = s.kind == RMP2_LEAF_OBSTACLE_AVOIDANCE; break;
+      default: break;
+    }
+    if (!ok) return err = "leaf " + std::to_string(l) + ": this (kind, taskmap) pair has no kernel", RMP2_ERR_UNSUPPORTED;
+    if (s.taskmap != RMP2_TASKMAP_IDENTITY && (s.frame < 0 || s.frame >= F))
+      return err = "leaf " + std::to_string(l) + ": frame out of range", RMP2_ERR_INVALID_ARGUMENT;
+    if (goal_len && (s.goal_offset < 0 || s.goal_offset + goal_len > d.goal_floats))
+      return err = "leaf " + std::to_string(l) + ": goal_offset/goal_floats inconsistent", RMP2_ERR_INVALID_ARGUMENT;
+    if (s.taskmap == RMP2_TASKMAP_IDENTITY) P.id_leaves[nid++] = l;
+  }
+  for (int k = 0; k < F; ++k) {
+    DevOp& op = P.ops[k];
+    op.leaf_begin = nfk;
+    for (int l = 0; l < d.n_leaves; ++l)
+      if (d.leaves[l].taskmap != RMP2_TASKMAP_IDENTITY && d.leaves[l].frame == op.frame) P.fk_leaves[nfk++] = l;
+    op.leaf_count = nfk - op.leaf_begin;
+  }
+  P.n_fk_leaves = nfk;
+  P.n_id_leaves = nid;
+  return RMP2_OK;
+}
+
+template <int N, int SLOTS>
+void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                 const OutArgs& out, int R, hipStream_t s) {
+  const int blocks = (R + kWave - 1) / kWave;
+  hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs, o, out,
+                     R);
+}
+
+template <int N>
+int dispatch_slots(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                   const OutArgs& out, int R, hipStream_t s) {
+  switch (h->n_slots) {
+    case 0: launch_step<N, 0>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 1: launch_step<N, 1>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 2: launch_step<N, 2>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    default: return RMP2_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int rmp2_abi_version(void) { return RMP2_ABI_VERSION; }
+size_t rmp2_sizeof_desc(void) { return sizeof(rmp2_desc); }
+size_t rmp2_sizeof_obstacles(void) { return sizeof(rmp2_obstacles); }
+
+const char* rmp2_last_error(const rmp2_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
+  if (!desc || !out) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (desc->abi_version != RMP2_ABI_VERSION)
+    return fail(nullptr, RMP2_ERR_ABI_MISMATCH, "rmp2_desc.abi_version does not match the library");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return fail(nullptr, RMP2_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
+  DevProgram P;
+  int n_slots = 0;
+  std::string err;
+  const int rc = compile_program(*desc, P, n_slots, err);
+  if (rc != RMP2_OK) return fail(nullptr, rc, err);
+  if (desc->robot.n_dof > 9)
+    return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kernels are instantiated for n_dof <= 9");
+  if (n_slots > 2)
+    return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kinematic tree needs more than 2 saved branch states");
+  rmp2_handle* h = new (std::nothrow) rmp2_handle();
+  if (!h) return fail(nullptr, RMP2_ERR_HIP, "out of host memory");
+  h->device = device;
+  h->n_dof = desc->robot.n_dof;
+  h->n_frames = desc->robot.n_frames;
+  h->n_slots = n_slots;
+  h->n_leaves = desc->n_leaves;
+  h->goal_floats = desc->goal_floats;
+  h->n_template = h->n_dof <= 2 ? 2 : 9;
+  for (int l = 0; l < desc->n_leaves; ++l)
+    if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
+  h->has_distance = !h->distance_leaves.empty();
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&h->d_prog, sizeof(DevProgram));
+  if (e == hipSuccess) e = hipMemcpy(h->d_prog, &P, sizeof(DevProgram), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&h->d_pair_begin, sizeof(h->h_pair_begin));
+  if (e == hipSuccess) e = hipMemset(h->d_pair_begin, 0, sizeof(h->h_pair_begin));
+  if (e != hipSuccess) {
+    const std::string msg = std::string("device setup failed: ") + hipGetErrorString(e);
+    rmp2_destroy(h);
+    return fail(nullptr, RMP2_ERR_HIP, msg);
+  }
+  *out = h;
+  return RMP2_OK;
+}
+
+int rmp2_destroy(rmp2_handle* h) {
+  if (!h) return RMP2_OK;
+  (void)hipSetDevice(h->device);
+  if (h->d_prog) (void)hipFree(h->d_prog);
+  if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
+  if (h->d_scratch) (void)hipFree(h->d_scratch);
+  delete h;
+  return RMP2_OK;
+}
+
+int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
+              const rmp2_obstacles* obs, const rmp2_outputs* out, int32_t R, void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "R < 0");
+  if (R == 0) return RMP2_OK;  // empty fleet: nothing to do (pointers may be null)
+  if (!q || !qd || !out || !out->qdd) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "q, qd and out->qdd are required");
+  if (h->goal_floats > 0) {
+    if (!goal) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "this RMP set has goal-bearing leaves: goal is required");
+    if (goal_stride != 0 && goal_stride < h->goal_floats)
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT, "goal_stride must be 0 (shared) or >= goal_floats");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ObsArgs o;
+  std::memset(&o, 0, sizeof(o));
+  o.mode = obs ? obs->mode : RMP2_OBS_NONE;
+  if (h->has_distance) {
+    if (o.mode == RMP2_OBS_NONE)
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT, "this RMP set has distance leaves: obstacles are required");
+    if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+      if (!obs->p_link || !obs->p_obs || obs->n_pairs < 0)
+        return fail(h, RMP2_ERR_INVALID_ARGUMENT, "EXPLICIT_PAIRS needs p_link, p_obs, n_pairs");
+      for (int l = 0; l < h->n_leaves; ++l)
+        if (obs->pair_begin[l] < 0 || obs->pair_begin[l + 1] < obs->pair_begin[l] ||
+            obs->pair_begin[l + 1] > obs->n_pairs)
+          return fail(h, RMP2_ERR_INVALID_ARGUMENT, "pair_begin must be non-decreasing within [0, n_pairs]");
+      if (!h->pair_begin_valid || std::memcmp(h->h_pair_begin, obs->pair_begin, sizeof(h->h_pair_begin)) != 0) {
+        // the ranges change only when the caller's pair layout changes; refresh the device copy then
+        std::memcpy(h->h_pair_begin, obs->pair_begin, sizeof(h->h_pair_begin));
+        HIP_TRY(h, hipMemcpyAsync(h->d_pair_begin, h->h_pair_begin, sizeof(h->h_pair_begin), hipMemcpyHostToDevice, s));
+        h->pair_begin_valid = true;
+      }
+    } else if (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES) {
+      if (obs->n_spheres < 0 || (obs->n_spheres > 0 && !obs->spheres))
+        return fail(h, RMP2_ERR_INVALID_ARGUMENT, "sphere table missing");
+      if (o.mode == RMP2_OBS_RAGGED_SPHERES && (!obs->csr_offset || (!obs->csr_index && obs->n_spheres > 0)))
+        return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
+    } else {
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle mode");
+    }
+    o.n_spheres = obs->n_spheres;
+    o.n_pairs = obs->n_pairs;
+    o.spheres = obs->spheres;
+    o.p_link = obs->p_link;
+    o.p_obs = obs->p_obs;
+    o.csr_offset = obs->csr_offset;
+    o.csr_index = obs->csr_index;
+    o.pair_begin = h->d_pair_begin;
+  }
+  OutArgs oa{out->qdd, out->status, out->M, out->f};
+  int rc;
+  if (h->n_template == 2)
+    rc = dispatch_slots<2>(h, q, qd, goal, goal_stride, o, oa, R, s);
+  else
+    rc = dispatch_slots<9>(h, q, qd, goal, goal_stride, o, oa, R, s);
+  if (rc != RMP2_OK) return fail(h, rc, "no kernel instantiation for this robot");
+  HIP_TRY(h, hipGetLastError());
+  return RMP2_OK;
+}
+
+int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R, void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (!q || !T || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
+  if (R == 0 || h->n_frames == 0) return RMP2_OK;
+  const int blocks = (R + kWave - 1) / kWave;
+  hipStream_t s = (hipStream_t)stream;
+  switch (h->n_slots) {
+    case 0: hipLaunchKernelGGL((rmp2_fk_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
+    case 1: hipLaunchKernelGGL((rmp2_fk_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
+    default: hipLaunchKernelGGL((rmp2_fk_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return RMP2_OK;
+}
+
+int rmp2_differentiate(rmp2_handle* h, const float* q, const float* qd, int32_t frame, float* x, float* xd, float* J,
+                       float* c, int32_t R, void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (!q || !qd || !x || !xd || !J || !c || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
+  if (frame < 0 || frame >= h->n_frames) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "frame out of range");
+  if (R == 0) return RMP2_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if ((size_t)R > h->scratch_robots) {  // setup-time style allocation, grows monotonically (not on the hot path)
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
+    h->d_scratch = nullptr;
+    h->scratch_robots = 0;
+    HIP_TRY(h, hipMalloc(&h->d_scratch, sizeof(float) * 6 * RMP2_MAX_DOF * (size_t)R));
+    h->scratch_robots = (size_t)R;
+  }
+  const int blocks = (R + kWave - 1) / kWave;
+  switch (h->n_slots) {
+    case 0:
+      hipLaunchKernelGGL((rmp2_diff_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+                         h->d_scratch, R);
+      break;
+    case 1:
+      hipLaunchKernelGGL((rmp2_diff_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+                         h->d_scratch, R);
+      break;
+    default:
+      hipLaunchKernelGGL((rmp2_diff_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+                         h->d_scratch, R);
+      break;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return RMP2_OK;
+}
+
+}  // extern "C"

@@ -73,6 +73,16 @@ def main():
     # ---- config 1: TwoJoint target-only; robot 0 is the rank-1 start pose q = [0, 0] -------
     t1, d1 = Cf.config1()
     s = Cf.sample_two_joint_states(rng, R + 1)
+    # keep away from the arm's kinematic singularity sin(q2) = 0, where J^T A J is (nearly) rank
+    # deficient and the reference's own fp32 -> fp64 pinv result is rounding noise;
+    # the EXACTLY singular start pose is covered separately by robot 0 below.
+    for _ in range(100):
+        bad = np.abs(np.sin(s["q"][:, 1])) < 0.2
+        if not bad.any():
+            break
+        fresh = Cf.sample_two_joint_states(rng, int(bad.sum()))
+        for k in s:
+            s[k][bad] = fresh[k]
     s["q"][0] = 0.0
     s["qd"][0] = 0.0
     s["goal"][0] = [1.4, -1.4, 0.1]  # experiments/two_joint_robot/01_target_rmp_only.py:28
