@@ -290,19 +290,16 @@ __device__ __forceinline__ constexpr int sym_idx(int i, int j) {
 template <int N>
 __device__ __forceinline__ void pull_position(const float (&col)[N][3], uint32_t active, const float S[6],
                                               const float h[3], double (&Ms)[N * (N + 1) / 2], double (&fv)[N]) {
-  float t[N][3];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    t[j][0] = S[0] * col[j][0] + S[1] * col[j][1] + S[2] * col[j][2];
-    t[j][1] = S[1] * col[j][0] + S[3] * col[j][1] + S[4] * col[j][2];
-    t[j][2] = S[2] * col[j][0] + S[4] * col[j][1] + S[5] * col[j][2];
-  }
+    if (!((active >> j) & 1u)) continue;  // wave-uniform: dof j does not move this frame
+    fv[j] += (double)dot3(col[j], h);
+    const float t[3] = {S[0] * col[j][0] + S[1] * col[j][1] + S[2] * col[j][2],
+                        S[1] * col[j][0] + S[3] * col[j][1] + S[4] * col[j][2],
+                        S[2] * col[j][0] + S[4] * col[j][1] + S[5] * col[j][2]};
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    if (!((active >> i) & 1u)) continue;  // wave-uniform: dof i does not move this frame
-    fv[i] += (double)dot3(col[i], h);
-#pragma unroll
-    for (int j = i; j < N; ++j) Ms[sym_idx<N>(i, j)] += (double)dot3(col[i], t[j]);
+    for (int i = 0; i <= j; ++i)
+      if ((active >> i) & 1u) Ms[sym_idx<N>(i, j)] += (double)dot3(col[i], t);
   }
 }
 

@@ -28,15 +28,17 @@ namespace {
 //   [64*N, 128*N)        qd tile                                  stride-N lane reads: N odd -> no conflicts
 //   [128*N, 128*N+6*N*64) per-dof world axis z_j and joint origin o_j, component-major
 //                         ((j*6+c)*64 + lane): lane-private columns, conflict free
+//   [.., +64*N)           qdd tile (written right after the resolve, stored coalesced at the end)
 template <int N>
 struct Lds {
   static constexpr int kQ = 0;
   static constexpr int kQd = kWave * N;
   static constexpr int kZo = 2 * kWave * N;
-  static constexpr int kFloats = 2 * kWave * N + 6 * N * kWave;
+  static constexpr int kOut = 2 * kWave * N + 6 * N * kWave;  // qdd tile, robot-major (stride n_dof)
+  static constexpr int kFloats = 3 * kWave * N + 6 * N * kWave;
 };
 
-template <int N, int SLOTS>
+template <int N, int SLOTS, bool STRICT>
 __global__ void __launch_bounds__(kWave)
 rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const float* __restrict__ qd,
                  const float* __restrict__ goal, int goal_stride, ObsArgs obs, OutArgs out, int R) {
@@ -69,17 +71,18 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
   float* zo = &lds[Lds<N>::kZo + lane];
   const float* my_goal = goal ? goal + (size_t)(live ? robot : 0) * goal_stride : nullptr;
   const uint32_t rev_mask = prog->rev_mask;
-  const int solve_mode = prog->solve_mode;
 
-  double x[N];        // resolved qdd
+  float* my_out = &lds[Lds<N>::kOut + lane * n_dof];
   uint32_t status = 0u;
   bool singular = false;
 
-  // pass 0: accumulate + LU.  pass 1 (only when some lane of the wave needs it, or in PINV
-  // mode): accumulate again + Jacobi pseudo-inverse.  The loop keeps ONE copy of the
-  // accumulation code.
+  // AUTO build (STRICT = false): pass 0 = accumulate + fp64 LU.  Only when some lane of the
+  // wave turns out (numerically) singular a second pass re-accumulates and resolves those
+  // lanes with the compact pseudo-inverse (rare path, scratch memory, deliberately not
+  // unrolled so that it costs the common path no registers and ~no code).
+  // STRICT build (solve_mode = PINV): one pass, register-resident Jacobi pseudo-inverse.
 #pragma nounroll
-  for (int pass = (solve_mode == RMP2_SOLVE_PINV) ? 1 : 0; pass < 2; ++pass) {
+  for (int pass = STRICT ? 1 : 0; pass < 2; ++pass) {
     double Ms[N * (N + 1) / 2];  // upper triangle of the FK-leaf part (always symmetric)
     double fv[N];
 #pragma unroll
@@ -242,12 +245,10 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
     for (int i = 0; i < N; ++i)
 #pragma unroll
       for (int j = 0; j < N; ++j) A[i][j] = Ms[sym_idx<N>(i < j ? i : j, i < j ? j : i)];
-    float ql[N], qdl[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      ql[i] = my_q[i];
-      qdl[i] = my_qd[i];
-    }
+    // q / qd are re-read from the LDS tile where needed (keeps them out of the VGPR budget
+    // while the 81 fp64 accumulators are live)
+#define ql my_q
+#define qdl my_qd
     const int n_id = prog->n_id_leaves;
     for (int li = 0; li < n_id; ++li) {
       const DevLeaf& lf = prog->leaves[prog->id_leaves[li]];
@@ -388,8 +389,10 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
       }
     }
 
+#undef ql
+#undef qdl
     // optional debug outputs: the combined metric / force before the resolve
-    if (pass == ((solve_mode == RMP2_SOLVE_PINV) ? 1 : 0) && live) {
+    if (pass == (STRICT ? 1 : 0) && live) {
       if (out.M) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -409,35 +412,58 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
       if (i >= n_dof) A[i][i] = 1.0;
 
     // ---- resolve   rmp.py:153-154 -----------------------------------------------------
-    if (pass == 0) {
-      singular = lu_solve<N>(A, fv, x);
-      if (!__any(singular && live)) break;
-    } else {
-      double xp[N];
-      const int dropped = pinv_solve<N>(A, fv, n_dof, xp);
-      const bool use = (solve_mode == RMP2_SOLVE_PINV) || singular;
-      if (use) {
+    // The result goes straight to the LDS output tile so that no fp64 result registers stay
+    // live across a second pass.
+    if (STRICT) {
+      double x[N];
+      const int dropped = pinv_solve<N>(A, fv, n_dof, x);
+      if (dropped) status |= RMP2_STATUS_RANK_DROP;
+      bool finite = true;
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = xp[i];
-        if (dropped) status |= RMP2_STATUS_RANK_DROP;
-        if (solve_mode != RMP2_SOLVE_PINV) status |= RMP2_STATUS_PINV_PATH;
+      for (int i = 0; i < N; ++i)
+        if (i < n_dof) {
+          finite = finite && (fabs(x[i]) < 1.7e308);
+          my_out[i] = (float)x[i];
+        }
+      if (!finite) status |= RMP2_STATUS_NONFINITE;
+    } else if (pass == 0) {
+      double x[N];
+      singular = lu_solve<N>(A, fv, x);
+      bool finite = true;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i < n_dof) {
+          finite = finite && (fabs(x[i]) < 1.7e308);
+          my_out[i] = (float)x[i];
+        }
+      singular = singular || !finite;  // let the careful path have a look before reporting NaN/Inf
+      if (!__any(singular && live)) break;
+    } else if (singular) {
+      double W[N * (N + 1)], T[N * (N + 1)], xp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) W[i * (N + 1) + j] = A[i][j];
+        W[i * (N + 1) + N] = fv[i];
       }
+      status |= RMP2_STATUS_PINV_PATH;
+      if (!lu_pivot_compact(W, T, N, xp)) {
+        const int dropped = pinv_solve_compact(W, N, n_dof, xp);
+        if (dropped) status |= RMP2_STATUS_RANK_DROP;
+      }
+      bool finite = true;
+      for (int i = 0; i < n_dof; ++i) {
+        finite = finite && (fabs(xp[i]) < 1.7e308);
+        my_out[i] = (float)xp[i];
+      }
+      if (!finite) status |= RMP2_STATUS_NONFINITE;
     }
   }
 
-  // ---- coalesced store of the qdd tile through LDS -------------------------------------------
-  bool finite = true;
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    if (i < n_dof) finite = finite && (fabs(x[i]) < 1.7e308);
-  if (!finite) status |= RMP2_STATUS_NONFINITE;
-  __syncthreads();
-  float* tile = &lds[Lds<N>::kQ];
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    if (i < n_dof) tile[lane * n_dof + i] = (float)x[i];
+  // ---- coalesced store of the qdd tile ----------------------------------------------------
   __syncthreads();
   {
+    const float* tile = &lds[Lds<N>::kOut];
     const int count = min(kWave, R - r0) * n_dof;
     float* go = out.qdd + (size_t)r0 * n_dof;
     for (int i = lane; i < count; i += kWave) go[i] = tile[i];
@@ -576,6 +602,7 @@ struct rmp2_handle {
   int n_dof = 0, n_frames = 0, n_slots = 0, n_leaves = 0, goal_floats = 0;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
+  bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
   std::vector<int> distance_leaves;
   DevProgram* d_prog = nullptr;
   int32_t* d_pair_begin = nullptr;
@@ -728,23 +755,30 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   return RMP2_OK;
 }
 
-template <int N, int SLOTS>
+template <int N, int SLOTS, bool STRICT>
 void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                  const OutArgs& out, int R, hipStream_t s) {
   const int blocks = (R + kWave - 1) / kWave;
-  hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs, o, out,
+  hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs, o, out,
                      R);
 }
 
-template <int N>
+template <int N, bool STRICT>
 int dispatch_slots(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                    const OutArgs& out, int R, hipStream_t s) {
   switch (h->n_slots) {
-    case 0: launch_step<N, 0>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
-    case 1: launch_step<N, 1>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
-    case 2: launch_step<N, 2>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 0: launch_step<N, 0, STRICT>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 1: launch_step<N, 1, STRICT>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 2: launch_step<N, 2, STRICT>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
     default: return RMP2_ERR_UNSUPPORTED;
   }
+}
+
+template <int N>
+int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                   const OutArgs& out, int R, hipStream_t s) {
+  return h->strict ? dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s)
+                   : dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
 }
 
 }  // namespace
@@ -786,6 +820,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->n_leaves = desc->n_leaves;
   h->goal_floats = desc->goal_floats;
   h->n_template = h->n_dof <= 2 ? 2 : 9;
+  h->strict = desc->solve_mode == RMP2_SOLVE_PINV;
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();
@@ -864,9 +899,9 @@ int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal
   OutArgs oa{out->qdd, out->status, out->M, out->f};
   int rc;
   if (h->n_template == 2)
-    rc = dispatch_slots<2>(h, q, qd, goal, goal_stride, o, oa, R, s);
+    rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, R, s);
   else
-    rc = dispatch_slots<9>(h, q, qd, goal, goal_stride, o, oa, R, s);
+    rc = dispatch_solve<9>(h, q, qd, goal, goal_stride, o, oa, R, s);
   if (rc != RMP2_OK) return fail(h, rc, "no kernel instantiation for this robot");
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;
