@@ -73,11 +73,12 @@ def main():
     # ---- config 1: TwoJoint target-only; robot 0 is the rank-1 start pose q = [0, 0] -------
     t1, d1 = Cf.config1()
     s = Cf.sample_two_joint_states(rng, R + 1)
-    # keep away from the arm's kinematic singularity sin(q2) = 0, where J^T A J is (nearly) rank
-    # deficient and the reference's own fp32 -> fp64 pinv result is rounding noise;
+    # keep cond(J^T A J) <= 100: near the arm's kinematic singularity sin(q2) = 0 the metric is (nearly)
+    # rank deficient and the reference's own fp32 -> fp64 pinv result is rounding noise;
     # the EXACTLY singular start pose is covered separately by robot 0 below.
-    for _ in range(100):
-        bad = np.abs(np.sin(s["q"][:, 1])) < 0.2
+    for _ in range(200):
+        Mx = O.step(d1, s["q"], s["qd"], s["goal"], precision="f64")["M"]
+        bad = np.array([np.linalg.cond(m) > 100.0 for m in Mx])
         if not bad.any():
             break
         fresh = Cf.sample_two_joint_states(rng, int(bad.sum()))
@@ -133,6 +134,15 @@ def main():
             sph[:, :2] *= 2.0
             sph[:, 2] = 0.1 + 0.3 * rng.uniform(-1, 1, len(sph)).astype(np.float32)
         st = redraw_until_clear(rng, sampler, desc, tab, sph, 32)
+        if key == "tj":  # no damping leaf in this set: keep cond(M) <= 100 as for config 1
+            for _ in range(200):
+                Mx = O.step(desc, st["q"], st["qd"], st["goal"], spheres=sph, precision="f64")["M"]
+                bad = np.array([np.linalg.cond(m) > 100.0 for m in Mx])
+                if not bad.any():
+                    break
+                fresh = redraw_until_clear(rng, sampler, desc, tab, sph, int(bad.sum()))
+                for k2 in st:
+                    st[k2][bad] = fresh[k2]
         off, idx = Cf.sample_ragged(rng, 32, len(sph))
         lists = [idx[off[r]:off[r + 1]] for r in range(32)]
         lists[0] = lists[0][:0]        # k_r = 0 edge case: robot 0 sees no obstacle
