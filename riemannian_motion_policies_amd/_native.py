@@ -11,7 +11,7 @@ import os
 from . import descriptor as D
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librmp2_hip.so")
+LIB_PATH = os.environ.get("RMP2_LIB", os.path.join(_PKG, "librmp2_hip.so"))  # RMP2_LIB: diagnostic builds only
 
 _lib = None
 

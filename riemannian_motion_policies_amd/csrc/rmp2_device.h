@@ -37,15 +37,30 @@ struct DevOp {
   int32_t leaf_begin, leaf_count;  // range in DevProgram::fk_leaves
   float axis[3];
   float Tc[12];
+  int32_t pad_;  // 96 bytes: 16-byte multiples so that the program can be staged with dwordx4 copies
 };
 
 struct DevLeaf {
+  // head: fetched with ONE 64-byte scalar load (s_load_dwordx16)
   int32_t kind, taskmap, frame, goal_offset;
-  int32_t index;  // leaf index in the caller's descriptor (pair_begin is indexed by it)
   float P[RMP2_MAX_PARAMS];
   float va[RMP2_MAX_DOF];
   float vb[RMP2_MAX_DOF];
+  int32_t index;  // leaf index in the caller's descriptor (pair_begin is indexed by it)
+  int32_t pad_[3];  // 208 bytes
 };
+// the 64-byte head of a leaf / the 32-byte control block of an op, as value types: copying
+// them makes the compiler issue one wide scalar load instead of one dependent s_load per field
+struct LeafHead {
+  int32_t kind, taskmap, frame, goal_offset;
+  float P[RMP2_MAX_PARAMS];
+};
+struct OpCtl {
+  int32_t frame, restore, save, jtype, qidx;
+  uint32_t anc_mask;
+  int32_t leaf_begin, leaf_count;
+};
+static_assert(sizeof(DevOp) % 16 == 0 && sizeof(DevLeaf) % 16 == 0, "program records must be 16-byte multiples");
 
 struct DevProgram {
   int32_t n_ops, n_dof, n_frames, n_leaves;

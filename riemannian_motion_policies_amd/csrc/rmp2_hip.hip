@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -15,6 +16,7 @@
 
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
+#include "rmp2_quad.h"
 
 using namespace rmp2;
 
@@ -602,7 +604,10 @@ struct rmp2_handle {
   int n_dof = 0, n_frames = 0, n_slots = 0, n_leaves = 0, goal_floats = 0;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
+  int n_id_leaves = 0;
+  uint32_t rev_mask = 0;
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
+  int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot (env RMP2_KERNEL=lane|quad, A/B only)
   std::vector<int> distance_leaves;
   DevProgram* d_prog = nullptr;
   int32_t* d_pair_begin = nullptr;
@@ -720,6 +725,16 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     std::memcpy(t.P, s.params, sizeof(t.P));
     std::memcpy(t.va, s.vec_a, sizeof(t.va));
     std::memcpy(t.vb, s.vec_b, sizeof(t.vb));
+    if (s.kind == RMP2_LEAF_OBSTACLE_AVOIDANCE) {
+      // reciprocals of the length scales, formed in double (used by the quad kernel's pair loop)
+      const double estd = s.params[9], rstd = s.params[6], dstd = s.params[2], glen = s.params[4], rad = s.params[7];
+      t.vb[0] = (float)(1.0 / estd);
+      t.vb[1] = (float)(1.0 / rstd);
+      t.vb[2] = (float)(1.0 / dstd);
+      t.vb[3] = (float)(1.0 / glen);
+      t.vb[4] = (float)(1.0 / (rad * rad));
+      t.vb[5] = (float)(2.0 / rad);
+    }
     int goal_len = 0;
     bool ok = false;
     switch (s.taskmap) {
@@ -774,11 +789,33 @@ int dispatch_slots(const rmp2_handle* h, const float* q, const float* qd, const 
   }
 }
 
+template <int N, int SLOTS>
+void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                 const OutArgs& out, int R, hipStream_t s) {
+  const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames);
+  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->rev_mask};
+  hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q, qd,
+                     goal, gs, o, out, R);
+}
+
 template <int N>
 int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                    const OutArgs& out, int R, hipStream_t s) {
-  return h->strict ? dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s)
-                   : dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
+  if (h->strict) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
+  // Kernel choice (both produce the same numbers to fp32 rounding):
+  //  * quad-per-robot: shortest dependent chain and 4x the waves -- wins whenever the fleet cannot
+  //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
+  //    splits 4 ways);
+  //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
+  const bool lane = h->kernel_choice == 1 || (h->kernel_choice == 0 && !h->has_distance && R > 16384);
+  if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
+  switch (h->n_slots) {
+    case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 1: launch_quad<N, 1>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 2: launch_quad<N, 2>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    default: return RMP2_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace
@@ -821,6 +858,12 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->goal_floats = desc->goal_floats;
   h->n_template = h->n_dof <= 2 ? 2 : 9;
   h->strict = desc->solve_mode == RMP2_SOLVE_PINV;
+  h->n_id_leaves = P.n_id_leaves;
+  h->rev_mask = P.rev_mask;
+  {
+    const char* kenv = std::getenv("RMP2_KERNEL");
+    h->kernel_choice = !kenv ? 0 : (std::strcmp(kenv, "lane") == 0 ? 1 : (std::strcmp(kenv, "quad") == 0 ? 2 : 0));
+  }
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();

@@ -1,0 +1,889 @@
+// rmp2_quad.h -- the production control-step kernel: FOUR LANES (one DPP quad) PER ROBOT.
+//
+// Why a quad: at the fleet sizes that matter (4 096 .. 65 536 robots per GPU) a
+// lane-per-robot mapping gives at most one wave per SIMD and every step is one long dependent
+// instruction stream (measured: 22 us for the 3-leaf Panda set, 183 us for the cluttered set,
+// identical at R = 4 096 and R = 65 536 -- pure latency).  Spreading one robot over a quad
+//   * shortens that stream 3-4x (each lane does a quarter of the pair loop, a third of the
+//     vector algebra of the tree walk, a third of the rows of the metric and of the LU),
+//   * gives 4x more waves to fill the 1024 SIMDs, and
+//   * keeps all cross-lane traffic on DPP quad_perm moves (full-rate VALU, no LDS, no
+//     ds_bpermute): broadcasts of a pivot row, 3-vector gathers, 4-lane butterfly sums.
+//
+// Lane roles inside a quad (sub = lane & 3):
+//   tree walk      sub 0..2 carry the x/y/z COMPONENT of every world vector (p, w, alpha, v, a,
+//                  joint axis) and ROW sub of the world rotation; cross products fetch the two
+//                  other components with quad rotations.  sub 3 idles through the walk.
+//   pair loop      sphere / pair b is handled by sub = b & 3; the 3x3 metric sum S and the force
+//                  sum h are combined with a 2-step xor butterfly.
+//   metric, LU     row i of the n x n fp64 system lives in lane sub = i & 3 (local row i >> 2);
+//                  elimination step k broadcasts row k from its owner.
+//
+// Numerics: fp32 leaves / Jacobians / pull-back products, fp64 accumulation and resolve, as in
+// the reference (rmp.py:136-154).  Reciprocals, rsqrt and exp in the per-pair code use the
+// hardware approximations refined to <= 1 ulp (Newton step / compensated argument); sin/cos
+// use a Cody-Waite + minimax kernel (<= 1 ulp for |q| <= 8192, ocml beyond).
+#pragma once
+#include "rmp2_device.h"
+#include "rmp2_solve.h"
+
+namespace rmp2 {
+
+constexpr int kQuad = 4;
+constexpr int kRobotsPerWave = kWave / kQuad;  // 16
+constexpr int kLdsSpheres = 256;               // sphere table staged in LDS up to this size
+
+// ---- DPP quad permutes -----------------------------------------------------------------
+constexpr int quad_perm(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int kBcast0 = quad_perm(0, 0, 0, 0), kBcast1 = quad_perm(1, 1, 1, 1), kBcast2 = quad_perm(2, 2, 2, 2),
+              kBcast3 = quad_perm(3, 3, 3, 3);
+constexpr int kRot1 = quad_perm(1, 2, 0, 3);  // lane i reads component (i+1) % 3
+constexpr int kRot2 = quad_perm(2, 0, 1, 3);  // lane i reads component (i+2) % 3
+constexpr int kXor1 = quad_perm(1, 0, 3, 2), kXor2 = quad_perm(2, 3, 0, 1);
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dppd(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int S>
+__device__ __forceinline__ float bcast(float v) {
+  return dpp<S * 0x55>(v);
+}
+template <int S>
+__device__ __forceinline__ double bcastd(double v) {
+  return dppd<S * 0x55>(v);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp<kXor1>(v);
+  v += dpp<kXor2>(v);
+  return v;
+}
+
+// ---- refined hardware approximations ------------------------------------------------------
+__device__ __forceinline__ float rcp1(float x) {  // 1/x, one Newton step on v_rcp_f32
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float rsq1(float x) {  // 1/sqrt(x), one Newton step on v_rsq_f32
+  float r = __builtin_amdgcn_rsqf(x);
+  const float e = fmaf(-x * r, r, 1.0f);
+  return fmaf(0.5f * e, r, r);
+}
+__device__ __forceinline__ float rcp0(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+__device__ __forceinline__ float rsq0(float x) { return __builtin_amdgcn_rsqf(x); }   // 1 ulp
+__device__ __forceinline__ float exp1(float x) {  // e^x: v_exp_f32 on a compensated x*log2(e)
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+  const float ph = x * L2E_HI;
+  const float pl = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -ph));
+  const float e = __builtin_amdgcn_exp2f(ph);
+  return fmaf(e, pl * 0.693147182464599609375f, e);
+}
+// sin and cos, |x| <= 8192: 3-term Cody-Waite reduction by pi/2 + degree-7/6 minimax kernels
+__device__ __forceinline__ void sincos1(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.636619746685028076171875f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.37113900018624283e-8f, r);
+  r = fmaf(-k, -1.71512449810525e-15f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                        z * z, fmaf(-0.5f, z, 1.0f));
+  const int n = (int)k;
+  const float s0 = (n & 1) ? pc : ps;
+  const float c0 = (n & 1) ? ps : pc;
+  sn = (n & 2) ? -s0 : s0;
+  cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
+__device__ __forceinline__ double rcpd(double x) {  // 1/x in fp64: v_rcp_f64 + two Newton steps (full precision)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ---- leaves, fast-math flavour (same formulas as rmp2_device.h) --------------------------------
+// rmp2.py:183-196; IP = host-precomputed reciprocals {1/estd, 1/rstd, 1/dstd, 1/gate_len, 1/radius^2, 2/radius}
+__device__ __forceinline__ void obstacle_pair(const float* P, const float* IP, float x,
+                                              float xd, float& accel, float& metric) {
+  x = fmaxf(x - P[0], 0.0f);
+  const float base = P[8] * rcp0(fmaf(x, IP[0], P[10]));
+  const float gate = fmaf(x * x, IP[4], fmaf(-x, IP[5], 1.0f));
+  const float repel = P[5] * exp1(-(x * IP[1]));
+  const float oms = 1.0f - rcp0(1.0f + exp1(-(xd * IP[3])));  // 1 - sigmoid
+  const float damp = -oms * P[1] * xd * rcp0(fmaf(x, IP[2], P[3]));
+  accel = repel + damp;
+  metric = (x > P[7]) ? 0.0f : oms * (base * gate);
+}
+
+// rmp2.py:52-83 with refined hardware reciprocals / exp
+__device__ __forceinline__ void target_attractor_fast(const float* P, const float x[3], const float xd[3],
+                                                      const float g[3], float xdd[3], float A[6]) {
+  const float kp = P[0], kd = P[1], eps = P[2], ell = P[3], amin = P[4], smax = P[5], smin = P[6], sb = P[7],
+              ellb = P[8];
+  float delta[3], dhat[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) delta[i] = g[i] - x[i];
+  const float d2 = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
+  const float dn = d2 > 0.f ? d2 * rsq1(d2) : 0.f;
+  const float isoft = rcp1(fmaxf(dn, eps / 10.0f));
+  const float ipe = rcp1(dn + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dhat[i] = delta[i] * isoft;
+    xdd[i] = kp * delta[i] * ipe - kd * xd[i];
+  }
+  const float sd = dn * rcp1(ell);
+  const float a = (1.0f - amin) * exp1(-0.5f * sd * sd) + amin;
+  const float bsd = dn * rcp1(ellb);
+  const float ba = exp1(-0.5f * bsd * bsd);
+  const float boost = ba * sb + (1.0f - ba) * 1.0f;
+  const float wI = a * smax, wS = (1.0f - a) * smin;
+  A[0] = boost * (wI + wS * (dhat[0] * dhat[0]));
+  A[1] = boost * (wS * (dhat[0] * dhat[1]));
+  A[2] = boost * (wS * (dhat[0] * dhat[2]));
+  A[3] = boost * (wI + wS * (dhat[1] * dhat[1]));
+  A[4] = boost * (wS * (dhat[1] * dhat[2]));
+  A[5] = boost * (wI + wS * (dhat[2] * dhat[2]));
+}
+
+// ---- the pair loop of one distance leaf, one instantiation per obstacle mode ----------------------
+constexpr int kPairsExplicit = 0, kPairsSharedLds = 1, kPairsSharedGlobal = 2, kPairsRaggedLds = 3,
+              kPairsRaggedGlobal = 4;
+
+template <int MODE>
+__device__ __forceinline__ void pair_loop(const float* sph, const float* pl, const float* po, const int32_t* ci,
+                                          int count, int max_count, int sub, const float P3[3], const float V3[3],
+                                          const float A3[3], const float* P, const float* IP, float S[6], float h[3]) {
+  const float vv = dot3(V3, V3);
+  const int trips = (max_count + kQuad - 1) / kQuad;  // wave-uniform trip count
+  // the obstacle record of the NEXT trip is fetched while the current one is evaluated
+  auto fetch = [&](int t, float4& a, float4& b2) {
+    const int b_raw = kQuad * t + sub;
+    const int b = b_raw < count ? b_raw : 0;  // masked-off lanes re-read pair 0 (in bounds whenever count > 0)
+    if (MODE == kPairsExplicit) {
+      if (count > 0) {
+        a = make_float4(pl[3 * b], pl[3 * b + 1], pl[3 * b + 2], 0.f);
+        b2 = make_float4(po[3 * b], po[3 * b + 1], po[3 * b + 2], 0.f);
+      } else {
+        a = make_float4(1.f, 1.f, 1.f, 0.f);
+        b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      int sidx = b;
+      if (MODE == kPairsRaggedLds || MODE == kPairsRaggedGlobal) sidx = (b_raw < count) ? ci[b] : 0;
+      a = reinterpret_cast<const float4*>(sph)[sidx];
+    }
+  };
+  float4 na, nb;
+  fetch(0, na, nb);
+#pragma unroll 2
+  for (int t = 0; t < trips; ++t) {
+    float nh[3], d;
+    const bool on = kQuad * t + sub < count;
+    const float4 ca = na, cb = nb;
+    fetch(min(t + 1, trips - 1), na, nb);
+    if (MODE == kPairsExplicit) {
+      // taskmap.py:124-129: rel = stop_gradient(p_link - p_joint); crit = p_joint + rel
+      const float plk[3] = {ca.x, ca.y, ca.z}, pob[3] = {cb.x, cb.y, cb.z};
+      float diff[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float rel = plk[c] - P3[c];
+        const float crit = P3[c] + rel;
+        diff[c] = crit - pob[c];
+      }
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const float inv = rsq0(d2);
+      d = d2 * inv;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nh[c] = diff[c] * inv;
+    } else {
+      const float diff[3] = {P3[0] - ca.x, P3[1] - ca.y, P3[2] - ca.z};
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const float inv = rsq0(d2);
+      d = d2 * inv - ca.w;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nh[c] = diff[c] * inv;
+    }
+    const float xdot = dot3(nh, V3);
+    const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+    float acc, met;
+    obstacle_pair(P, IP, d, xdot, acc, met);
+    if (!on) met = 0.f;
+    const float wgt = met * (acc - cd);
+    const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+    S[0] = fmaf(mn[0], nh[0], S[0]);
+    S[1] = fmaf(mn[0], nh[1], S[1]);
+    S[2] = fmaf(mn[0], nh[2], S[2]);
+    S[3] = fmaf(mn[1], nh[1], S[3]);
+    S[4] = fmaf(mn[1], nh[2], S[4]);
+    S[5] = fmaf(mn[2], nh[2], S[5]);
+    h[0] = fmaf(wgt, nh[0], h[0]);
+    h[1] = fmaf(wgt, nh[1], h[1]);
+    h[2] = fmaf(wgt, nh[2], h[2]);
+  }
+}
+
+// ---- the kernel -------------------------------------------------------------------------------
+template <int N>
+struct QuadLds {
+  static constexpr int kQ = 0;                                 // [16][N]
+  static constexpr int kQd = kRobotsPerWave * N;               // [16][N]
+  static constexpr int kZo = 2 * kRobotsPerWave * N;           // [N*6][16]
+  static constexpr int kOut = kZo + 6 * N * kRobotsPerWave;    // [16][n_dof]
+  static constexpr int kSph = kOut + kRobotsPerWave * N;       // [kLdsSpheres][4]
+  static constexpr int kLoc = kSph + 4 * kLdsSpheres;          // [16 robots][n_ops][16]: Rl(9) tl(3) zl(3) pad
+  static constexpr int kFloats = kLoc;                         // + 16*16*n_ops floats of dynamic LDS
+};
+
+// header of the program, passed BY VALUE as a kernel argument (lands in SGPRs with the kernarg
+// preload: the prologue needs no dependent round trip before it can issue the tile loads)
+struct QuadHdr {
+  int32_t n_ops, n_dof, n_id;
+  uint32_t rev_mask;
+};
+
+__device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * 16 * n_ops; }
+
+// walk state of one lane: component `sub` of the world vectors, row `sub` of the rotation
+struct QuadState {
+  float R[3];
+  float p, w, al, v, a;
+};
+
+template <int N, int SLOTS>
+__global__ void __launch_bounds__(kWave, 2)
+rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
+                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
+                      OutArgs out, int R) {
+  constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
+  // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats]
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef RMP2_STAMPS
+  // diagnostic build only: shader-clock stamps per phase, written to a buffer nothing else reads
+  unsigned long long st_[8];
+  unsigned long long stx_[4] = {0, 0, 0, 0};
+  int st_n = 0;
+#define RMP2_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[st_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RMP2_STAMP() do {} while (0)
+#endif
+  RMP2_STAMP();
+  const int lane = threadIdx.x;
+  const int sub = lane & 3;
+  const int g = lane >> 2;
+  const int r0 = blockIdx.x * kRobotsPerWave;
+  const int robot = r0 + g;
+  const bool live = robot < R;
+  const int n_dof = hdr.n_dof;
+
+  // ---- stage the q / qd tile (coalesced) and the sphere table in LDS --------------------------
+  const int n_ops = hdr.n_ops, n_id = hdr.n_id;
+  const uint32_t rev_mask = hdr.rev_mask;
+  const int n_live = min(kRobotsPerWave, R - r0);
+  {
+    const int tile = n_live * n_dof;
+    const float* gq = q + (size_t)r0 * n_dof;
+    const float* gqd = qd + (size_t)r0 * n_dof;
+    for (int i = lane; i < tile; i += kWave) {
+      const int rr = i / n_dof, jj = i - rr * n_dof;
+      lds[QuadLds<N>::kQ + rr * N + jj] = gq[i];
+      lds[QuadLds<N>::kQd + rr * N + jj] = gqd[i];
+    }
+    if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
+      const int nf = 4 * min(obs.n_spheres, kLdsSpheres);
+      for (int i = lane; i < nf; i += kWave) lds[QuadLds<N>::kSph + i] = obs.spheres[i];
+    }
+    __syncthreads();
+  }
+  RMP2_STAMP();  // 1: prologue done
+  // quads beyond the fleet's tail re-use the last live robot's inputs (results are discarded)
+  const int gi = min(g, n_live - 1);
+  const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
+  const float* my_q = &lds[QuadLds<N>::kQ + gi * N];
+  const float* my_qd = &lds[QuadLds<N>::kQd + gi * N];
+  float* zo = &lds[QuadLds<N>::kZo + g];
+  float* my_out = &lds[QuadLds<N>::kOut + g * n_dof];
+  const float* my_goal = goal ? goal + (size_t)(live ? robot : 0) * goal_stride : nullptr;
+  uint32_t status = 0u;
+  bool flagged = false;
+
+  // ---- phase 1: local transforms T_constant @ T_variable(q) of ALL frames, in parallel -------
+  // (kinematics.py:222-240).  They do not depend on the chain, so lane `sub` of the quad builds
+  // the frames k = sub, sub+4, ... (branch-free: the joint type selects by arithmetic) and
+  // leaves Rl (9), tl (3) and Rl @ axis (3) in LDS; the serial walk below only multiplies.
+  float* const loc = &lds[QuadLds<N>::kLoc + gi_loc(g, n_ops)];
+  for (int k = sub; k < n_ops; k += kQuad) {
+    const DevOp& opg = prog->ops[k];  // lane-dependent record: vector loads (L2 resident)
+    const int jt = opg.jtype, qi = opg.qidx;
+    const float qv = qi >= 0 ? my_q[qi] : 0.f;
+    const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
+    float sn = 0.f, cs = 1.f;
+    if (jt == RMP2_JOINT_REVOLUTE) {
+      if (fabsf(qv) <= 8192.0f)
+        sincos1(qv, sn, cs);
+      else
+        sincosf(qv, &sn, &cs);
+    }
+    const float omc = 1.0f - cs;
+    const bool rev = jt == RMP2_JOINT_REVOLUTE;
+    // Rodrigues: cos*I + sin*[u]x + (1-cos)*u u^T ; for non-revolute joints T_variable's rotation is I exactly
+    const float ut[9] = {0.f, -ax[2], ax[1], ax[2], 0.f, -ax[0], -ax[1], ax[0], 0.f};
+    float Rv[9], Tc[12], rec[16];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) Tc[c] = opg.Tc[c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float e = (r == c) ? 1.f : 0.f;
+        Rv[3 * r + c] = rev ? cs * e + sn * ut[3 * r + c] + omc * (ax[r] * ax[c]) : e;
+      }
+    const float tq = (jt == RMP2_JOINT_PRISMATIC) ? qv : 0.f;
+    const float tv[3] = {tq * ax[0], tq * ax[1], tq * ax[2]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rec[3 * r + c] = Tc[4 * r + 0] * Rv[c] + Tc[4 * r + 1] * Rv[3 + c] + Tc[4 * r + 2] * Rv[6 + c];
+      rec[9 + r] = Tc[4 * r + 0] * tv[0] + Tc[4 * r + 1] * tv[1] + Tc[4 * r + 2] * tv[2] + Tc[4 * r + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) rec[12 + r] = rec[3 * r] * ax[0] + rec[3 * r + 1] * ax[1] + rec[3 * r + 2] * ax[2];
+    rec[15] = 0.f;
+    float4* dst = reinterpret_cast<float4*>(loc + 16 * k);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+  }
+  __syncthreads();
+
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
+    double A[ROWS][N];
+    double fv[ROWS];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      fv[m] = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[m][j] = 0.0;
+    }
+
+    // ---- tree walk (component layout) -----------------------------------------------------
+    QuadState cur;
+    QuadState slot[SLOTS > 0 ? SLOTS : 1];
+    // control words and local transforms are fetched ONE FRAME AHEAD (software pipelining): the
+    // walk is a serial dependency chain, any exposed scalar-load or LDS latency adds to it directly
+    OpCtl op_next = *reinterpret_cast<const OpCtl*>(&prog->ops[0]);
+    const float4* rec4n = reinterpret_cast<const float4*>(loc);
+    float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2], n3 = rec4n[3];
+    float qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
+    for (int k = 0; k < n_ops; ++k) {
+#ifdef RMP2_STAMPS
+      if (k >= 3 && k < 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stx_[k - 3] = __builtin_amdgcn_s_memtime(); }
+#endif
+      const OpCtl op = op_next;
+      const float4 r0_ = n0, r1_ = n1, r2_ = n2, r3_ = n3;
+      const float qdv = qd_next;
+      {
+        const int kn = min(k + 1, n_ops - 1);
+        op_next = *reinterpret_cast<const OpCtl*>(&prog->ops[kn]);
+        rec4n = reinterpret_cast<const float4*>(loc + 16 * kn);
+        n0 = rec4n[0];
+        n1 = rec4n[1];
+        n2 = rec4n[2];
+        n3 = rec4n[3];
+      }
+      const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
+      const float tl[3] = {r2_.y, r2_.z, r2_.w};
+      const float zl[3] = {r3_.x, r3_.y, r3_.z};
+      if (op.restore == -2) {
+        // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) cur.R[m] = (m == sub) ? 1.0f : 0.0f;
+        cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
+      } else if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.restore == s) cur = slot[s];
+      }
+      const int qi = op.qidx;
+      // world: my row of  R_parent @ R_local, my component of  R_parent @ t_local + p_parent
+      float Rn[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rn[c] = cur.R[0] * Rl[c] + cur.R[1] * Rl[3 + c] + cur.R[2] * Rl[6 + c];
+      const float pn = cur.R[0] * tl[0] + cur.R[1] * tl[1] + cur.R[2] * tl[2] + cur.p;
+      const float rr = pn - cur.p;
+      // world joint axis: R_parent @ (R_local @ axis)
+      const float z = cur.R[0] * zl[0] + cur.R[1] * zl[1] + cur.R[2] * zl[2];
+      // velocity / bias-acceleration recursion, one component per lane; (a x b)_i = a_{i+1} b_{i+2} - a_{i+2} b_{i+1}
+      const float w1 = dpp<kRot1>(cur.w), w2 = dpp<kRot2>(cur.w);
+      const float r1 = dpp<kRot1>(rr), r2 = dpp<kRot2>(rr);
+      const float a1 = dpp<kRot1>(cur.al), a2 = dpp<kRot2>(cur.al);
+      const float t1 = w1 * r2 - w2 * r1;  // w_p x r
+      const float t2 = a1 * r2 - a2 * r1;  // alpha_p x r
+      const float t1a = dpp<kRot1>(t1), t1b = dpp<kRot2>(t1);
+      const float t3 = w1 * t1b - w2 * t1a;  // w_p x (w_p x r)
+      float wn = cur.w, aln = cur.al, vn = cur.v + t1, an = cur.a + t2 + t3;
+      if (op.jtype != RMP2_JOINT_FIXED) {
+        const float zq = z * qdv;
+        const float zq1 = dpp<kRot1>(zq), zq2 = dpp<kRot2>(zq);
+        const float t4 = w1 * zq2 - w2 * zq1;  // w_p x (z qd)
+        if (op.jtype == RMP2_JOINT_REVOLUTE) {
+          wn += zq;
+          aln += t4;
+        } else {
+          vn += zq;
+          an += 2.0f * t4;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cur.R[c] = Rn[c];
+      cur.p = pn;
+      cur.w = wn;
+      cur.al = aln;
+      cur.v = vn;
+      cur.a = an;
+      if (qi >= 0 && op.jtype != RMP2_JOINT_FIXED && sub < 3) {
+        zo[(qi * 6 + sub) * kRobotsPerWave] = z;
+        zo[(qi * 6 + 3 + sub) * kRobotsPerWave] = pn;
+      }
+      if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.save == s) slot[s] = cur;
+      }
+      qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
+      if (op.leaf_count == 0) continue;
+
+      // ---- leaves attached to this frame ----------------------------------------------------
+      // full 3-vectors of the frame in every lane
+      const float P3[3] = {bcast<0>(cur.p), bcast<1>(cur.p), bcast<2>(cur.p)};
+      const float V3[3] = {bcast<0>(cur.v), bcast<1>(cur.v), bcast<2>(cur.v)};
+      const float A3[3] = {bcast<0>(cur.a), bcast<1>(cur.a), bcast<2>(cur.a)};
+      // Jacobian columns of the frame origin (all dofs; wave-uniform activity mask)
+      float col[N][3];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if ((op.anc_mask >> j) & 1u) {
+          const float zj[3] = {zo[(j * 6 + 0) * kRobotsPerWave], zo[(j * 6 + 1) * kRobotsPerWave],
+                               zo[(j * 6 + 2) * kRobotsPerWave]};
+          if ((rev_mask >> j) & 1u) {
+            const float d[3] = {P3[0] - zo[(j * 6 + 3) * kRobotsPerWave], P3[1] - zo[(j * 6 + 4) * kRobotsPerWave],
+                                P3[2] - zo[(j * 6 + 5) * kRobotsPerWave]};
+            cross3(zj, d, col[j]);
+          } else {
+            col[j][0] = zj[0];
+            col[j][1] = zj[1];
+            col[j][2] = zj[2];
+          }
+        } else {
+          col[j][0] = col[j][1] = col[j][2] = 0.f;
+        }
+      }
+      // the columns of MY rows (lane-dependent dof index -> dynamic LDS address)
+      float mycol[ROWS][3];
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m) {
+        const int i = sub + kQuad * m;
+        const bool act = (i < N) && ((op.anc_mask >> i) & 1u);
+        const int ii = act ? i : 0;
+        const float zj[3] = {zo[(ii * 6 + 0) * kRobotsPerWave], zo[(ii * 6 + 1) * kRobotsPerWave],
+                             zo[(ii * 6 + 2) * kRobotsPerWave]};
+        const float d[3] = {P3[0] - zo[(ii * 6 + 3) * kRobotsPerWave], P3[1] - zo[(ii * 6 + 4) * kRobotsPerWave],
+                            P3[2] - zo[(ii * 6 + 5) * kRobotsPerWave]};
+        float cr[3];
+        cross3(zj, d, cr);
+        const bool rev = (rev_mask >> ii) & 1u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rev ? cr[c] : zj[c]) : 0.f;
+      }
+
+      for (int li = 0; li < op.leaf_count; ++li) {
+        const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
+        const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte scalar load
+        const int lf_kind = lh.kind;
+        float S[6], h[3];
+        if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+          float gl[3], xdd[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
+          if (lf_kind == RMP2_LEAF_TARGET_ATTRACTOR)
+            target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
+          else
+            leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
+          const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
+          h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
+          h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
+          h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+        } else {
+          // distance leaf: this lane takes pairs b = sub, sub+4, ...; S and h are butterfly-summed.
+          // The obstacle mode is resolved OUTSIDE the loop (one straight-line loop body per mode).
+#pragma unroll
+          for (int c = 0; c < 6; ++c) S[c] = 0.f;
+          h[0] = h[1] = h[2] = 0.f;
+          const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
+          const float* sph_lds = &lds[QuadLds<N>::kSph];
+          if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
+            if (spheres_in_lds)
+              pair_loop<kPairsSharedLds>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3,
+                                         lh.P, IP, S, h);
+            else
+              pair_loop<kPairsSharedGlobal>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                            V3, A3, lh.P, IP, S, h);
+          } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+            const int lidx = lf.index;
+            const int pb = obs.pair_begin[lidx];
+            const int count = obs.pair_begin[lidx + 1] - pb;
+            const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
+            pair_loop<kPairsExplicit>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3, A3,
+                                      lh.P, IP, S, h);
+          } else {
+            const int b0 = obs.csr_offset[live ? robot : 0];
+            const int count = live ? obs.csr_offset[robot + 1] - b0 : 0;
+            int max_count = count;
+#pragma unroll
+            for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+            if (spheres_in_lds)
+              pair_loop<kPairsRaggedLds>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3, A3,
+                                         lh.P, IP, S, h);
+            else
+              pair_loop<kPairsRaggedGlobal>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3,
+                                            V3, A3, lh.P, IP, S, h);
+          }
+#pragma unroll
+          for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
+        }
+        // pull-back into MY rows:  f_i += col_i . h ;  A[i][j] += (S col_i) . col_j
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          const float u[3] = {S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2],
+                              S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2],
+                              S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2]};
+          fv[m] += (double)dot3(mycol[m], h);
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+            if ((op.anc_mask >> j) & 1u) A[m][j] += (double)dot3(u, col[j]);
+        }
+      }
+    }
+
+    RMP2_STAMP();  // 2: walk + FK leaves done
+    // ---- identity-task-map leaves (row layout) -------------------------------------------------
+    for (int li = 0; li < n_id; ++li) {
+      const DevLeaf& lfr = prog->leaves[prog->id_leaves[li]];
+      const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte scalar load
+      struct {
+        int kind, goal_offset;
+        const float* va;
+        const float* vb;
+      } lf = {lh.kind, lh.goal_offset, lfr.va, lfr.vb};
+      const float* P = lh.P;
+      if (lf.kind == RMP2_LEAF_JOINT_DAMPING || lf.kind == RMP2_LEAF_CSPACE_BIASING ||
+          lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {
+        // diagonal metrics m * I:  A_ii += m, f_i += m * xdd_i
+        float mdiag, nrm = 0.f;
+        if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {  // rmp2.py:127-137
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) s2 += my_qd[j] * my_qd[j];
+          nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+          mdiag = P[1] * nrm + P[2];
+        } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {  // rmp2.py:212-226
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float e = my_q[j] - lf.va[j];
+            s2 += e * e;
+          }
+          nrm = sqrtf(s2);
+          mdiag = P[0] + P[4];
+        } else {  // rmp.py:330-347
+          mdiag = P[2];
+        }
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          const int i = sub + kQuad * m;
+          const int ii = i < N ? i : 0;
+          const float qi_ = my_q[ii], qdi = my_qd[ii];
+          float acc;
+          if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {
+            acc = -(P[0] * nrm) * qdi;
+          } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {
+            const float e = qi_ - lf.va[ii];
+            const float pos = (nrm < P[3]) ? (-e * P[1]) : (-P[3] * (e / nrm) * P[1]);
+            acc = pos + (-P[2] * qdi);
+          } else {
+            acc = P[0] * (lf.va[ii] - qi_) - P[1] * qdi;
+          }
+          fv[m] += (double)(mdiag * acc);
+        }
+        // A_jj += m: column j's diagonal lives in local row j >> 2 of lane sub == (j & 3)
+        const double dm = (double)mdiag;
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[j >> 2][j] += (sub == (j & 3)) ? dm : 0.0;
+      } else {
+        // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij)
+        float zeta[N], xdd[N], cw[N], beta, wsc;
+        if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+          // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) on the FULL matrix (quirk Q4):
+          // off-diagonal = w, diagonal = w / (1 - ratio_i^2)
+          const float cutoff = P[0] - P[1];
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float qdj = my_qd[j];
+            const float dv = fabsf(qdj) - cutoff;
+            const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
+            const float acc = -fabsf(P[2] * dv) * sgn;
+            xdd[j] = (fabsf(qdj) < cutoff) ? 0.f : acc;
+            const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+            zeta[j] = P[3] / (1.0f - ratio * ratio);  // diagonal entry
+            cw[j] = P[3] / 1.0f;                      // off-diagonal entry
+          }
+          beta = 0.f;
+          wsc = 0.f;
+        } else if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+          // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
+          const float rr_ = 0.15f;
+          const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
+          const float iqd_max = (float)(60.0 / (20.0 * (2.0 * 3.14159265358979323846)));
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float qj = my_q[j], qdj = my_qd[j];
+            const float irange = rcp1(lf.vb[j] - lf.va[j]);
+            const float du = (lf.vb[j] - qj) * irange;
+            const float dl = (qj - lf.va[j]) * irange;
+            const float d = fminf(du, dl);
+            const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
+            cw[j] = (j < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
+            zeta[j] = qdj * iqd_max;
+            s2 += zeta[j] * zeta[j];
+            xdd[j] = -P[0] * qj - P[1] * qdj;
+          }
+          const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+          // soft norm h = |v| + (1/c) log(1 + exp(-2 c |v|)), c = 5   (helper/rmp_helper.py:62-65)
+          const float hh = nrm + 0.2f * (0.693147182464599609375f * __builtin_amdgcn_logf(1.0f + exp1(-10.0f * nrm)));
+          const float ihh = rcp1(hh);
+#pragma unroll
+          for (int j = 0; j < N; ++j) zeta[j] = zeta[j] * ihh;
+          beta = 0.9f;
+          wsc = 1.0f;
+        } else {
+          // TargetPolicy on the identity map, rmp.py:241-260 (goal is an n-vector)
+          const float alpha = P[0], beta_d = P[1], c = P[2];
+          float v[N], s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            v[j] = (j < n_dof) ? my_goal[lf.goal_offset + j] - my_q[j] : 0.f;
+            s2 += v[j] * v[j];
+          }
+          const float vn = sqrtf(s2);
+          const float hq = vn + c * logf(1.0f + expf(-2.0f * c * vn));
+          const float inv_h = 1.0f / hq;
+          float f2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            xdd[j] = alpha * (inv_h * v[j]) - beta_d * my_qd[j];
+            f2 += xdd[j] * xdd[j];
+            cw[j] = 1.0f;
+          }
+          const float fn = sqrtf(f2);
+          const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+#pragma unroll
+          for (int j = 0; j < N; ++j) zeta[j] = xdd[j] / hs;
+          beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
+          wsc = expf(-vn / 3.0f);
+        }
+        const float omb = 1.0f - beta;
+        const bool is_cap = lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP;
+        const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          const int i = sub + kQuad * m;
+          const bool row_ok = i < n_dof;
+          // zeta_i of MY row: select from the statically indexed vector
+          float zi = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) zi = (j == i) ? zeta[j] : zi;
+          float fi = 0.f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            if (j >= n_dof) continue;
+            float a;
+            if (is_cap) {
+              a = (j == i) ? zeta[j] : cw[j];
+            } else {
+              const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
+              a = is_jla ? cw[j] * Hij : wsc * Hij;
+            }
+            a = row_ok ? a : 0.f;
+            A[m][j] += (double)a;
+            fi += a * xdd[j];
+          }
+          fv[m] += (double)fi;
+        }
+      }
+    }
+
+    RMP2_STAMP();  // 3: identity leaves done
+    // optional debug outputs: the combined metric / force before the resolve
+    if (pass == 0 && live) {
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m) {
+        const int i = sub + kQuad * m;
+        if (i < n_dof) {
+          if (out.M) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              if (j < n_dof) out.M[((size_t)robot * n_dof + i) * n_dof + j] = A[m][j];
+          }
+          if (out.f) out.f[(size_t)robot * n_dof + i] = fv[m];
+        }
+      }
+    }
+    // padding dofs of the template: identity rows so that they resolve to qdd = 0
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int i = sub + kQuad * m;
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (i >= n_dof && j == i) A[m][j] = 1.0;
+    }
+
+    if (pass == 0) {
+      // ---- resolve: row-distributed fp64 elimination without row exchanges -------------------
+      // (certification and fall-through exactly as lu_solve<N>, rmp2_solve.h)
+      double scale = 0.0;
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m)
+#pragma unroll
+        for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(A[m][j]));
+      scale = fmax(scale, dppd<kXor1>(scale));
+      scale = fmax(scale, dppd<kXor2>(scale));
+      const double tiny = 1e-11 * scale;
+      flagged = !(scale > 0.0) || !(scale < 1.7e308);
+      double lmax = 0.0;
+      double inv_piv[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const int ks = k & 3, km = k >> 2;
+        // broadcast row k (columns k..N-1) and b_k from its owner
+        double rowk[N], bk;
+#pragma unroll
+        for (int j = k; j < N; ++j) {
+          const double v = A[km][j];
+          rowk[j] = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
+        }
+        {
+          const double v = fv[km];
+          bk = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
+        }
+        const bool bad = !(fabs(rowk[k]) > tiny);
+        flagged = flagged || bad;
+        const double inv = bad ? 0.0 : rcpd(rowk[k]);
+        inv_piv[k] = inv;
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          if (kQuad * m + 3 <= k) continue;  // no lane has a row i = sub + 4m > k in this block
+          const int i = sub + kQuad * m;
+          const double l = (i > k) ? A[m][k] * inv : 0.0;
+          lmax = fmax(lmax, fabs(l));
+#pragma unroll
+          for (int j = k + 1; j < N; ++j) A[m][j] = fma(-l, rowk[j], A[m][j]);
+          fv[m] = fma(-l, bk, fv[m]);
+        }
+      }
+      lmax = fmax(lmax, dppd<kXor1>(lmax));
+      lmax = fmax(lmax, dppd<kXor2>(lmax));
+      flagged = flagged || !(lmax <= 1e4);
+      // back substitution, column oriented: the owner finishes x_i and broadcasts it, then every
+      // lane retires column i from the right-hand sides of ITS rows (independent FMAs: the
+      // dependent chain per unknown is one multiply + one broadcast)
+      double x[N];
+#pragma unroll
+      for (int i = N - 1; i >= 0; --i) {
+        const int is = i & 3, im = i >> 2;
+        const double s = fv[im] * inv_piv[i];
+        x[i] = is == 0 ? bcastd<0>(s) : is == 1 ? bcastd<1>(s) : is == 2 ? bcastd<2>(s) : bcastd<3>(s);
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          if (kQuad * m >= i) continue;  // rows of this block are all >= i: nothing above the diagonal
+          fv[m] = fma(-A[m][i], x[i], fv[m]);
+        }
+      }
+      bool finite = true;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i < n_dof) finite = finite && (fabs(x[i]) < 1.7e308);
+      flagged = flagged || !finite;
+      if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (i < n_dof) my_out[i] = (float)x[i];
+      }
+      RMP2_STAMP();  // 4: LU done
+      if (!__any(flagged && live)) break;
+#ifndef RMP2_EXP_NO_RARE
+    } else if (flagged) {
+      // ---- rare path: gather the whole system into every lane of the quad, careful solve -------
+      double W[N * (N + 1)], T[N * (N + 1)], xp[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int is = i & 3, im = i >> 2;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const double v = A[im][j];
+          W[i * (N + 1) + j] = is == 0 ? bcastd<0>(v) : is == 1 ? bcastd<1>(v) : is == 2 ? bcastd<2>(v) : bcastd<3>(v);
+        }
+        const double v = fv[im];
+        W[i * (N + 1) + N] = is == 0 ? bcastd<0>(v) : is == 1 ? bcastd<1>(v) : is == 2 ? bcastd<2>(v) : bcastd<3>(v);
+      }
+      status |= RMP2_STATUS_PINV_PATH;
+      if (!lu_pivot_compact(W, T, N, xp)) {
+        const int dropped = pinv_solve_compact(W, N, n_dof, xp);
+        if (dropped) status |= RMP2_STATUS_RANK_DROP;
+      }
+      bool finite = true;
+      for (int i = 0; i < n_dof; ++i) {
+        finite = finite && (fabs(xp[i]) < 1.7e308);
+        if (sub == 0) my_out[i] = (float)xp[i];
+      }
+      if (!finite) status |= RMP2_STATUS_NONFINITE;
+#endif
+    }
+  }
+
+  // ---- coalesced store of the qdd tile ---------------------------------------------------------
+  __syncthreads();
+  {
+    const float* tile = &lds[QuadLds<N>::kOut];
+    const int count = min(kRobotsPerWave, R - r0) * n_dof;
+    float* go = out.qdd + (size_t)r0 * n_dof;
+    for (int i = lane; i < count; i += kWave) go[i] = tile[i];
+  }
+  if (out.status && live && sub == 0) out.status[robot] = status;
+#ifdef RMP2_STAMPS
+  RMP2_STAMP();  // 5: stored
+  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: f buffer receives the stamps
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
+    dst[6] = stx_[1] - stx_[0];
+    dst[7] = stx_[3] - stx_[2];
+  }
+#endif
+}
+
+}  // namespace rmp2
