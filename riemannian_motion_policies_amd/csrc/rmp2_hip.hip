@@ -795,8 +795,12 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames);
   const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->rev_mask};
-  hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q, qd,
-                     goal, gs, o, out, R);
+  if (blocks <= 1024)  // at most one wave per SIMD (256 CUs x 4): give the allocator all 512 registers
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 1>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q,
+                       qd, goal, gs, o, out, R);
+  else
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 2>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q,
+                       qd, goal, gs, o, out, R);
 }
 
 template <int N>

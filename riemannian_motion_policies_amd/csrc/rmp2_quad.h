@@ -261,8 +261,10 @@ struct QuadState {
   float p, w, al, v, a;
 };
 
-template <int N, int SLOTS>
-__global__ void __launch_bounds__(kWave, 2)
+// MINW = minimum waves per SIMD the register allocator must leave room for: 1 (up to 512
+// registers, no spills) for fleets that cannot put two waves on a SIMD anyway, 2 for larger ones.
+template <int N, int SLOTS, int MINW>
+__global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                       OutArgs out, int R) {

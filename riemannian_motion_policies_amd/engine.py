@@ -135,6 +135,35 @@ class Engine:
         _native.check(rc, self._h)
         return out
 
+    def bind(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
+             out: Optional[torch.Tensor] = None, stream=None):
+        """Pre-validate and pre-marshal one step on FIXED device buffers (the usual control loop:
+        the simulator writes q/qd in place, the engine writes qdd in place).  Returns
+        (launch, out): `launch()` is a bare C-ABI call (~2 us of host time)."""
+        out = self.step(q, qd, goal, obstacles=obstacles, out=out, stream=stream)  # validates + warms up
+        q, qd = _f32(q, self.device), _f32(qd, self.device)
+        R = q.shape[0]
+        goal_ptr, goal_stride = None, 0
+        keep = [q, qd, out, obstacles]
+        if self.desc.goal_floats:
+            goal = _f32(goal, self.device)
+            goal_stride = 0 if goal.dim() == 1 else self.desc.goal_floats
+            goal_ptr = goal.data_ptr()
+            keep.append(goal)
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        obs_ref = C.byref(obstacles) if obstacles is not None else None
+        out_ref = C.byref(o)
+        fn, h, qp, qdp = self._lib.rmp2_step, self._h, q.data_ptr(), qd.data_ptr()
+        keep.append(o)
+
+        def launch(_keep=keep):
+            rc = fn(h, qp, qdp, goal_ptr, goal_stride, obs_ref, out_ref, R, s)
+            if rc:
+                _native.check(rc, h)
+        return launch, out
+
     def forward_kinematics(self, q: torch.Tensor) -> torch.Tensor:
         q = _f32(q, self.device)
         R = q.shape[0]
