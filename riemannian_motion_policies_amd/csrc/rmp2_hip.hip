@@ -794,13 +794,17 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                  const OutArgs& out, int R, hipStream_t s) {
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames);
-  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->rev_mask};
-  if (blocks <= 1024)  // at most one wave per SIMD (256 CUs x 4): give the allocator all 512 registers
-    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 1>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q,
-                       qd, goal, gs, o, out, R);
+  const size_t stage_bytes = sizeof(DevOp) * h->n_frames + sizeof(DevLeaf) * h->n_leaves +
+                             sizeof(int32_t) * 2 * RMP2_MAX_LEAVES + sizeof(float) * 16 * kRobotsPerWave;
+  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->rev_mask};
+  // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
+  // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
+  if (blocks <= 1024 && h->goal_floats <= 16)
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 1, true>), dim3(blocks), dim3(kWave), lds_bytes + stage_bytes, s,
+                       h->d_prog, hdr, q, qd, goal, gs, o, out, R);
   else
-    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 2>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog, hdr, q,
-                       qd, goal, gs, o, out, R);
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 2, false>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog,
+                       hdr, q, qd, goal, gs, o, out, R);
 }
 
 template <int N>
@@ -907,6 +911,10 @@ int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "goal_stride must be 0 (shared) or >= goal_floats");
   }
   hipStream_t s = (hipStream_t)stream;
+  {
+    int cur = -1;  // the launch goes to the calling thread's current device: make sure it is the handle's
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
+  }
   ObsArgs o;
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;

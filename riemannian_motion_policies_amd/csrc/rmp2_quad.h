@@ -249,7 +249,7 @@ struct QuadLds {
 // header of the program, passed BY VALUE as a kernel argument (lands in SGPRs with the kernarg
 // preload: the prologue needs no dependent round trip before it can issue the tile loads)
 struct QuadHdr {
-  int32_t n_ops, n_dof, n_id;
+  int32_t n_ops, n_dof, n_id, n_leaves, goal_floats;
   uint32_t rev_mask;
 };
 
@@ -263,13 +263,26 @@ struct QuadState {
 
 // MINW = minimum waves per SIMD the register allocator must leave room for: 1 (up to 512
 // registers, no spills) for fleets that cannot put two waves on a SIMD anyway, 2 for larger ones.
-template <int N, int SLOTS, int MINW>
+// STAGE = true: the whole program (ops, leaf records, lists) and the goal rows are copied into LDS
+// in the SAME burst of loads that brings the q / qd tile on chip.  At the kernel boundary every
+// XCD's L2 starts cold, so each DEPENDENT scalar/global load round costs ~1000 cycles (measured);
+// a 3-leaf step has ~11 such rounds when the program is walked through the scalar cache.  With
+// STAGE the step pays one round, later accesses are LDS reads (~100 cycles, prefetchable).  For
+// big grids (many waves per CU share the scalar cache, latency is hidden by other waves) the
+// scalar path costs fewer instructions: STAGE = false.
+template <bool STAGE>
+__device__ __forceinline__ int uni(int v) {
+  return STAGE ? __builtin_amdgcn_readfirstlane(v) : v;
+}
+
+template <int N, int SLOTS, int MINW, bool STAGE>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                       OutArgs out, int R) {
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
-  // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats]
+  // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats |
+  //               STAGE only: ops[n_ops] | leaves[n_leaves] | fk list | id list | goal tile 16 x 16 floats]
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef RMP2_STAMPS
   // diagnostic build only: shader-clock stamps per phase, written to a buffer nothing else reads
@@ -292,6 +305,17 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // ---- stage the q / qd tile (coalesced) and the sphere table in LDS --------------------------
   const int n_ops = hdr.n_ops, n_id = hdr.n_id;
   const uint32_t rev_mask = hdr.rev_mask;
+  // staged copies (STAGE) live behind the local-transform records
+  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops;
+  DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
+  DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
+  int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
+  int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
+  float* const s_goal = reinterpret_cast<float*>(s_id + RMP2_MAX_LEAVES);
+  const DevOp* const ops = STAGE ? s_ops : prog->ops;
+  const DevLeaf* const leaves = STAGE ? s_leaves : prog->leaves;
+  const int32_t* const fk_list = STAGE ? s_fk : prog->fk_leaves;
+  const int32_t* const id_list = STAGE ? s_id : prog->id_leaves;
   const int n_live = min(kRobotsPerWave, R - r0);
   {
     const int tile = n_live * n_dof;
@@ -306,6 +330,25 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const int nf = 4 * min(obs.n_spheres, kLdsSpheres);
       for (int i = lane; i < nf; i += kWave) lds[QuadLds<N>::kSph + i] = obs.spheres[i];
     }
+    if (STAGE) {
+      const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
+      uint4* dst = reinterpret_cast<uint4*>(s_ops);
+      for (int i = lane; i < n_ops * (int)(sizeof(DevOp) / 16); i += kWave) dst[i] = src[i];
+      src = reinterpret_cast<const uint4*>(prog->leaves);
+      dst = reinterpret_cast<uint4*>(s_leaves);
+      for (int i = lane; i < hdr.n_leaves * (int)(sizeof(DevLeaf) / 16); i += kWave) dst[i] = src[i];
+      if (lane < RMP2_MAX_LEAVES) {
+        s_fk[lane] = prog->fk_leaves[lane];
+        s_id[lane] = prog->id_leaves[lane];
+      }
+      if (goal) {
+        const int gf = hdr.goal_floats;  // <= 16 (checked on the host)
+        for (int i = lane; i < n_live * gf; i += kWave) {
+          const int rr = i / gf, jj = i - rr * gf;
+          s_goal[rr * 16 + jj] = goal[(size_t)(r0 + rr) * goal_stride + jj];
+        }
+      }
+    }
     __syncthreads();
   }
   RMP2_STAMP();  // 1: prologue done
@@ -316,7 +359,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const float* my_qd = &lds[QuadLds<N>::kQd + gi * N];
   float* zo = &lds[QuadLds<N>::kZo + g];
   float* my_out = &lds[QuadLds<N>::kOut + g * n_dof];
-  const float* my_goal = goal ? goal + (size_t)(live ? robot : 0) * goal_stride : nullptr;
+  const float* my_goal = !goal ? nullptr : (STAGE ? s_goal + gi * 16 : goal + (size_t)(live ? robot : 0) * goal_stride);
   uint32_t status = 0u;
   bool flagged = false;
 
@@ -326,7 +369,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // leaves Rl (9), tl (3) and Rl @ axis (3) in LDS; the serial walk below only multiplies.
   float* const loc = &lds[QuadLds<N>::kLoc + gi_loc(g, n_ops)];
   for (int k = sub; k < n_ops; k += kQuad) {
-    const DevOp& opg = prog->ops[k];  // lane-dependent record: vector loads (L2 resident)
+    const DevOp& opg = ops[k];  // lane-dependent record (LDS copy when staged, else vector loads)
     const int jt = opg.jtype, qi = opg.qidx;
     const float qv = qi >= 0 ? my_q[qi] : 0.f;
     const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
@@ -386,7 +429,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     QuadState slot[SLOTS > 0 ? SLOTS : 1];
     // control words and local transforms are fetched ONE FRAME AHEAD (software pipelining): the
     // walk is a serial dependency chain, any exposed scalar-load or LDS latency adds to it directly
-    OpCtl op_next = *reinterpret_cast<const OpCtl*>(&prog->ops[0]);
+    // (control words two frames ahead: a scalar load that misses the scalar cache takes longer than
+    // one frame of the walk)
+    OpCtl op_next = *reinterpret_cast<const OpCtl*>(&ops[0]);
+    OpCtl op_next2 = *reinterpret_cast<const OpCtl*>(&ops[min(1, n_ops - 1)]);
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2], n3 = rec4n[3];
     float qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
@@ -394,17 +440,29 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #ifdef RMP2_STAMPS
       if (k >= 3 && k < 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stx_[k - 3] = __builtin_amdgcn_s_memtime(); }
 #endif
-      const OpCtl op = op_next;
+      OpCtl op = op_next;
+      if (STAGE) {  // LDS reads land in VGPRs: move the (wave-uniform) control words to SGPRs for scalar branches
+        op.restore = uni<STAGE>(op.restore);
+        op.save = uni<STAGE>(op.save);
+        op.jtype = uni<STAGE>(op.jtype);
+        op.qidx = uni<STAGE>(op.qidx);
+        op.anc_mask = (uint32_t)uni<STAGE>((int)op.anc_mask);
+        op.leaf_begin = uni<STAGE>(op.leaf_begin);
+        op.leaf_count = uni<STAGE>(op.leaf_count);
+      }
       const float4 r0_ = n0, r1_ = n1, r2_ = n2, r3_ = n3;
       const float qdv = qd_next;
+      op_next = op_next2;
       {
         const int kn = min(k + 1, n_ops - 1);
-        op_next = *reinterpret_cast<const OpCtl*>(&prog->ops[kn]);
+        op_next2 = *reinterpret_cast<const OpCtl*>(&ops[min(k + 2, n_ops - 1)]);
         rec4n = reinterpret_cast<const float4*>(loc + 16 * kn);
         n0 = rec4n[0];
         n1 = rec4n[1];
         n2 = rec4n[2];
         n3 = rec4n[3];
+        const int qn = uni<STAGE>(op_next.qidx);
+        qd_next = qn >= 0 ? my_qd[qn] : 0.f;
       }
       const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
       const float tl[3] = {r2_.y, r2_.z, r2_.w};
@@ -465,7 +523,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         for (int s = 0; s < SLOTS; ++s)
           if (op.save == s) slot[s] = cur;
       }
-      qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
       if (op.leaf_count == 0) continue;
 
       // ---- leaves attached to this frame ----------------------------------------------------
@@ -512,8 +569,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
 
       for (int li = 0; li < op.leaf_count; ++li) {
-        const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
-        const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte scalar load
+        const DevLeaf& lf = leaves[uni<STAGE>(fk_list[op.leaf_begin + li])];
+        LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
+        lh.kind = uni<STAGE>(lh.kind);
+        lh.taskmap = uni<STAGE>(lh.taskmap);
+        lh.goal_offset = uni<STAGE>(lh.goal_offset);
         const int lf_kind = lh.kind;
         float S[6], h[3];
         if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
@@ -544,7 +604,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
               pair_loop<kPairsSharedGlobal>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
                                             V3, A3, lh.P, IP, S, h);
           } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
-            const int lidx = lf.index;
+            const int lidx = uni<STAGE>(lf.index);
             const int pb = obs.pair_begin[lidx];
             const int count = obs.pair_begin[lidx + 1] - pb;
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
@@ -585,13 +645,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     RMP2_STAMP();  // 2: walk + FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
     for (int li = 0; li < n_id; ++li) {
-      const DevLeaf& lfr = prog->leaves[prog->id_leaves[li]];
-      const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte scalar load
+      const DevLeaf& lfr = leaves[uni<STAGE>(id_list[li])];
+      const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte load
       struct {
         int kind, goal_offset;
         const float* va;
         const float* vb;
-      } lf = {lh.kind, lh.goal_offset, lfr.va, lfr.vb};
+      } lf = {uni<STAGE>(lh.kind), uni<STAGE>(lh.goal_offset), lfr.va, lfr.vb};
       const float* P = lh.P;
       if (lf.kind == RMP2_LEAF_JOINT_DAMPING || lf.kind == RMP2_LEAF_CSPACE_BIASING ||
           lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {

@@ -79,3 +79,34 @@ class Fleet:
             self.exchange.start(local_spheres)
             obstacles = self.engine.obstacles(spheres=self.exchange.finish())
         return self.engine.step(q, qd, goal, obstacles=obstacles, out=out)
+
+
+class MixedFleet:
+    """BASELINE config 5: a fleet of several robot TYPES on one GPU.  Robots are stably
+    partitioned by type so that every wavefront is type-homogeneous; each type has its own engine
+    (its own compiled program); results are scattered back into the caller's robot order.
+
+        fleet = MixedFleet({"two_joint": desc_a, "panda": desc_b}, device=0)
+        qdd = fleet.step(type_of_robot, {"two_joint": (q, qd, goal, obstacle_kwargs), "panda": (...)})
+    """
+
+    def __init__(self, descs: dict, device: int = 0):
+        from .engine import Engine
+        self.engines = {k: Engine(d, device) for k, d in descs.items()}
+
+    def step(self, robot_types, per_type_inputs):
+        """robot_types: sequence of type keys, one per robot of the fleet (caller order).
+        per_type_inputs[key] = (q[Rk,n], qd[Rk,n], goal, obstacle_kwargs) for the robots of that type
+        in caller order.  Returns {key: qdd[Rk,n]} plus, under "index", the caller positions."""
+        import numpy as np
+        types = np.asarray(robot_types)
+        out = {"index": {}}
+        for key, eng in self.engines.items():
+            idx = np.nonzero(types == key)[0]
+            out["index"][key] = idx
+            if idx.size == 0:
+                continue
+            q, qd, goal, okw = per_type_inputs[key]
+            obstacles = eng.obstacles(**okw) if okw else None
+            out[key] = eng.step(q, qd, goal, obstacles=obstacles)
+        return out
