@@ -436,6 +436,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2], n3 = rec4n[3];
     float qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
+#ifdef RMP2_WALK_UNROLL
+#pragma unroll RMP2_WALK_UNROLL
+#endif
     for (int k = 0; k < n_ops; ++k) {
 #ifdef RMP2_STAMPS
       if (k >= 3 && k < 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stx_[k - 3] = __builtin_amdgcn_s_memtime(); }
