@@ -326,6 +326,14 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       lds[QuadLds<N>::kQ + rr * N + jj] = gq[i];
       lds[QuadLds<N>::kQd + rr * N + jj] = gqd[i];
     }
+    if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
+      const int pad = N - n_dof;
+      for (int i = lane; i < kRobotsPerWave * pad; i += kWave) {
+        const int rr = i / pad, jj = n_dof + (i - rr * pad);
+        lds[QuadLds<N>::kQ + rr * N + jj] = 0.f;
+        lds[QuadLds<N>::kQd + rr * N + jj] = 0.f;
+      }
+    }
     if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
       const int nf = 4 * min(obs.n_spheres, kLdsSpheres);
       for (int i = lane; i < nf; i += kWave) lds[QuadLds<N>::kSph + i] = obs.spheres[i];

@@ -237,3 +237,37 @@ def test_config5_mixed_fleet(torch_mod, golden_dir):
     cuts = balanced_bounds(w, 8)
     loads = [w[cuts[r]:cuts[r + 1]].sum() for r in range(8)]
     assert max(loads) <= w.sum() / 8 + w.max()
+
+
+@pytest.mark.parametrize("R", [5, 4096, 20000])
+def test_seven_dof_arm_uses_padded_template(torch_mod, R):
+    """Panda with only the 7 arm joints actuated (fingers evaluated at q = 0, kinematics.py:197,218-219):
+    n_dof = 7 runs on the N = 9 kernels with identity padding rows.  R = 20000 takes the lane-per-robot
+    kernel, the others the quad kernel."""
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf
+    t = urdf.compile_urdf(urdf.PANDA_URDF, urdf.PANDA_ORDER[:7])
+    assert t.n_dof == 7 and t.q_reordering()[9] == 7
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                   Cf.TARGET_ATTRACTOR_PARAMS, goal_len=3),
+        D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, Cf.JOINT_LIMIT_PARAMS,
+                   vec_a=Cf.PANDA_Q_LOW[:7], vec_b=Cf.PANDA_Q_HIGH[:7]),
+        D.LeafSpec(D.LEAF_JOINT_VELOCITY_CAP, D.TASKMAP_IDENTITY, -1, Cf.JOINT_VELOCITY_CAP_PARAMS),
+        D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, Cf.JOINT_DAMPING_PARAMS),
+        D.LeafSpec(D.LEAF_CONFIG_SPACE_BIASING, D.TASKMAP_IDENTITY, -1, [0.01, 0.1, 0.05], vec_a=Cf.PANDA_Q_READY[:7]),
+        D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index("panda_hand_joint"),
+                   Cf.OBSTACLE_AVOIDANCE_PARAMS),
+    ]
+    rng = np.random.default_rng(77)
+    s = Cf.sample_panda_states(rng, R)
+    q, qd = np.ascontiguousarray(s["q"][:, :7]), np.ascontiguousarray(s["qd"][:, :7])
+    sph = Cf.sample_spheres(rng, 6)
+    sph[:, 2] += 1.2  # keep the spheres clear of the arm (well-conditioned states)
+    for solve in ("auto", "pinv"):
+        desc = D.build_desc(t, specs, solve)
+        qdd, M, f, st = _run(torch_mod, _engine(desc), q, qd, s["goal"], spheres=sph)
+        sub = np.arange(R) if R <= 4096 else rng.choice(R, 1024, replace=False)
+        ref = O.step(desc, q[sub], qd[sub], s["goal"][sub], spheres=sph)
+        _check(qdd[sub], ref["qdd64"], f"7-dof {solve} R={R}")
+        assert np.abs(M[sub] - ref["M"]).max() < 1e-5 * max(1.0, np.abs(ref["M"]).max())
