@@ -71,6 +71,8 @@ struct DevProgram {
   DevLeaf leaves[RMP2_MAX_LEAVES];
   int32_t fk_leaves[RMP2_MAX_LEAVES];  // leaf ids grouped by op
   int32_t id_leaves[RMP2_MAX_LEAVES];  // identity-task-map leaves, caller's order
+  int32_t n_leaf_ops;
+  int32_t leaf_ops[kMaxOps];  // schedule positions of the frames that carry leaves
 };
 
 struct ObsArgs {

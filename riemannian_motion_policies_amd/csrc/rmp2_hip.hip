@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -605,6 +606,7 @@ struct rmp2_handle {
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
   int n_id_leaves = 0;
+  int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot (env RMP2_KERNEL=lane|quad, A/B only)
@@ -766,6 +768,9 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     op.leaf_count = nfk - op.leaf_begin;
   }
   P.n_fk_leaves = nfk;
+  P.n_leaf_ops = 0;
+  for (int k = 0; k < F; ++k)
+    if (P.ops[k].leaf_count > 0) P.leaf_ops[P.n_leaf_ops++] = k;
   P.n_id_leaves = nid;
   return RMP2_OK;
 }
@@ -793,10 +798,12 @@ template <int N, int SLOTS>
 void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                  const OutArgs& out, int R, hipStream_t s) {
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames);
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames + 4 * n_sph_lds);
   const size_t stage_bytes = sizeof(DevOp) * h->n_frames + sizeof(DevLeaf) * h->n_leaves +
-                             sizeof(int32_t) * 2 * RMP2_MAX_LEAVES + sizeof(float) * 16 * kRobotsPerWave;
-  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->rev_mask};
+                             sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
+  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   if (blocks <= 1024 && h->goal_floats <= 16)
@@ -867,6 +874,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->n_template = h->n_dof <= 2 ? 2 : 9;
   h->strict = desc->solve_mode == RMP2_SOLVE_PINV;
   h->n_id_leaves = P.n_id_leaves;
+  h->n_leaf_ops = P.n_leaf_ops;
   h->rev_mask = P.rev_mask;
   {
     const char* kenv = std::getenv("RMP2_KERNEL");

@@ -241,15 +241,14 @@ struct QuadLds {
   static constexpr int kQd = kRobotsPerWave * N;               // [16][N]
   static constexpr int kZo = 2 * kRobotsPerWave * N;           // [N*6][16]
   static constexpr int kOut = kZo + 6 * N * kRobotsPerWave;    // [16][n_dof]
-  static constexpr int kSph = kOut + kRobotsPerWave * N;       // [kLdsSpheres][4]
-  static constexpr int kLoc = kSph + 4 * kLdsSpheres;          // [16 robots][n_ops][16]: Rl(9) tl(3) zl(3) pad
-  static constexpr int kFloats = kLoc;                         // + 16*16*n_ops floats of dynamic LDS
+  static constexpr int kLoc = kOut + kRobotsPerWave * N;       // [16 robots][n_ops][16]: Rl(9) tl(3) zl(3) ctl
+  static constexpr int kFloats = kLoc;                         // + dynamic: records, sphere table, staged program
 };
 
 // header of the program, passed BY VALUE as a kernel argument (lands in SGPRs with the kernarg
 // preload: the prologue needs no dependent round trip before it can issue the tile loads)
 struct QuadHdr {
-  int32_t n_ops, n_dof, n_id, n_leaves, goal_floats;
+  int32_t n_ops, n_dof, n_id, n_leaves, goal_floats, n_leaf_ops;
   uint32_t rev_mask;
 };
 
@@ -282,12 +281,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
                       OutArgs out, int R) {
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
   // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats |
+  //               sphere table min(K, 256) x 4 |
   //               STAGE only: ops[n_ops] | leaves[n_leaves] | fk list | id list | goal tile 16 x 16 floats]
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef RMP2_STAMPS
   // diagnostic build only: shader-clock stamps per phase, written to a buffer nothing else reads
   unsigned long long st_[8];
-  unsigned long long stx_[4] = {0, 0, 0, 0};
   int st_n = 0;
 #define RMP2_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[st_n++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -304,18 +303,23 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
   // ---- stage the q / qd tile (coalesced) and the sphere table in LDS --------------------------
   const int n_ops = hdr.n_ops, n_id = hdr.n_id;
+  const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? min(obs.n_spheres, kLdsSpheres) : 0;
+  float* const sph_lds_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops;  // 16-byte aligned
   const uint32_t rev_mask = hdr.rev_mask;
   // staged copies (STAGE) live behind the local-transform records
-  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops;
+  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops + 4 * n_sph_lds;
   DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
   int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
-  float* const s_goal = reinterpret_cast<float*>(s_id + RMP2_MAX_LEAVES);
+  int32_t* const s_lo = s_id + RMP2_MAX_LEAVES;
+  float* const s_goal = reinterpret_cast<float*>(s_lo + kMaxOps);
   const DevOp* const ops = STAGE ? s_ops : prog->ops;
   const DevLeaf* const leaves = STAGE ? s_leaves : prog->leaves;
   const int32_t* const fk_list = STAGE ? s_fk : prog->fk_leaves;
   const int32_t* const id_list = STAGE ? s_id : prog->id_leaves;
+  const int32_t* const leaf_ops = STAGE ? s_lo : prog->leaf_ops;
   const int n_live = min(kRobotsPerWave, R - r0);
   {
     const int tile = n_live * n_dof;
@@ -335,8 +339,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
     if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
-      const int nf = 4 * min(obs.n_spheres, kLdsSpheres);
-      for (int i = lane; i < nf; i += kWave) lds[QuadLds<N>::kSph + i] = obs.spheres[i];
+      const int nf = 4 * n_sph_lds;
+      for (int i = lane; i < nf; i += kWave) sph_lds_base[i] = obs.spheres[i];
     }
     if (STAGE) {
       const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
@@ -349,6 +353,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         s_fk[lane] = prog->fk_leaves[lane];
         s_id[lane] = prog->id_leaves[lane];
       }
+      if (lane < kMaxOps) s_lo[lane] = prog->leaf_ops[lane];
       if (goal) {
         const int gf = hdr.goal_floats;  // <= 16 (checked on the host)
         for (int i = lane; i < n_live * gf; i += kWave) {
@@ -413,82 +418,51 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) rec[12 + r] = rec[3 * r] * ax[0] + rec[3 * r + 1] * ax[1] + rec[3 * r + 2] * ax[2];
-    rec[15] = 0.f;
+    // control word of the frame for the serial walk, packed into the record's 16th slot
+    const int packed = (opg.restore + 2) | ((opg.save + 1) << 2) | (jt << 4) | ((qi + 1) << 6) |
+                       ((opg.leaf_count > 0 ? 1 : 0) << 11);
+    rec[15] = __int_as_float(packed);
     float4* dst = reinterpret_cast<float4*>(loc + 16 * k);
 #pragma unroll
     for (int c = 0; c < 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
   }
   __syncthreads();
 
-#pragma nounroll
-  for (int pass = 0; pass < 2; ++pass) {
-    // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
-    double A[ROWS][N];
-    double fv[ROWS];
-#pragma unroll
-    for (int m = 0; m < ROWS; ++m) {
-      fv[m] = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) A[m][j] = 0.0;
-    }
-
-    // ---- tree walk (component layout) -----------------------------------------------------
+  // ---- phase 2: serial tree walk (component layout), ONCE per step ------------------------------
+  // Deliberately a tiny loop with nothing else in it: the walk is one dependent chain, so every
+  // instruction in its body is latency.  The frame's control word travels inside its LDS record;
+  // frames that carry leaves drop (p, v, a) into LDS for the leaf phase below.
+  {
     QuadState cur;
     QuadState slot[SLOTS > 0 ? SLOTS : 1];
-    // control words and local transforms are fetched ONE FRAME AHEAD (software pipelining): the
-    // walk is a serial dependency chain, any exposed scalar-load or LDS latency adds to it directly
-    // (control words two frames ahead: a scalar load that misses the scalar cache takes longer than
-    // one frame of the walk)
-    OpCtl op_next = *reinterpret_cast<const OpCtl*>(&ops[0]);
-    OpCtl op_next2 = *reinterpret_cast<const OpCtl*>(&ops[min(1, n_ops - 1)]);
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2], n3 = rec4n[3];
-    float qd_next = op_next.qidx >= 0 ? my_qd[op_next.qidx] : 0.f;
-#ifdef RMP2_WALK_UNROLL
-#pragma unroll RMP2_WALK_UNROLL
-#endif
     for (int k = 0; k < n_ops; ++k) {
-#ifdef RMP2_STAMPS
-      if (k >= 3 && k < 7) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stx_[k - 3] = __builtin_amdgcn_s_memtime(); }
-#endif
-      OpCtl op = op_next;
-      if (STAGE) {  // LDS reads land in VGPRs: move the (wave-uniform) control words to SGPRs for scalar branches
-        op.restore = uni<STAGE>(op.restore);
-        op.save = uni<STAGE>(op.save);
-        op.jtype = uni<STAGE>(op.jtype);
-        op.qidx = uni<STAGE>(op.qidx);
-        op.anc_mask = (uint32_t)uni<STAGE>((int)op.anc_mask);
-        op.leaf_begin = uni<STAGE>(op.leaf_begin);
-        op.leaf_count = uni<STAGE>(op.leaf_count);
-      }
       const float4 r0_ = n0, r1_ = n1, r2_ = n2, r3_ = n3;
-      const float qdv = qd_next;
-      op_next = op_next2;
-      {
-        const int kn = min(k + 1, n_ops - 1);
-        op_next2 = *reinterpret_cast<const OpCtl*>(&ops[min(k + 2, n_ops - 1)]);
-        rec4n = reinterpret_cast<const float4*>(loc + 16 * kn);
+      const int ctl = __builtin_amdgcn_readfirstlane(__float_as_int(r3_.w));
+      const int c_restore = (ctl & 3) - 2, c_save = ((ctl >> 2) & 3) - 1, c_jtype = (ctl >> 4) & 3;
+      const int qi = ((ctl >> 6) & 31) - 1;
+      const float qdv = qi >= 0 ? my_qd[qi] : 0.f;
+      {  // next frame's record: issued now, consumed one iteration later
+        rec4n = reinterpret_cast<const float4*>(loc + 16 * min(k + 1, n_ops - 1));
         n0 = rec4n[0];
         n1 = rec4n[1];
         n2 = rec4n[2];
         n3 = rec4n[3];
-        const int qn = uni<STAGE>(op_next.qidx);
-        qd_next = qn >= 0 ? my_qd[qn] : 0.f;
       }
       const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
       const float tl[3] = {r2_.y, r2_.z, r2_.w};
       const float zl[3] = {r3_.x, r3_.y, r3_.z};
-      if (op.restore == -2) {
+      if (c_restore == -2) {
         // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
 #pragma unroll
         for (int m = 0; m < 3; ++m) cur.R[m] = (m == sub) ? 1.0f : 0.0f;
         cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
-      } else if (SLOTS > 0 && op.restore >= 0) {
+      } else if (SLOTS > 0 && c_restore >= 0) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-          if (op.restore == s) cur = slot[s];
+        for (int s2 = 0; s2 < SLOTS; ++s2)
+          if (c_restore == s2) cur = slot[s2];
       }
-      const int qi = op.qidx;
       // world: my row of  R_parent @ R_local, my component of  R_parent @ t_local + p_parent
       float Rn[3];
 #pragma unroll
@@ -506,11 +480,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const float t1a = dpp<kRot1>(t1), t1b = dpp<kRot2>(t1);
       const float t3 = w1 * t1b - w2 * t1a;  // w_p x (w_p x r)
       float wn = cur.w, aln = cur.al, vn = cur.v + t1, an = cur.a + t2 + t3;
-      if (op.jtype != RMP2_JOINT_FIXED) {
+      if (c_jtype != RMP2_JOINT_FIXED) {
         const float zq = z * qdv;
         const float zq1 = dpp<kRot1>(zq), zq2 = dpp<kRot2>(zq);
         const float t4 = w1 * zq2 - w2 * zq1;  // w_p x (z qd)
-        if (op.jtype == RMP2_JOINT_REVOLUTE) {
+        if (c_jtype == RMP2_JOINT_REVOLUTE) {
           wn += zq;
           aln += t4;
         } else {
@@ -525,22 +499,50 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       cur.al = aln;
       cur.v = vn;
       cur.a = an;
-      if (qi >= 0 && op.jtype != RMP2_JOINT_FIXED && sub < 3) {
-        zo[(qi * 6 + sub) * kRobotsPerWave] = z;
-        zo[(qi * 6 + 3 + sub) * kRobotsPerWave] = pn;
+      if (sub < 3) {
+        if (qi >= 0 && c_jtype != RMP2_JOINT_FIXED) {
+          zo[(qi * 6 + sub) * kRobotsPerWave] = z;
+          zo[(qi * 6 + 3 + sub) * kRobotsPerWave] = pn;
+        }
+        if ((ctl >> 11) & 1) {  // a frame with leaves: leave (p, v, a) for the leaf phase -- in the frame's own
+          float* fr = loc + 16 * k;  // record slot, which every lane of the quad has already consumed
+          fr[sub] = pn;
+          fr[3 + sub] = vn;
+          fr[6 + sub] = an;
+        }
       }
-      if (SLOTS > 0 && op.save >= 0) {
+      if (SLOTS > 0 && c_save >= 0) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-          if (op.save == s) slot[s] = cur;
+        for (int s2 = 0; s2 < SLOTS; ++s2)
+          if (c_save == s2) slot[s2] = cur;
       }
-      if (op.leaf_count == 0) continue;
+    }
+  }
+  RMP2_STAMP();  // 2: walk done
 
-      // ---- leaves attached to this frame ----------------------------------------------------
-      // full 3-vectors of the frame in every lane
-      const float P3[3] = {bcast<0>(cur.p), bcast<1>(cur.p), bcast<2>(cur.p)};
-      const float V3[3] = {bcast<0>(cur.v), bcast<1>(cur.v), bcast<2>(cur.v)};
-      const float A3[3] = {bcast<0>(cur.a), bcast<1>(cur.a), bcast<2>(cur.a)};
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
+    double A[ROWS][N];
+    double fv[ROWS];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      fv[m] = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[m][j] = 0.0;
+    }
+
+    // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
+    for (int t = 0; t < hdr.n_leaf_ops; ++t) {
+      const int k = uni<STAGE>(leaf_ops[t]);
+      OpCtl op = *reinterpret_cast<const OpCtl*>(&ops[k]);
+      op.anc_mask = (uint32_t)uni<STAGE>((int)op.anc_mask);
+      op.leaf_begin = uni<STAGE>(op.leaf_begin);
+      op.leaf_count = uni<STAGE>(op.leaf_count);
+      // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
+      const float4* fr4 = reinterpret_cast<const float4*>(loc + 16 * k);
+      const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
+      const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
       // Jacobian columns of the frame origin (all dofs; wave-uniform activity mask)
       float col[N][3];
 #pragma unroll
@@ -606,7 +608,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           for (int c = 0; c < 6; ++c) S[c] = 0.f;
           h[0] = h[1] = h[2] = 0.f;
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
-          const float* sph_lds = &lds[QuadLds<N>::kSph];
+          const float* sph_lds = sph_lds_base;
           if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds)
               pair_loop<kPairsSharedLds>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3,
@@ -653,7 +655,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
 
-    RMP2_STAMP();  // 2: walk + FK leaves done
+    RMP2_STAMP();  // 3: FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
     for (int li = 0; li < n_id; ++li) {
       const DevLeaf& lfr = leaves[uni<STAGE>(id_list[li])];
@@ -811,7 +813,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
 
-    RMP2_STAMP();  // 3: identity leaves done
+    RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
     if (pass == 0 && live) {
 #pragma unroll
@@ -907,7 +909,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         for (int i = 0; i < N; ++i)
           if (i < n_dof) my_out[i] = (float)x[i];
       }
-      RMP2_STAMP();  // 4: LU done
+      RMP2_STAMP();  // 5: LU done
       if (!__any(flagged && live)) break;
 #ifndef RMP2_EXP_NO_RARE
     } else if (flagged) {
@@ -949,12 +951,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   }
   if (out.status && live && sub == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS
-  RMP2_STAMP();  // 5: stored
+  RMP2_STAMP();  // 6: stored
   if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: f buffer receives the stamps
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)blockIdx.x * 8;
     for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
-    dst[6] = stx_[1] - stx_[0];
-    dst[7] = stx_[3] - stx_[2];
   }
 #endif
 }

@@ -18,7 +18,7 @@ sets = {"D no-frames damping": D.build_desc(_null_table(9), [damp]), "C walk dam
 s = Cf.sample_panda_states(np.random.default_rng(1), R)
 q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
 sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng(7))).cuda()
-names = ["prologue", "walk+fk-leaves", "identity leaves", "LU", "store"]
+names = ["prologue", "phase1+walk", "fk leaves", "identity leaves", "LU", "store"]
 for name, desc in sets.items():
     eng = Engine(desc, 0)
     obs = eng.obstacles(spheres=sph) if name == "config3" else None
@@ -28,8 +28,7 @@ for name, desc in sets.items():
         eng.step(q, qd, g, obstacles=obs, f=f)
     torch.cuda.synchronize()
     st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + 15) // 16) * 8].reshape(-1, 8).astype(np.int64)
-    d = np.diff(st[:, :6], axis=1)
+    d = np.diff(st[:, :7], axis=1)
     med = np.median(d, axis=0)
-    tot = np.median(st[:, 5] - st[:, 0])
+    tot = np.median(st[:, 6] - st[:, 0])
     print(f"R={R} {name:22s} total {tot:8.0f} cyc | " + " ".join(f"{n}={m:.0f}" for n, m in zip(names, med)))
-    print(f"      per-frame cycles (frame 3->4, 5->6): {np.median(st[:,6]):.0f} {np.median(st[:,7]):.0f}")
