@@ -603,6 +603,9 @@ thread_local std::string g_create_error;
 struct rmp2_handle {
   int device = 0;
   int n_dof = 0, n_frames = 0, n_slots = 0, n_leaves = 0, goal_floats = 0;
+  int n_slots_full = 0;  // slots of the unpruned program (FK / differentiate entry points)
+  int n_ops_step = 0;    // frames the control-step kernels visit (pruned + folded program)
+  DevProgram* d_prog_full = nullptr;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
   int n_id_leaves = 0;
@@ -637,23 +640,68 @@ int fail(rmp2_handle* h, int code, const std::string& msg) {
       return fail(h, RMP2_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
   } while (0)
 
-// depth-first schedule with save/restore slots (same algorithm as urdf.py:depth_first_schedule)
-int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string& err) {
+// Compile the descriptor into the device program: depth-first schedule with save/restore slots
+// (same algorithm as urdf.py:depth_first_schedule).
+// prune = true (control-step kernels): frames that are not an ancestor-or-self of a frame carrying a
+// leaf are dropped (they cannot influence qdd), and FIXED frames without a leaf are folded into their
+// children's constant transform (T_c' = T_fixed @ T_c, formed in fp64; exact up to one fp32 rounding
+// of the folded constant).  prune = false: every frame is visited (forward-kinematics entry points).
+int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string& err, bool prune) {
   const rmp2_robot& rb = d.robot;
-  const int F = rb.n_frames, n = rb.n_dof;
-  if (F < 0 || F > RMP2_MAX_FRAMES) return err = "n_frames out of range", RMP2_ERR_INVALID_ARGUMENT;
+  const int F0 = rb.n_frames, n = rb.n_dof;
+  if (F0 < 0 || F0 > RMP2_MAX_FRAMES) return err = "n_frames out of range", RMP2_ERR_INVALID_ARGUMENT;
   if (n < 1 || n > RMP2_MAX_DOF) return err = "n_dof out of range", RMP2_ERR_INVALID_ARGUMENT;
   if (d.n_leaves < 0 || d.n_leaves > RMP2_MAX_LEAVES) return err = "n_leaves out of range", RMP2_ERR_INVALID_ARGUMENT;
   std::memset(&P, 0, sizeof(P));
-  std::vector<std::vector<int>> children(F);
-  std::vector<int> roots;
-  for (int i = 0; i < F; ++i) {
+  for (int i = 0; i < F0; ++i) {
     const int p = rb.parent[i];
     if (p >= i || p < -1) return err = "parent[] must be topologically ordered (parent < child)", RMP2_ERR_INVALID_ARGUMENT;
     if (rb.joint_type[i] < 0 || rb.joint_type[i] > 2) return err = "bad joint_type", RMP2_ERR_INVALID_ARGUMENT;
     if (rb.q_index[i] >= n) return err = "q_index out of range", RMP2_ERR_INVALID_ARGUMENT;
-    (p < 0 ? roots : children[p]).push_back(i);
   }
+  // working tree (possibly pruned / folded); wf[i] refers to original frame wf[i].orig
+  struct WFrame {
+    int orig, parent;
+    double Tc[12];
+  };
+  std::vector<WFrame> wf;
+  {
+    std::vector<char> has_leaf(F0, 0), needed(F0, prune ? 0 : 1), keep(F0, 0);
+    for (int l = 0; l < d.n_leaves; ++l)
+      if (d.leaves[l].taskmap != RMP2_TASKMAP_IDENTITY && d.leaves[l].frame >= 0 && d.leaves[l].frame < F0)
+        has_leaf[d.leaves[l].frame] = 1;
+    for (int f = F0 - 1; f >= 0; --f)
+      if (has_leaf[f])
+        for (int j = f; j >= 0 && !needed[j]; j = rb.parent[j]) needed[j] = 1;
+    std::vector<int> new_index(F0, -1);
+    for (int f = 0; f < F0; ++f) {
+      keep[f] = needed[f] && !(prune && rb.joint_type[f] == RMP2_JOINT_FIXED && !has_leaf[f]);
+      if (!keep[f]) continue;
+      WFrame w;
+      w.orig = f;
+      for (int c = 0; c < 12; ++c) w.Tc[c] = rb.T_const[f][c];
+      int p = rb.parent[f];
+      while (p >= 0 && !keep[p]) {  // fold the dropped (fixed, leaf-less) ancestors: T = T_p @ T
+        double T[12];
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            T[4 * r + c] = (double)rb.T_const[p][4 * r] * w.Tc[c] + (double)rb.T_const[p][4 * r + 1] * w.Tc[4 + c] +
+                           (double)rb.T_const[p][4 * r + 2] * w.Tc[8 + c];
+          T[4 * r + 3] = (double)rb.T_const[p][4 * r] * w.Tc[3] + (double)rb.T_const[p][4 * r + 1] * w.Tc[7] +
+                         (double)rb.T_const[p][4 * r + 2] * w.Tc[11] + (double)rb.T_const[p][4 * r + 3];
+        }
+        std::memcpy(w.Tc, T, sizeof(T));
+        p = rb.parent[p];
+      }
+      w.parent = p < 0 ? -1 : new_index[p];
+      new_index[f] = (int)wf.size();
+      wf.push_back(w);
+    }
+  }
+  const int F = (int)wf.size();
+  std::vector<std::vector<int>> children(F);
+  std::vector<int> roots;
+  for (int i = 0; i < F; ++i) (wf[i].parent < 0 ? roots : children[wf[i].parent]).push_back(i);
   std::vector<int> order, stack(roots.rbegin(), roots.rend());
   while (!stack.empty()) {
     const int i = stack.back();
@@ -665,14 +713,21 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   for (int k = 0; k < F; ++k) pos[order[k]] = k;
   uint32_t rev_mask = 0;
   std::vector<int> dof_owner(n, -1);
+  for (int f0 = 0; f0 < F0; ++f0) {  // dof ownership / revolute mask over ALL frames of the robot
+    const int qi = (rb.joint_type[f0] == RMP2_JOINT_FIXED) ? -1 : rb.q_index[f0];
+    if (qi < 0) continue;
+    if (dof_owner[qi] >= 0) return err = "two joints share one q index", RMP2_ERR_INVALID_ARGUMENT;
+    dof_owner[qi] = f0;
+    if (rb.joint_type[f0] == RMP2_JOINT_REVOLUTE) rev_mask |= 1u << qi;
+  }
   for (int k = 0; k < F; ++k) {
-    const int f = order[k], p = rb.parent[f];
+    const int w = order[k], p = wf[w].parent, f = wf[w].orig;
     DevOp& op = P.ops[k];
     op.frame = f;
     op.restore = (p < 0) ? -2 : ((k > 0 && order[k - 1] == p) ? -1 : slot_of[p]);
     op.save = -1;
     int last_use = -1;
-    for (int c : children[f])
+    for (int c : children[w])
       if (pos[c] != k + 1) last_use = std::max(last_use, pos[c]);
     if (last_use >= 0) {
       int s = -1;
@@ -686,27 +741,22 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
         s = (int)free_at.size() - 1;
       }
       free_at[s] = last_use;
-      slot_of[f] = s;
+      slot_of[w] = s;
       op.save = s;
     }
     op.jtype = rb.joint_type[f];
     op.qidx = (op.jtype == RMP2_JOINT_FIXED) ? -1 : rb.q_index[f];
-    if (op.qidx >= 0) {
-      if (dof_owner[op.qidx] >= 0) return err = "two joints share one q index", RMP2_ERR_INVALID_ARGUMENT;
-      dof_owner[op.qidx] = f;
-      if (op.jtype == RMP2_JOINT_REVOLUTE) rev_mask |= 1u << op.qidx;
-    }
     uint32_t mask = 0;
     for (int j = f; j >= 0; j = rb.parent[j])
       if (rb.joint_type[j] != RMP2_JOINT_FIXED && rb.q_index[j] >= 0) mask |= 1u << rb.q_index[j];
     op.anc_mask = mask;
     for (int c = 0; c < 3; ++c) op.axis[c] = rb.axis[f][c];
-    for (int c = 0; c < 12; ++c) op.Tc[c] = rb.T_const[f][c];
+    for (int c = 0; c < 12; ++c) op.Tc[c] = (float)wf[w].Tc[c];
   }
   n_slots = (int)free_at.size();
   P.n_ops = F;
   P.n_dof = n;
-  P.n_frames = F;
+  P.n_frames = F0;
   P.n_leaves = d.n_leaves;
   P.goal_floats = d.goal_floats;
   P.solve_mode = d.solve_mode;
@@ -754,7 +804,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
       default: break;
     }
     if (!ok) return err = "leaf " + std::to_string(l) + ": this (kind, taskmap) pair has no kernel", RMP2_ERR_UNSUPPORTED;
-    if (s.taskmap != RMP2_TASKMAP_IDENTITY && (s.frame < 0 || s.frame >= F))
+    if (s.taskmap != RMP2_TASKMAP_IDENTITY && (s.frame < 0 || s.frame >= F0))
       return err = "leaf " + std::to_string(l) + ": frame out of range", RMP2_ERR_INVALID_ARGUMENT;
     if (goal_len && (s.goal_offset < 0 || s.goal_offset + goal_len > d.goal_floats))
       return err = "leaf " + std::to_string(l) + ": goal_offset/goal_floats inconsistent", RMP2_ERR_INVALID_ARGUMENT;
@@ -800,10 +850,10 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_frames + 4 * n_sph_lds);
-  const size_t stage_bytes = sizeof(DevOp) * h->n_frames + sizeof(DevLeaf) * h->n_leaves +
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + 4 * n_sph_lds);
+  const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
-  const QuadHdr hdr{h->n_frames, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
+  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   if (blocks <= 1024 && h->goal_floats <= 16)
@@ -854,14 +904,15 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
     return fail(nullptr, RMP2_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
-  DevProgram P;
-  int n_slots = 0;
+  DevProgram P, Pfull;
+  int n_slots = 0, n_slots_full = 0;
   std::string err;
-  const int rc = compile_program(*desc, P, n_slots, err);
+  int rc = compile_program(*desc, P, n_slots, err, /*prune=*/true);
+  if (rc == RMP2_OK) rc = compile_program(*desc, Pfull, n_slots_full, err, /*prune=*/false);
   if (rc != RMP2_OK) return fail(nullptr, rc, err);
   if (desc->robot.n_dof > 9)
     return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kernels are instantiated for n_dof <= 9");
-  if (n_slots > 2)
+  if (n_slots > 2 || n_slots_full > 2)
     return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kinematic tree needs more than 2 saved branch states");
   rmp2_handle* h = new (std::nothrow) rmp2_handle();
   if (!h) return fail(nullptr, RMP2_ERR_HIP, "out of host memory");
@@ -869,6 +920,8 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->n_dof = desc->robot.n_dof;
   h->n_frames = desc->robot.n_frames;
   h->n_slots = n_slots;
+  h->n_slots_full = n_slots_full;
+  h->n_ops_step = P.n_ops;
   h->n_leaves = desc->n_leaves;
   h->goal_floats = desc->goal_floats;
   h->n_template = h->n_dof <= 2 ? 2 : 9;
@@ -886,6 +939,8 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&h->d_prog, sizeof(DevProgram));
   if (e == hipSuccess) e = hipMemcpy(h->d_prog, &P, sizeof(DevProgram), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&h->d_prog_full, sizeof(DevProgram));
+  if (e == hipSuccess) e = hipMemcpy(h->d_prog_full, &Pfull, sizeof(DevProgram), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&h->d_pair_begin, sizeof(h->h_pair_begin));
   if (e == hipSuccess) e = hipMemset(h->d_pair_begin, 0, sizeof(h->h_pair_begin));
   if (e != hipSuccess) {
@@ -901,6 +956,7 @@ int rmp2_destroy(rmp2_handle* h) {
   if (!h) return RMP2_OK;
   (void)hipSetDevice(h->device);
   if (h->d_prog) (void)hipFree(h->d_prog);
+  if (h->d_prog_full) (void)hipFree(h->d_prog_full);
   if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   delete h;
@@ -976,10 +1032,10 @@ int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R,
   if (R == 0 || h->n_frames == 0) return RMP2_OK;
   const int blocks = (R + kWave - 1) / kWave;
   hipStream_t s = (hipStream_t)stream;
-  switch (h->n_slots) {
-    case 0: hipLaunchKernelGGL((rmp2_fk_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
-    case 1: hipLaunchKernelGGL((rmp2_fk_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
-    default: hipLaunchKernelGGL((rmp2_fk_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, T, R); break;
+  switch (h->n_slots_full) {
+    case 0: hipLaunchKernelGGL((rmp2_fk_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
+    case 1: hipLaunchKernelGGL((rmp2_fk_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
+    default: hipLaunchKernelGGL((rmp2_fk_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
   }
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;
@@ -1001,17 +1057,17 @@ int rmp2_differentiate(rmp2_handle* h, const float* q, const float* qd, int32_t 
     h->scratch_robots = (size_t)R;
   }
   const int blocks = (R + kWave - 1) / kWave;
-  switch (h->n_slots) {
+  switch (h->n_slots_full) {
     case 0:
-      hipLaunchKernelGGL((rmp2_diff_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+      hipLaunchKernelGGL((rmp2_diff_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
                          h->d_scratch, R);
       break;
     case 1:
-      hipLaunchKernelGGL((rmp2_diff_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+      hipLaunchKernelGGL((rmp2_diff_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
                          h->d_scratch, R);
       break;
     default:
-      hipLaunchKernelGGL((rmp2_diff_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, frame, x, xd, J, c,
+      hipLaunchKernelGGL((rmp2_diff_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
                          h->d_scratch, R);
       break;
   }

@@ -432,7 +432,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // Deliberately a tiny loop with nothing else in it: the walk is one dependent chain, so every
   // instruction in its body is latency.  The frame's control word travels inside its LDS record;
   // frames that carry leaves drop (p, v, a) into LDS for the leaf phase below.
-  {
+  if (n_ops > 0) {
     QuadState cur;
     QuadState slot[SLOTS > 0 ? SLOTS : 1];
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
@@ -797,6 +797,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             if (j >= n_dof) continue;
+            // JointLimitAvoidance scales COLUMN j by the limit weight of joint j, which is exactly 0 unless
+            // that joint is inside its limit band: skip the column when that holds for the whole wave
+            if (is_jla && !__any(cw[j] != 0.f)) continue;
             float a;
             if (is_cap) {
               a = (j == i) ? zeta[j] : cw[j];
