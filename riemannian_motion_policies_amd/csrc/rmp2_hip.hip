@@ -778,12 +778,13 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     std::memcpy(t.va, s.vec_a, sizeof(t.va));
     std::memcpy(t.vb, s.vec_b, sizeof(t.vb));
     if (s.kind == RMP2_LEAF_OBSTACLE_AVOIDANCE) {
-      // reciprocals of the length scales, formed in double (used by the quad kernel's pair loop)
+      // reciprocals of the length scales (two of them pre-multiplied by log2 e), formed in double
+      // (used by the quad kernel's pair loop)
       const double estd = s.params[9], rstd = s.params[6], dstd = s.params[2], glen = s.params[4], rad = s.params[7];
       t.vb[0] = (float)(1.0 / estd);
-      t.vb[1] = (float)(1.0 / rstd);
+      t.vb[1] = (float)(1.4426950408889634 / rstd);  // log2(e) / rstd
       t.vb[2] = (float)(1.0 / dstd);
-      t.vb[3] = (float)(1.0 / glen);
+      t.vb[3] = (float)(1.4426950408889634 / glen);  // log2(e) / gate_len
       t.vb[4] = (float)(1.0 / (rad * rad));
       t.vb[5] = (float)(2.0 / rad);
     }

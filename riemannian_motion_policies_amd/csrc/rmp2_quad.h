@@ -112,14 +112,16 @@ __device__ __forceinline__ double rcpd(double x) {  // 1/x in fp64: v_rcp_f64 + 
 }
 
 // ---- leaves, fast-math flavour (same formulas as rmp2_device.h) --------------------------------
-// rmp2.py:183-196; IP = host-precomputed reciprocals {1/estd, 1/rstd, 1/dstd, 1/gate_len, 1/radius^2, 2/radius}
-__device__ __forceinline__ void obstacle_pair(const float* P, const float* IP, float x,
-                                              float xd, float& accel, float& metric) {
+// rmp2.py:183-196; IP = host-precomputed {1/estd, log2(e)/rstd, 1/dstd, log2(e)/gate_len, 1/radius^2, 2/radius}
+// (formed in fp64, rounded once): exp(-x/rstd) = exp2(-x * IP[1]) costs one multiply + v_exp_f32 and
+// rounds the argument once, like the reference's own x / rstd.
+__device__ __forceinline__ void obstacle_pair(const float* P, const float* IP, float x, float xd, float& accel,
+                                              float& metric) {
   x = fmaxf(x - P[0], 0.0f);
   const float base = P[8] * rcp0(fmaf(x, IP[0], P[10]));
   const float gate = fmaf(x * x, IP[4], fmaf(-x, IP[5], 1.0f));
-  const float repel = P[5] * exp1(-(x * IP[1]));
-  const float oms = 1.0f - rcp0(1.0f + exp1(-(xd * IP[3])));  // 1 - sigmoid
+  const float repel = P[5] * __builtin_amdgcn_exp2f(-(x * IP[1]));
+  const float oms = 1.0f - rcp0(1.0f + __builtin_amdgcn_exp2f(-(xd * IP[3])));  // 1 - sigmoid
   const float damp = -oms * P[1] * xd * rcp0(fmaf(x, IP[2], P[3]));
   accel = repel + damp;
   metric = (x > P[7]) ? 0.0f : oms * (base * gate);
