@@ -101,13 +101,19 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the RMP2 engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torchrun (RANK/WORLD_SIZE set) the process group is created even for one rank, so that the
+    # N > 1 code path (RCCL init, barriers, MAX-reduce of the time, obstacle all-gather) is the one
+    # exercised on a single-GPU box as well
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
+        # keep stdout to the ONE JSON line: RCCL prints a version banner there at NCCL_DEBUG=VERSION/INFO
+        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_hip()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from riemannian_motion_policies_amd.engine import Engine
     from riemannian_motion_policies_amd.fleet import ObstacleExchange
@@ -128,7 +134,7 @@ def main():
     if wl["spheres"]:
         K = wl["spheres"]
         spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
-        if world > 1:
+        if use_dist:
             if K % world:
                 raise SystemExit("sphere count must divide by the world size")
             exch = ObstacleExchange(K // world, dev)
@@ -157,7 +163,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -173,7 +179,7 @@ def main():
             e[1].record(stream)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -231,7 +237,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(desc, s, spheres_np)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
