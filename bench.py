@@ -106,9 +106,19 @@ def main():
     # exercised on a single-GPU box as well
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
-        # keep stdout to the ONE JSON line: RCCL prints a version banner there at NCCL_DEBUG=VERSION/INFO
-        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # keep stdout to the ONE JSON line: RCCL prints its version banner (and warnings) on fd 1 while the
+        # communicator is created, so fd 1 points at stderr until the first collective has completed
+        sys.stdout.flush()
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd1, 1)
+            os.close(saved_fd1)
 
     import __graft_entry__ as ge
     if rank == 0:
