@@ -185,6 +185,24 @@ const char *rmp2_last_error(const rmp2_handle *h);
 int rmp2_step(rmp2_handle *h, const float *q, const float *qd, const float *goal, int32_t goal_stride,
               const rmp2_obstacles *obs, const rmp2_outputs *out, int32_t R, void *stream);
 
+/* Closed-loop rollout of the fleet inside ONE launch (the reference's control loop
+ * experiments/franka_panda/06_cluttered_environment.py:120-131 with simulation.step tracking qdd):
+ *   repeat n_control_steps times:  qdd = control step(q, qd);
+ *                                  repeat substeps times:  qd += dt * qdd;  q += dt * qd;
+ * q and qd (device, [R][n_dof]) are advanced IN PLACE; out->qdd receives the last qdd, out->status the
+ * OR of the per-step status words.  Goals and the sphere table are constant during the rollout;
+ * RMP2_OBS_EXPLICIT_PAIRS is rejected (closest-point pairs are only valid for the state they were
+ * computed at).  Resolve semantics are those of RMP2_SOLVE_AUTO. */
+typedef struct rmp2_rollout_cfg {
+  int32_t n_control_steps;
+  int32_t substeps;
+  float dt;
+} rmp2_rollout_cfg;
+
+int rmp2_rollout(rmp2_handle *h, float *q, float *qd, const float *goal, int32_t goal_stride,
+                 const rmp2_obstacles *obs, const rmp2_rollout_cfg *cfg, const rmp2_outputs *out, int32_t R,
+                 void *stream);
+
 /* Forward kinematics of every frame: T[R][n_frames][16] row-major 4x4
  * (UrdfForwardKinematic.forward, kinematics.py:212-247, for all frames at once).      */
 int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R, void *stream);

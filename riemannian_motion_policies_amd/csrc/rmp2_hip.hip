@@ -450,7 +450,11 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
         W[i * (N + 1) + N] = fv[i];
       }
       status |= RMP2_STATUS_PINV_PATH;
-      if (!lu_pivot_compact(W, T, N, xp)) {
+      bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does):
+      for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);  // no point iterating on it
+      if (!finite_in) {
+        for (int i = 0; i < N; ++i) xp[i] = __builtin_nan("");
+      } else if (!lu_pivot_compact(W, T, N, xp)) {
         const int dropped = pinv_solve_compact(W, N, n_dof, xp);
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }
@@ -847,7 +851,7 @@ int dispatch_slots(const rmp2_handle* h, const float* q, const float* qd, const 
 
 template <int N, int SLOTS>
 void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                 const OutArgs& out, int R, hipStream_t s) {
+                 const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
@@ -859,27 +863,28 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   if (blocks <= 1024 && h->goal_floats <= 16)
     hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 1, true>), dim3(blocks), dim3(kWave), lds_bytes + stage_bytes, s,
-                       h->d_prog, hdr, q, qd, goal, gs, o, out, R);
+                       h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);
   else
     hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 2, false>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog,
-                       hdr, q, qd, goal, gs, o, out, R);
+                       hdr, q, qd, goal, gs, o, out, ro, R);
 }
 
 template <int N>
 int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                   const OutArgs& out, int R, hipStream_t s) {
-  if (h->strict) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
+                   const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
+  if (h->strict && !rollout) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
   // Kernel choice (both produce the same numbers to fp32 rounding):
   //  * quad-per-robot: shortest dependent chain and 4x the waves -- wins whenever the fleet cannot
   //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
-  //    splits 4 ways);
+  //    splits 4 ways); the only kernel with the fused rollout loop;
   //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
-  const bool lane = h->kernel_choice == 1 || (h->kernel_choice == 0 && !h->has_distance && R > 16384);
+  const bool lane = !rollout && (h->kernel_choice == 1 || (h->kernel_choice == 0 && !h->has_distance && R > 16384));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
-    case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
-    case 1: launch_quad<N, 1>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
-    case 2: launch_quad<N, 2>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
+    case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
+    case 1: launch_quad<N, 1>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
+    case 2: launch_quad<N, 2>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
     default: return RMP2_ERR_UNSUPPORTED;
   }
 }
@@ -964,8 +969,8 @@ int rmp2_destroy(rmp2_handle* h) {
   return RMP2_OK;
 }
 
-int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
-              const rmp2_obstacles* obs, const rmp2_outputs* out, int32_t R, void* stream) {
+static int step_impl(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
+                     const rmp2_obstacles* obs, const rmp2_outputs* out, const RolloutArgs& ro, int32_t R, void* stream) {
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
   if (R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "R < 0");
   if (R == 0) return RMP2_OK;  // empty fleet: nothing to do (pointers may be null)
@@ -1019,12 +1024,30 @@ int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal
   OutArgs oa{out->qdd, out->status, out->M, out->f};
   int rc;
   if (h->n_template == 2)
-    rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, R, s);
+    rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
   else
-    rc = dispatch_solve<9>(h, q, qd, goal, goal_stride, o, oa, R, s);
+    rc = dispatch_solve<9>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
   if (rc != RMP2_OK) return fail(h, rc, "no kernel instantiation for this robot");
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;
+}
+
+int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
+              const rmp2_obstacles* obs, const rmp2_outputs* out, int32_t R, void* stream) {
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr};
+  return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
+}
+
+int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t goal_stride,
+                 const rmp2_obstacles* obs, const rmp2_rollout_cfg* cfg, const rmp2_outputs* out, int32_t R,
+                 void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (!cfg || cfg->n_control_steps < 1 || cfg->substeps < 0 || !(cfg->dt >= 0.f))
+    return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: need n_control_steps >= 1, substeps >= 0, dt >= 0");
+  if (obs && obs->mode == RMP2_OBS_EXPLICIT_PAIRS)
+    return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: explicit closest-point pairs go stale as the robots move; use a sphere mode");
+  const RolloutArgs ro{cfg->n_control_steps, cfg->substeps, cfg->dt, q, qd};
+  return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
 }
 
 int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R, void* stream) {

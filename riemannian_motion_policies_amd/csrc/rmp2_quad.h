@@ -249,6 +249,17 @@ struct QuadLds {
 
 // header of the program, passed BY VALUE as a kernel argument (lands in SGPRs with the kernarg
 // preload: the prologue needs no dependent round trip before it can issue the tile loads)
+// closed-loop rollout: n_iters control steps inside ONE launch; after each resolve the
+// state is advanced by `substeps` semi-implicit Euler ticks of length dt with qdd held (the reference's
+// 10 Hz control / 100 Hz plant loop, 06_cluttered_environment.py:120-131).  A plain control step is
+// {1, 0, 0, nullptr, nullptr}.
+struct RolloutArgs {
+  int32_t n_iters, substeps;
+  float dt;
+  float* q_out;
+  float* qd_out;
+};
+
 struct QuadHdr {
   int32_t n_ops, n_dof, n_id, n_leaves, goal_floats, n_leaf_ops;
   uint32_t rev_mask;
@@ -280,7 +291,7 @@ template <int N, int SLOTS, int MINW, bool STAGE>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
-                      OutArgs out, int R) {
+                      OutArgs out, RolloutArgs ro, int R) {
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
   // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats |
   //               sphere table min(K, 256) x 4 |
@@ -378,6 +389,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   uint32_t status = 0u;
   bool flagged = false;
 
+#pragma nounroll
+  for (int it = 0; it < ro.n_iters; ++it) {
+  flagged = false;
   // ---- phase 1: local transforms T_constant @ T_variable(q) of ALL frames, in parallel -------
   // (kinematics.py:222-240).  They do not depend on the chain, so lane `sub` of the quad builds
   // the frames k = sub, sub+4, ... (branch-free: the joint type selects by arithmetic) and
@@ -932,7 +946,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         W[i * (N + 1) + N] = is == 0 ? bcastd<0>(v) : is == 1 ? bcastd<1>(v) : is == 2 ? bcastd<2>(v) : bcastd<3>(v);
       }
       status |= RMP2_STATUS_PINV_PATH;
-      if (!lu_pivot_compact(W, T, N, xp)) {
+      bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does):
+      for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);  // no point iterating on it
+      if (!finite_in) {
+        for (int i = 0; i < N; ++i) xp[i] = __builtin_nan("");
+      } else if (!lu_pivot_compact(W, T, N, xp)) {
         const int dropped = pinv_solve_compact(W, N, n_dof, xp);
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }
@@ -945,9 +963,37 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #endif
     }
   }
+  if (ro.substeps > 0) {
+    // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd); every lane advances ITS dofs
+    float* qw = &lds[QuadLds<N>::kQ + gi * N];
+    float* qdw = &lds[QuadLds<N>::kQd + gi * N];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int i = sub + kQuad * m;
+      if (i < n_dof) {
+        const float acc = my_out[i];
+        float qi_ = qw[i], qdi = qdw[i];
+        for (int t = 0; t < ro.substeps; ++t) {
+          qdi = fmaf(ro.dt, acc, qdi);
+          qi_ = fmaf(ro.dt, qdi, qi_);
+        }
+        qw[i] = qi_;
+        qdw[i] = qdi;
+      }
+    }
+  }
+  }  // rollout iterations
 
-  // ---- coalesced store of the qdd tile ---------------------------------------------------------
+  // ---- coalesced store of the qdd tile (and of the advanced state after a rollout) ---------------------
   __syncthreads();
+  if (ro.q_out) {
+    const int count = n_live * n_dof;
+    for (int i = lane; i < count; i += kWave) {
+      const int rr = i / n_dof, jj = i - rr * n_dof;
+      ro.q_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQ + rr * N + jj];
+      ro.qd_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQd + rr * N + jj];
+    }
+  }
   {
     const float* tile = &lds[QuadLds<N>::kOut];
     const int count = min(kRobotsPerWave, R - r0) * n_dof;

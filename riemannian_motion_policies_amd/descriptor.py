@@ -106,6 +106,10 @@ class Outputs(C.Structure):
     ]
 
 
+class RolloutCfg(C.Structure):
+    _fields_ = [("n_control_steps", C.c_int32), ("substeps", C.c_int32), ("dt", C.c_float)]
+
+
 class LeafSpec:
     """Plain-data description of one leaf (what the policy classes serialise to)."""
 

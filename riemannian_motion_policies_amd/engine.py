@@ -164,6 +164,40 @@ class Engine:
                 _native.check(rc, h)
         return launch, out
 
+    def rollout(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
+                n_control_steps: int = 1, substeps: int = 10, dt: float = 0.01, out: Optional[torch.Tensor] = None,
+                status: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """Closed-loop rollout in ONE launch: `n_control_steps` x (control step, then `substeps` semi-implicit
+        Euler ticks of `dt` with qdd held).  q and qd (contiguous fp32 device tensors) are advanced IN PLACE;
+        returns the last qdd."""
+        for t in (q, qd):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("rollout needs contiguous fp32 CUDA tensors (they are updated in place)")
+        if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
+            raise ValueError(f"q and qd must be [R, {self.n_dof}]")
+        R = q.shape[0]
+        goal_ptr, goal_stride = None, 0
+        if self.desc.goal_floats:
+            if goal is None:
+                raise ValueError("this RMP set has goal-bearing leaves: pass goal")
+            goal = _f32(goal, self.device)
+            goal_stride = 0 if goal.dim() == 1 else self.desc.goal_floats
+            goal_ptr = goal.data_ptr()
+        if self._dist_leaves and (obstacles is None or obstacles.mode == D.OBS_NONE):
+            raise ValueError("this RMP set has distance leaves: pass obstacles=engine.obstacles(...)")
+        if out is None:
+            out = torch.empty((R, self.n_dof), dtype=torch.float32, device=self.device)
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        if status is not None:
+            o.status = status.data_ptr()
+        cfg = D.RolloutCfg(int(n_control_steps), int(substeps), float(dt))
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.rmp2_rollout(self._h, q.data_ptr(), qd.data_ptr(), goal_ptr, goal_stride,
+                                    C.byref(obstacles) if obstacles is not None else None, C.byref(cfg), C.byref(o), R, s)
+        _native.check(rc, self._h)
+        return out
+
     def forward_kinematics(self, q: torch.Tensor) -> torch.Tensor:
         q = _f32(q, self.device)
         R = q.shape[0]

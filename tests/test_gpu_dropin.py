@@ -123,3 +123,48 @@ def test_closed_loop_goal_reaching(hip_lib):
     dist = (x - goal).norm(dim=1)
     assert torch.isfinite(q).all()
     assert (dist < 0.02).float().mean() > 0.95, f"only {(dist < 0.02).float().mean():.2f} reached the goal (median {dist.median():.3f})"
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_fused_rollout_matches_step_loop(hip_lib, workload):
+    """rmp2_rollout (K control steps + plant ticks inside one launch) against the same loop
+    driven from the host with rmp2_step; same arithmetic (fma plant), so agreement is ~1e-6."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2() if workload == "config2" else Cf.config3()
+    eng = Engine(desc, 0)
+    R, sub, dt = 333, 10, 0.01
+    rng = np.random.default_rng(9)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += 1.5  # spheres above the workspace: mild repulsion, no contact
+    obs = eng.obstacles(spheres=torch.from_numpy(sph)) if workload == "config3" else None
+    goal = torch.from_numpy(s["goal"]).cuda()
+    q0, qd0 = torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda()
+    for K in (3, 40):
+        q, qd = q0.clone(), qd0.clone()           # host-driven reference loop
+        for _ in range(K):
+            qdd = eng.step(q, qd, goal, obstacles=obs)
+            for _ in range(sub):
+                qd = qd + dt * qdd
+                q = q + dt * qd
+        qf, qdf = q0.clone(), qd0.clone()           # fused
+        st = torch.zeros(R, dtype=torch.int32, device="cuda")
+        last = eng.rollout(qf, qdf, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt, status=st)
+        torch.cuda.synchronize()
+        assert last.shape == (R, 9)
+        ok = torch.isfinite(qf).all(dim=1) & torch.isfinite(q).all(dim=1)
+        err = (qf - q).abs().max(dim=1).values
+        if K == 3:
+            assert ok.all() and not (st & 1).any()
+            assert err.max().item() < 1e-5 and (qdf - qd).abs().max().item() < 1e-4
+        else:
+            # Long horizon.  (i) For a few robots (fingers sitting in the joint-limit band) the closed loop is
+            # exponentially sensitive -- 1e-7 of rounding difference grows ~100x per 0.2 s in BOTH
+            # implementations; (ii) the experiment-06 set contains JointVelocityCap, whose metric has a pole at
+            # |qd| = 0.2 and is negative below it (quirk Q4): some robots blow up to Inf in both implementations.
+            # Agreement is therefore asserted for the bulk of the fleet.
+            assert ok.float().mean().item() > 0.8
+            assert err[ok].median().item() < 1e-5 and (err[ok] < 1e-3).float().mean().item() > 0.9
+            assert (qf[ok] - q0[ok]).abs().max().item() > 1e-2  # the fleet actually moved
