@@ -616,6 +616,7 @@ struct rmp2_handle {
   int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
+  bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot (env RMP2_KERNEL=lane|quad, A/B only)
   std::vector<int> distance_leaves;
   DevProgram* d_prog = nullptr;
@@ -873,7 +874,11 @@ template <int N>
 int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                    const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
-  if (h->strict && !rollout) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
+  // RMP sets without any identity-map leaf carrying a positive diagonal metric (JointDamping, CSpaceBiasing,
+  // ConfigurationSpaceBiasing) are rank deficient by construction on redundant arms (e.g. a lone target policy:
+  // rank <= 3 of 9): every robot would fall through to the pseudo-inverse anyway, so AUTO goes there directly
+  // (register-resident Jacobi, same result).
+  if ((h->strict || h->likely_singular) && !rollout) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
   // Kernel choice (both produce the same numbers to fp32 rounding):
   //  * quad-per-robot: shortest dependent chain and 4x the waves -- wins whenever the fleet cannot
   //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
@@ -933,6 +938,15 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->n_template = h->n_dof <= 2 ? 2 : 9;
   h->strict = desc->solve_mode == RMP2_SOLVE_PINV;
   h->n_id_leaves = P.n_id_leaves;
+  h->likely_singular = true;
+  for (int l = 0; l < desc->n_leaves; ++l) {
+    const rmp2_leaf& lf = desc->leaves[l];
+    if (lf.taskmap != RMP2_TASKMAP_IDENTITY) continue;
+    if ((lf.kind == RMP2_LEAF_JOINT_DAMPING && lf.params[2] > 0.f) ||
+        (lf.kind == RMP2_LEAF_CSPACE_BIASING && lf.params[0] + lf.params[4] > 0.f) ||
+        (lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING && lf.params[2] > 0.f))
+      h->likely_singular = false;
+  }
   h->n_leaf_ops = P.n_leaf_ops;
   h->rev_mask = P.rev_mask;
   {

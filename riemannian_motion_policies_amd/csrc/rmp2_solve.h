@@ -65,7 +65,7 @@ __device__ __forceinline__ bool lu_solve(double (&A)[N][N], double (&b)[N], doub
 // excluded from sigma_max.  Returns the number of dropped singular values.
 template <int N>
 __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int n_dof, double (&x)[N]) {
-  for (int sweep = 0; sweep < 40; ++sweep) {
+  for (int sweep = 0; sweep < 30; ++sweep) {
     bool rotated = false;
 #pragma unroll
     for (int p = 0; p < N - 1; ++p) {
@@ -78,7 +78,9 @@ __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int
           be = fma(A[q][j], A[q][j], be);
           ga = fma(A[p][j], A[q][j], ga);
         }
-        const bool rot = (fabs(ga) > 1e-300) && (fabs(ga) > 1e-17 * sqrt(al * be));
+        // converged pair: |<w_p, w_q>| <= 4 eps |w_p| |w_q|  (a tighter bound than eps can never be met
+        // and only burns sweeps)
+        const bool rot = (fabs(ga) > 1e-300) && (fabs(ga) > 1e-15 * sqrt(al * be));
         rotated = rotated || rot;
         const double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));
         const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -176,7 +178,7 @@ __device__ __forceinline__ bool lu_pivot_compact(const double* W, double* T, int
 // One-sided Jacobi pseudo-inverse, same algorithm as pinv_solve<N> on a flat [n x (n+1)] array.
 __device__ __forceinline__ int pinv_solve_compact(double* W, int n, int n_dof, double* x) {
   const int ld = n + 1;
-  for (int sweep = 0; sweep < 40; ++sweep) {
+  for (int sweep = 0; sweep < 30; ++sweep) {
     bool rotated = false;
 #pragma nounroll
     for (int p = 0; p < n - 1; ++p) {
@@ -190,7 +192,7 @@ __device__ __forceinline__ int pinv_solve_compact(double* W, int n, int n_dof, d
           be = fma(wq, wq, be);
           ga = fma(wp, wq, ga);
         }
-        if (!((fabs(ga) > 1e-300) && (fabs(ga) > 1e-17 * sqrt(al * be)))) continue;
+        if (!((fabs(ga) > 1e-300) && (fabs(ga) > 1e-15 * sqrt(al * be)))) continue;
         rotated = true;
         const double zeta = (be - al) / (2.0 * ga);
         const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

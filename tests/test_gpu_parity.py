@@ -271,3 +271,61 @@ def test_seven_dof_arm_uses_padded_template(torch_mod, R):
         ref = O.step(desc, q[sub], qd[sub], s["goal"][sub], spheres=sph)
         _check(qdd[sub], ref["qdd64"], f"7-dof {solve} R={R}")
         assert np.abs(M[sub] - ref["M"]).max() < 1e-5 * max(1.0, np.abs(ref["M"]).max())
+
+
+def test_step_is_graph_capturable_and_abi_errors(torch_mod):
+    """rmp2_step allocates nothing and never synchronises: it can be captured into a HIP graph and replayed.
+    Also: C-ABI error behaviour (codes + messages) for bad arguments."""
+    import ctypes as C
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, _native
+    _, desc = Cf.config3()
+    eng = _engine(desc)
+    s = Cf.sample_panda_states(np.random.default_rng(21), 512)
+    sph = Cf.sample_spheres(np.random.default_rng(22))
+    sph[:, 2] += 1.0
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    obs = eng.obstacles(spheres=torch.from_numpy(sph))
+    launch, out = eng.bind(q, qd, goal, obstacles=obs, stream=None)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    launch_s, out_s = eng.bind(q, qd, goal, obstacles=obs, stream=side.cuda_stream)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(3):
+            launch_s()
+    q.add_(0.01)  # change the inputs in place, replay: the graph must pick up the new values
+    g.replay()
+    torch.cuda.synchronize()
+    ref = O.step(desc, q.cpu().numpy(), s["qd"], s["goal"], spheres=sph)
+    _check(out_s.cpu().numpy(), ref["qdd64"], "graph replay")
+    # ---- error behaviour through the raw ABI
+    lib = _native.lib()
+    h = eng._h
+    o = D.Outputs()
+    o.qdd = out.data_ptr()
+    assert lib.rmp2_step(h, None, qd.data_ptr(), goal.data_ptr(), 3, C.byref(obs), C.byref(o), 512, None) == -1
+    assert b"required" in lib.rmp2_last_error(h)
+    assert lib.rmp2_step(h, q.data_ptr(), qd.data_ptr(), None, 3, C.byref(obs), C.byref(o), 512, None) == -1
+    assert b"goal" in lib.rmp2_last_error(h)
+    assert lib.rmp2_step(h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, None, C.byref(o), 512, None) == -1
+    assert b"obstacles" in lib.rmp2_last_error(h)
+    assert lib.rmp2_step(h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, C.byref(obs), C.byref(o), -5, None) == -1
+    assert lib.rmp2_step(h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, C.byref(obs), C.byref(o), 0, None) == 0
+    bad = D.Obstacles()
+    bad.mode = 7
+    assert lib.rmp2_step(h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, C.byref(bad), C.byref(o), 512, None) == -1
+    assert lib.rmp2_differentiate(h, q.data_ptr(), qd.data_ptr(), 99, q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), 4, None) == -1
+    # descriptor validation at create time
+    _, d = Cf.config2()
+    d.leaves[0].frame = 77
+    hh = C.c_void_p()
+    assert lib.rmp2_create(C.byref(d), 0, C.byref(hh)) == -1 and b"frame" in lib.rmp2_last_error(None)
+    _, d = Cf.config2()
+    d.leaves[1].taskmap = D.TASKMAP_FK_DISTANCE   # JointLimitAvoidance on a distance map: no such kernel
+    d.leaves[1].frame = 3
+    assert lib.rmp2_create(C.byref(d), 0, C.byref(hh)) == -2
+    _, d = Cf.config2()
+    d.robot.parent[3] = 5                          # not topologically ordered
+    assert lib.rmp2_create(C.byref(d), 0, C.byref(hh)) == -1
