@@ -130,18 +130,30 @@ typedef struct rmp2_desc {
  *     d = |origin - c| - radius, direction (origin - c)/|origin - c|.
  *   RAGGED_SPHERES: as SHARED_SPHERES but robot r only sees the spheres
  *     csr_index[csr_offset[r] .. csr_offset[r+1]) .
+ * Both table modes take either primitive:
+ *   PRIM_SPHERE  record = 4 floats (cx, cy, cz, radius)
+ *   PRIM_CAPSULE record = 8 floats (ax, ay, az, radius, bx, by, bz, unused): a segment a-b swept by a
+ *     sphere (the reference's cylinder obstacles, simulation.py:245-261, :495-500).  The engine forms the
+ *     closest point of the segment to the control point, c* = a + clamp((p-a).(b-a)/|b-a|^2, 0, 1)(b-a),
+ *     and proceeds as for a sphere centred at c*: this IS the closest-point preprocessing the reference
+ *     runs on the CPU before every step (simulation.py:462-484 calculate_distances -> Datamanager),
+ *     fused into the step.  rmp2_closest_points() below materialises the same pairs as arrays.
  */
 #define RMP2_OBS_NONE 0
 #define RMP2_OBS_EXPLICIT_PAIRS 1
 #define RMP2_OBS_SHARED_SPHERES 2
 #define RMP2_OBS_RAGGED_SPHERES 3
 
+#define RMP2_PRIM_SPHERE 0
+#define RMP2_PRIM_CAPSULE 1
+
 typedef struct rmp2_obstacles {
   int32_t mode;
-  int32_t n_spheres;                       /* K */
+  int32_t n_spheres;                       /* K = records in the primitive table             */
   int32_t n_pairs;                         /* P = pairs per robot, EXPLICIT_PAIRS            */
+  int32_t primitive;                       /* RMP2_PRIM_* (table modes)                      */
   int32_t pair_begin[RMP2_MAX_LEAVES + 1]; /* indexed by LEAF index; non-distance leaves: empty range */
-  const float *spheres;                    /* device [K][4]                                  */
+  const float *spheres;                    /* device [K][4] spheres or [K][8] capsules       */
   const float *p_link;                     /* device [R][P][3]                               */
   const float *p_obs;                      /* device [R][P][3]                               */
   const int32_t *csr_offset;               /* device [R+1]                                   */
@@ -202,6 +214,17 @@ typedef struct rmp2_rollout_cfg {
 int rmp2_rollout(rmp2_handle *h, float *q, float *qd, const float *goal, int32_t goal_stride,
                  const rmp2_obstacles *obs, const rmp2_rollout_cfg *cfg, const rmp2_outputs *out, int32_t R,
                  void *stream);
+
+/* Closest-point preprocessing as a stand-alone stage (the reference's calculate_distances,
+ * simulation.py:462-484, which fills the Datamanager arrays read by taskmap.py:115-138).
+ * `table` must be a SHARED_SPHERES table (either primitive) with K records.  For the i-th
+ * FK_DISTANCE leaf (leaf order) and record k, pair index i*K + k:
+ *   p_link[r][i*K + k][3] = origin of the leaf's frame (the control point),
+ *   p_obs [r][i*K + k][3] = nearest point on the surface of primitive k.
+ * The two arrays are a valid EXPLICIT_PAIRS input (pair_begin[l] = i*K); feeding them back
+ * reproduces the fused table mode.  p_link / p_obs: device [R][n_distance_leaves*K][3].   */
+int rmp2_closest_points(rmp2_handle *h, const float *q, const rmp2_obstacles *table, float *p_link, float *p_obs,
+                        int32_t R, void *stream);
 
 /* Forward kinematics of every frame: T[R][n_frames][16] row-major 4x4
  * (UrdfForwardKinematic.forward, kinematics.py:212-247, for all frames at once).      */

@@ -73,7 +73,8 @@ def make_obstacles(desc: D.Desc, *, spheres=None, p_link=None, p_obs=None, pair_
         keep += [p_link, p_obs]
     elif spheres is not None:
         spheres = np.ascontiguousarray(spheres, dtype=np.float32)
-        assert spheres.ndim == 2 and spheres.shape[1] == 4
+        assert spheres.ndim == 2 and spheres.shape[1] in (4, 8)
+        o.primitive = D.PRIM_CAPSULE if spheres.shape[1] == 8 else D.PRIM_SPHERE
         o.n_spheres = spheres.shape[0]
         o.spheres = spheres.ctypes.data
         keep.append(spheres)

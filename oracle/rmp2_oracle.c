@@ -528,8 +528,22 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
            * curvature term below keeps the reference's "p_obs is a fixed point" semantics
            * (it divides by the SURFACE distance d) */
           const int s = (obs->mode == RMP2_OBS_RAGGED_SPHERES) ? csr_idx[b] : b;
-          const float *sp = obs->spheres + 4 * s;
-          for (int k = 0; k < 3; ++k) diff[k] = pj[k] - (real)sp[k];
+          const int cap = obs->primitive == RMP2_PRIM_CAPSULE;
+          const float *sp = obs->spheres + (cap ? 8 : 4) * s;
+          real ctr[3] = {(real)sp[0], (real)sp[1], (real)sp[2]};
+          if (cap) { /* nearest point of the segment a-b to the control point (calculate_distances
+                      * stage, simulation.py:462-484, for a point-vs-capsule pair) */
+            real u[3], w[3];
+            for (int k = 0; k < 3; ++k) {
+              u[k] = (real)sp[4 + k] - (real)sp[k];
+              w[k] = pj[k] - (real)sp[k];
+            }
+            const real uu = dot3(u, u);
+            real t = uu > 0 ? dot3(w, u) / uu : 0;
+            t = t < 0 ? 0 : (t > 1 ? 1 : t);
+            for (int k = 0; k < 3; ++k) ctr[k] += t * u[k];
+          }
+          for (int k = 0; k < 3; ++k) diff[k] = pj[k] - ctr[k];
           const real dc = R_SQRT(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
           d = dc - (real)sp[3];
           for (int k = 0; k < 3; ++k) nh[k] = diff[k] / dc;

@@ -42,6 +42,8 @@ def lib():
     l.rmp2_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
                                C.POINTER(D.RolloutCfg), C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
     l.rmp2_forward_kinematics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    l.rmp2_closest_points.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(D.Obstacles), C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p]
     l.rmp2_differentiate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     if l.rmp2_abi_version() != D.ABI_VERSION:

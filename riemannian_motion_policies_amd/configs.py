@@ -122,6 +122,46 @@ def sample_spheres(rng: np.random.Generator, K: int = N_SPHERES) -> np.ndarray:
     return np.stack([r * np.cos(phi), r * np.sin(phi), z, rad], axis=1).astype(np.float32)
 
 
+def sample_capsules(rng: np.random.Generator, K: int = N_SPHERES) -> np.ndarray:
+    """The reference's cylinder clutter (simulation.py:495-500: centre cylindrical r~U(.4,.9), phi~U(0,2pi),
+    z~U(0,1); rpy~U(0,pi)^3; radius U(.05,.1); height .5) as capsules [K, 8] = (a, radius, b, 0): the cylinder
+    axis swept by its radius."""
+    r, phi, z = rng.uniform(0.4, 0.9, K), rng.uniform(0, 2 * np.pi, K), rng.uniform(0, 1, K)
+    centre = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
+    rpy = rng.uniform(0, np.pi, size=(K, 3))
+    cr, sr, cp, sp = np.cos(rpy[:, 0]), np.sin(rpy[:, 0]), np.cos(rpy[:, 1]), np.sin(rpy[:, 1])
+    cy, sy = np.cos(rpy[:, 2]), np.sin(rpy[:, 2])
+    # third column of Rz(yaw) Ry(pitch) Rx(roll) (PyBullet's getQuaternionFromEuler): the cylinder's local z axis
+    axis = np.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], axis=1)
+    rad = rng.uniform(0.05, 0.1, K)
+    half = 0.25
+    out = np.zeros((K, 8))
+    out[:, 0:3] = centre - half * axis
+    out[:, 3] = rad
+    out[:, 4:7] = centre + half * axis
+    return out.astype(np.float32)
+
+
+def pairs_from_capsules(origins: np.ndarray, capsules: np.ndarray):
+    """Explicit closest-point pairs equivalent to a capsule table, in fp64 numpy (independent of the engine and
+    of the C oracle): origins [R, C, 3], capsules [K, 8] -> p_link, p_obs [R, C*K, 3]."""
+    R, Cn, _ = origins.shape
+    K = capsules.shape[0]
+    o = origins.astype(np.float64)[:, :, None, :]
+    a = capsules[None, None, :, 0:3].astype(np.float64)
+    b = capsules[None, None, :, 4:7].astype(np.float64)
+    u = b - a
+    uu = (u * u).sum(-1, keepdims=True)
+    t = np.where(uu > 0, ((o - a) * u).sum(-1, keepdims=True) / np.where(uu > 0, uu, 1.0), 0.0)
+    c = a + np.clip(t, 0.0, 1.0) * u
+    diff = o - c
+    dist = np.sqrt((diff * diff).sum(-1, keepdims=True))
+    p_obs = c + capsules[None, None, :, 3:4].astype(np.float64) * diff / dist
+    p_link = np.broadcast_to(o, (R, Cn, K, 3))
+    return (p_link.reshape(R, Cn * K, 3).astype(np.float32).copy(),
+            p_obs.reshape(R, Cn * K, 3).astype(np.float32).copy())
+
+
 def pairs_from_spheres(origins: np.ndarray, spheres: np.ndarray):
     """Explicit closest-point pairs equivalent to the sphere table: origins [R, C, 3] (control
     point = frame origin), spheres [K,4] -> p_link, p_obs [R, C*K, 3] (fp32)."""

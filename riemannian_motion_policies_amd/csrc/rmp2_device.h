@@ -77,6 +77,7 @@ struct DevProgram {
 
 struct ObsArgs {
   int32_t mode, n_spheres, n_pairs;
+  int32_t capsule;  // 1: table records are 8-float capsules, 0: 4-float spheres
   const float* __restrict__ spheres;
   const float* __restrict__ p_link;
   const float* __restrict__ p_obs;
@@ -84,6 +85,19 @@ struct ObsArgs {
   const int32_t* __restrict__ csr_index;
   const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
 };
+
+// Nearest point of the segment a-b (capsule axis) to the control point p: the point-vs-capsule case of the
+// reference's CPU closest-point stage (simulation.py:462-484).  rec = (a.xyz, radius, b.xyz, unused).
+__device__ __forceinline__ void capsule_centre(const float4 ra, const float4 rb, const float p[3], float ctr[3]) {
+  const float u[3] = {rb.x - ra.x, rb.y - ra.y, rb.z - ra.z};
+  const float w[3] = {p[0] - ra.x, p[1] - ra.y, p[2] - ra.z};
+  const float uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  float t = uu > 0.f ? (w[0] * u[0] + w[1] * u[1] + w[2] * u[2]) / uu : 0.f;
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  ctr[0] = ra.x + t * u[0];
+  ctr[1] = ra.y + t * u[1];
+  ctr[2] = ra.z + t * u[2];
+}
 
 struct OutArgs {
   float* __restrict__ qdd;

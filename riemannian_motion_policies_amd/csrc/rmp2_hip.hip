@@ -211,10 +211,18 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
                 on = b < count;
                 sidx = on ? ci[b] : 0;
               }
-              const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[sidx];
-              diff[0] = cur.p[0] - sp.x;
-              diff[1] = cur.p[1] - sp.y;
-              diff[2] = cur.p[2] - sp.z;
+              float4 sp;
+              float ctr[3];
+              if (obs.capsule) {
+                sp = reinterpret_cast<const float4*>(obs.spheres)[2 * sidx];
+                capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * sidx + 1], cur.p, ctr);
+              } else {
+                sp = reinterpret_cast<const float4*>(obs.spheres)[sidx];
+                ctr[0] = sp.x, ctr[1] = sp.y, ctr[2] = sp.z;
+              }
+              diff[0] = cur.p[0] - ctr[0];
+              diff[1] = cur.p[1] - ctr[1];
+              diff[2] = cur.p[2] - ctr[2];
               const float dc = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
               d = dc - sp.w;
 #pragma unroll
@@ -513,6 +521,57 @@ rmp2_fk_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q,
     }
     o[12] = o[13] = o[14] = 0.f;
     o[15] = 1.f;
+  }
+}
+
+// Closest-point stage on its own: control point = frame origin of each distance leaf, nearest surface
+// point of every primitive of the shared table (simulation.py:462-484 calculate_distances; lane per robot).
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave)
+rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const ObsArgs obs,
+                    float* __restrict__ p_link, float* __restrict__ p_obs, int R) {
+  const int robot = blockIdx.x * kWave + threadIdx.x;
+  if (robot >= R) return;
+  const float* my_q = q + (size_t)robot * prog->n_dof;
+  FrameState cur;
+  FrameState slot[SLOTS > 0 ? SLOTS : 1];
+  for (int k = 0; k < prog->n_ops; ++k) {
+    const DevOp& op = prog->ops[k];
+    if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.restore == s) cur = slot[s];
+    }
+    float z[3];
+    visit_frame<false>(cur, op, op.qidx >= 0 ? my_q[op.qidx] : 0.f, 0.f, op.restore == -2, z);
+    if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        if (op.save == s) slot[s] = cur;
+    }
+    for (int li = 0; li < op.leaf_count; ++li) {
+      const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
+      if (lf.taskmap != RMP2_TASKMAP_FK_DISTANCE) continue;
+      const size_t base = ((size_t)robot * obs.n_pairs + obs.pair_begin[lf.index]) * 3;
+      for (int b = 0; b < obs.n_spheres; ++b) {
+        float4 sp;
+        float ctr[3];
+        if (obs.capsule) {
+          sp = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
+          capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1], cur.p, ctr);
+        } else {
+          sp = reinterpret_cast<const float4*>(obs.spheres)[b];
+          ctr[0] = sp.x, ctr[1] = sp.y, ctr[2] = sp.z;
+        }
+        const float diff[3] = {cur.p[0] - ctr[0], cur.p[1] - ctr[1], cur.p[2] - ctr[2]};
+        const float dc = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          p_link[base + 3 * b + c] = cur.p[c];
+          p_obs[base + 3 * b + c] = ctr[c] + sp.w * (diff[c] / dc);
+        }
+      }
+    }
   }
 }
 
@@ -856,7 +915,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + 4 * n_sph_lds);
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + (o.capsule ? 8 : 4) * n_sph_lds);
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
@@ -1021,6 +1080,8 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     } else if (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES) {
       if (obs->n_spheres < 0 || (obs->n_spheres > 0 && !obs->spheres))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "sphere table missing");
+      if (obs->primitive != RMP2_PRIM_SPHERE && obs->primitive != RMP2_PRIM_CAPSULE)
+        return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
       if (o.mode == RMP2_OBS_RAGGED_SPHERES && (!obs->csr_offset || (!obs->csr_index && obs->n_spheres > 0)))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
     } else {
@@ -1028,6 +1089,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     }
     o.n_spheres = obs->n_spheres;
     o.n_pairs = obs->n_pairs;
+    o.capsule = (o.mode != RMP2_OBS_EXPLICIT_PAIRS && obs->primitive == RMP2_PRIM_CAPSULE) ? 1 : 0;
     o.spheres = obs->spheres;
     o.p_link = obs->p_link;
     o.p_obs = obs->p_obs;
@@ -1074,6 +1136,51 @@ int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R,
     case 0: hipLaunchKernelGGL((rmp2_fk_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
     case 1: hipLaunchKernelGGL((rmp2_fk_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
     default: hipLaunchKernelGGL((rmp2_fk_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return RMP2_OK;
+}
+
+int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* table, float* p_link, float* p_obs,
+                        int32_t R, void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (!q || !table || !p_link || !p_obs || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
+  if (table->mode != RMP2_OBS_SHARED_SPHERES || table->n_spheres < 0 || (table->n_spheres > 0 && !table->spheres))
+    return fail(h, RMP2_ERR_INVALID_ARGUMENT, "closest_points needs a SHARED_SPHERES primitive table");
+  if (table->primitive != RMP2_PRIM_SPHERE && table->primitive != RMP2_PRIM_CAPSULE)
+    return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
+  if (R == 0 || !h->has_distance || table->n_spheres == 0) return RMP2_OK;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
+  }
+  // pair layout of the arrays written here: the i-th distance leaf owns pairs [i*K, (i+1)*K)
+  int32_t pb[RMP2_MAX_LEAVES + 1];
+  int acc = 0;
+  for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) {
+    pb[l] = acc;
+    if (l < h->n_leaves && std::find(h->distance_leaves.begin(), h->distance_leaves.end(), l) != h->distance_leaves.end())
+      acc += table->n_spheres;
+  }
+  if (!h->pair_begin_valid || std::memcmp(h->h_pair_begin, pb, sizeof(pb)) != 0) {
+    std::memcpy(h->h_pair_begin, pb, sizeof(pb));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pair_begin, h->h_pair_begin, sizeof(h->h_pair_begin), hipMemcpyHostToDevice, s));
+    h->pair_begin_valid = true;
+  }
+  ObsArgs o;
+  std::memset(&o, 0, sizeof(o));
+  o.mode = table->mode;
+  o.n_spheres = table->n_spheres;
+  o.n_pairs = acc;
+  o.capsule = table->primitive == RMP2_PRIM_CAPSULE ? 1 : 0;
+  o.spheres = table->spheres;
+  o.pair_begin = h->d_pair_begin;
+  const int blocks = (R + kWave - 1) / kWave;
+  switch (h->n_slots) {
+    case 0: hipLaunchKernelGGL((rmp2_closest_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
+    case 1: hipLaunchKernelGGL((rmp2_closest_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
+    default: hipLaunchKernelGGL((rmp2_closest_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
   }
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;

@@ -43,6 +43,9 @@ OBS_EXPLICIT_PAIRS = 1
 OBS_SHARED_SPHERES = 2
 OBS_RAGGED_SPHERES = 3
 
+PRIM_SPHERE = 0
+PRIM_CAPSULE = 1
+
 STATUS_NONFINITE = 1
 STATUS_RANK_DROP = 2
 STATUS_PINV_PATH = 4
@@ -88,6 +91,7 @@ class Obstacles(C.Structure):
         ("mode", C.c_int32),
         ("n_spheres", C.c_int32),
         ("n_pairs", C.c_int32),
+        ("primitive", C.c_int32),
         ("pair_begin", C.c_int32 * (MAX_LEAVES + 1)),
         ("spheres", C.c_void_p),
         ("p_link", C.c_void_p),

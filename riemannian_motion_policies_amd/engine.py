@@ -73,8 +73,10 @@ class Engine:
             keep += [p_link, p_obs]
         elif spheres is not None:
             spheres = _f32(spheres, self.device)
-            if spheres.dim() != 2 or spheres.shape[1] != 4:
-                raise ValueError("spheres must be [K, 4] = (cx, cy, cz, radius)")
+            if spheres.dim() != 2 or spheres.shape[1] not in (4, 8):
+                raise ValueError("spheres must be [K, 4] = (cx, cy, cz, radius) or, for capsules, "
+                                 "[K, 8] = (ax, ay, az, radius, bx, by, bz, unused)")
+            o.primitive = D.PRIM_CAPSULE if spheres.shape[1] == 8 else D.PRIM_SPHERE
             o.n_spheres, o.spheres = spheres.shape[0], spheres.data_ptr()
             keep.append(spheres)
             if csr_offset is not None:
@@ -205,6 +207,20 @@ class Engine:
         s = torch.cuda.current_stream(self.device).cuda_stream
         _native.check(self._lib.rmp2_forward_kinematics(self._h, q.data_ptr(), T.data_ptr(), R, s), self._h)
         return T
+
+    def closest_points(self, q: torch.Tensor, table):
+        """Closest-point preprocessing stage on its own (simulation.py:462-484 calculate_distances):
+        returns (p_link, p_obs), each [R, n_distance_leaves * K, 3], for the shared primitive `table`
+        built by obstacles(spheres=...).  The pair arrays can be fed back as obstacles(p_link=, p_obs=)."""
+        q = _f32(q, self.device)
+        R = q.shape[0]
+        P = len(self._dist_leaves) * int(table.n_spheres)
+        p_link = torch.empty((R, P, 3), dtype=torch.float32, device=self.device)
+        p_obs = torch.empty_like(p_link)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(self._lib.rmp2_closest_points(self._h, q.data_ptr(), C.byref(table), p_link.data_ptr(),
+                                                    p_obs.data_ptr(), R, s), self._h)
+        return p_link, p_obs
 
     def differentiate(self, q: torch.Tensor, qd: torch.Tensor, frame: int):
         q, qd = _f32(q, self.device), _f32(qd, self.device)

@@ -1,0 +1,158 @@
+"""GPU parity for the capsule primitive and the stand-alone closest-point stage (first
+"next" row: the reference's CPU stage simulation.py:462-484 feeding taskmap.py:115-138).
+
+Checker: the C oracle (capsule mode pinned against brute force and against the reference-faithful explicit-pair
+mode in tests/test_oracle_pins.py).  Tolerance as in test_gpu_parity.py for robots with >= 0.05 m clearance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_mod(hip_lib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _clearance(desc, q, caps):
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    T = O.forward_kinematics(desc, q, "f64")
+    frames = [desc.leaves[i].frame for i in range(desc.n_leaves) if desc.leaves[i].taskmap == 2]
+    org = T[:, frames][:, :, :3, 3]
+    pl, po = Cf.pairs_from_capsules(org, caps)
+    return org, np.linalg.norm(pl.astype(np.float64) - po, axis=-1).min(axis=1) if caps.shape[0] else None
+
+
+def _step(torch, eng, s, **obs):
+    o = eng.obstacles(**{k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in obs.items()})
+    st = torch.zeros(s["q"].shape[0], dtype=torch.int32, device="cuda")
+    out = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=o,
+                   status=st)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), st.cpu().numpy()
+
+
+def _gate(qdd, ref, clr, what):
+    e = np.abs(qdd.astype(np.float64) - ref).max(axis=1)
+    mag = np.maximum(1.0, np.abs(ref).max(axis=1))
+    clear = clr >= 0.05
+    assert clear.sum() >= 20, what
+    assert (e[clear] <= ATOL * mag[clear]).all(), f"{what}: clear robots worst {e[clear].max():.2e}"
+    fin = np.isfinite(ref).all(axis=1) & ~clear
+    if fin.any():
+        assert (e[fin] <= 1e-3 * mag[fin]).mean() > 0.95, f"{what}: near-contact robots"
+
+
+@pytest.mark.parametrize("kernel", ["quad", "lane"])
+@pytest.mark.parametrize("K", [9, 300])
+def test_capsule_table_vs_oracle(torch_mod, kernel, K):
+    """Shared capsule table: K=9 is staged in LDS, K=300 exceeds the 256-record LDS table (global reads)."""
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(40 + K)
+    R = 500
+    s = Cf.sample_panda_states(rng, R)
+    caps = Cf.sample_capsules(rng, K)
+    if K > 100:   # dense table: short thin capsules, so that a share of the robots keeps >= 0.05 m clearance
+        mid, half = 0.5 * (caps[:, 0:3] + caps[:, 4:7]), 0.05 * (caps[:, 4:7] - caps[:, 0:3])
+        caps[:, 0:3], caps[:, 4:7], caps[:, 3] = mid - half, mid + half, 0.1 * caps[:, 3]
+    caps[0, 4:7] = caps[0, 0:3]                       # one degenerate capsule (a == b)
+    _, desc = Cf.config3()
+    old = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel
+    try:
+        eng = Engine(desc, 0)
+    finally:
+        if old is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old
+    qdd, _ = _step(torch_mod, eng, s, spheres=caps)
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], spheres=caps)
+    _, clr = _clearance(desc, s["q"], caps)
+    _gate(qdd, ref["qdd64"], clr, f"capsules K={K} {kernel}")
+
+
+def test_ragged_capsules_vs_oracle(torch_mod):
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    R, K = 333, 9
+    s = Cf.sample_panda_states(rng, R)
+    caps = Cf.sample_capsules(rng, K)
+    off, idx = Cf.sample_ragged(rng, R, K)
+    _, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    qdd, _ = _step(torch_mod, eng, s, spheres=caps, csr_offset=off, csr_index=idx)
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], spheres=caps, csr_offset=off, csr_index=idx)
+    _, clr_all = _clearance(desc, s["q"], caps)      # conservative: clearance to the whole table
+    _gate(qdd, ref["qdd64"], clr_all, "ragged capsules")
+
+
+@pytest.mark.parametrize("prim", ["sphere", "capsule"])
+def test_closest_point_stage_feeds_explicit_pairs(torch_mod, prim):
+    """rmp2_closest_points writes exactly the arrays the reference's Datamanager holds; (i) they match an
+    independent fp64 numpy computation, (ii) fed back as EXPLICIT_PAIRS they reproduce the fused table mode."""
+    torch = torch_mod
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    R, K = 257, 9
+    s = Cf.sample_panda_states(rng, R)
+    table = Cf.sample_capsules(rng, K) if prim == "capsule" else Cf.sample_spheres(rng, K)
+    _, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    tab = eng.obstacles(spheres=torch.from_numpy(table))
+    p_link, p_obs = eng.closest_points(torch.from_numpy(s["q"]), tab)
+    torch.cuda.synchronize()
+    as_caps = table if prim == "capsule" else np.concatenate([table, table[:, :3], np.zeros((K, 1), np.float32)], axis=1)
+    org, clr = _clearance(desc, s["q"], as_caps)
+    pl_ref, po_ref = Cf.pairs_from_capsules(org, as_caps)
+    assert p_link.shape == (R, 8 * K, 3)
+    assert np.abs(p_link.cpu().numpy() - pl_ref).max() < 2e-6
+    assert np.abs(p_obs.cpu().numpy() - po_ref).max() < 2e-6
+    fused, _ = _step(torch, eng, s, spheres=table)
+    o = eng.obstacles(p_link=p_link, p_obs=p_obs)
+    fed = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=o)
+    torch.cuda.synchronize()
+    fed = fed.cpu().numpy()
+    clear = clr >= 0.05
+    mag = np.maximum(1.0, np.abs(fused).max(axis=1))
+    # the explicit form re-derives d = |p - p_obs| from rounded surface points: a few fp32 ulp of |p| in d
+    assert (np.abs(fed - fused).max(axis=1)[clear] <= 5e-5 * mag[clear]).all()
+
+
+def test_closest_points_abi_errors(torch_mod):
+    import ctypes as C
+    torch = torch_mod
+    from riemannian_motion_policies_amd import _native, configs as Cf, descriptor as D
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    lib = _native.lib()
+    q = torch.zeros((4, 9), device="cuda")
+    out = torch.zeros((4, 8, 3), device="cuda")
+    o = D.Obstacles()
+    o.mode = D.OBS_RAGGED_SPHERES
+    assert lib.rmp2_closest_points(eng._h, q.data_ptr(), C.byref(o), out.data_ptr(), out.data_ptr(), 4, None) == -1
+    assert b"SHARED_SPHERES" in lib.rmp2_last_error(eng._h)
+    sph = torch.zeros((1, 4), device="cuda")
+    o = eng.obstacles(spheres=sph)
+    o.primitive = 7
+    assert lib.rmp2_closest_points(eng._h, q.data_ptr(), C.byref(o), out.data_ptr(), out.data_ptr(), 4, None) == -1
+    qd = torch.zeros_like(q)
+    res = D.Outputs()
+    res.qdd = torch.zeros_like(q).data_ptr()
+    g = torch.zeros((4, 3), device="cuda")
+    assert lib.rmp2_step(eng._h, q.data_ptr(), qd.data_ptr(), g.data_ptr(), 3, C.byref(o), C.byref(res), 4, None) == -1
+    assert b"primitive" in lib.rmp2_last_error(eng._h)
