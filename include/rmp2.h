@@ -86,12 +86,18 @@ typedef struct rmp2_robot {
 #define RMP2_LEAF_JOINT_LIMIT_AVOIDANCE 7 /* rmp.py:349-382 params: gamma_p, gamma_d ;
                                         vec_a = lower limits, vec_b = upper limits             */
 #define RMP2_LEAF_CONFIG_SPACE_BIASING 8 /* rmp.py:318-347 params: gamma_p, gamma_d, w ; vec_a = q0 */
+#define RMP2_LEAF_COLLISION_AVOIDANCE 9 /* rmp.py:264-315 params: eta_rep, nu_rep, eta_damp, nu_damp, r, c ;
+                                        per-pair data d, n (rmp2_obstacles.dist / p_obs), FK_POINT map only.
+                                        beta = 0 in the reference (rmp.py:311) => metric w(d) * I          */
 
 /* task map of a leaf (the chains the reference's experiments build with chain_taskmaps,
  * taskmap.py:142-168) */
 #define RMP2_TASKMAP_IDENTITY 0    /* IdentityTaskmap                  taskmap.py:13-20        */
 #define RMP2_TASKMAP_FK_POSITION 1 /* FK(frame) -> 4x4 -> position     taskmap.py:22-31,45-54  */
 #define RMP2_TASKMAP_FK_DISTANCE 2 /* FK(frame) -> 4x4 -> distance     taskmap.py:22-31,115-138 */
+#define RMP2_TASKMAP_FK_POINT 3    /* FK(frame) -> relative 4x4 -> position   taskmap.py:22-31,79-99,45-54:
+                                      a point rigidly attached to the frame, one per pair (position given in the
+                                      JOINT frame, rmp2_obstacles.p_link); lever arm included, unlike FK_DISTANCE */
 
 typedef struct rmp2_leaf {
   int32_t kind;        /* RMP2_LEAF_*                                                     */
@@ -125,6 +131,9 @@ typedef struct rmp2_desc {
  *   EXPLICIT_PAIRS (reference-faithful): for every FK_DISTANCE leaf l a block of pairs
  *     p_link[r][pair_begin[l] .. pair_begin[l+1])[3], p_obs[...] in the robot base frame.
  *     value d = |p_link - p_obs|; derivative w.r.t. the FRAME ORIGIN only (quirk Q5).
+ *     For an FK_POINT leaf (CollisionAvoidance) the same pair range carries the Datamanager's
+ *     other three fields (data_management.py:14-16): p_link = 'relative_position' in the joint
+ *     frame, p_obs = 'normal_vec' in the base frame, dist[r][pair] = 'distance'.
  *   SHARED_SPHERES: one table spheres[K][4] = (cx, cy, cz, radius) for the whole fleet;
  *     every FK_DISTANCE leaf sees K pairs: control point = its frame origin,
  *     d = |origin - c| - radius, direction (origin - c)/|origin - c|.
@@ -158,6 +167,7 @@ typedef struct rmp2_obstacles {
   const float *p_obs;                      /* device [R][P][3]                               */
   const int32_t *csr_offset;               /* device [R+1]                                   */
   const int32_t *csr_index;                /* device [csr_offset[R]]                         */
+  const float *dist;                       /* device [R][P], FK_POINT leaves only (else NULL) */
 } rmp2_obstacles;
 
 /* ---- outputs ----------------------------------------------------------------------- */

@@ -47,7 +47,7 @@ def _ptr(a, ctype):
 
 
 def make_obstacles(desc: D.Desc, *, spheres=None, p_link=None, p_obs=None, pair_counts=None, csr_offset=None,
-                   csr_index=None):
+                   csr_index=None, dist=None):
     """Host-pointer `rmp2_obstacles`; returns (struct, keepalive)."""
     o = D.Obstacles()
     keep = []
@@ -71,6 +71,11 @@ def make_obstacles(desc: D.Desc, *, spheres=None, p_link=None, p_obs=None, pair_
         o.p_link = p_link.ctypes.data
         o.p_obs = p_obs.ctypes.data
         keep += [p_link, p_obs]
+        if dist is not None:
+            dist = np.ascontiguousarray(dist, dtype=np.float32)
+            assert dist.shape == p_link.shape[:2]
+            o.dist = dist.ctypes.data
+            keep.append(dist)
     elif spheres is not None:
         spheres = np.ascontiguousarray(spheres, dtype=np.float32)
         assert spheres.ndim == 2 and spheres.shape[1] in (4, 8)

@@ -354,6 +354,27 @@ static void leaf_config_space_biasing(const float *P, const float *q0, int n, co
   }
 }
 
+/* rmp.py:264-315 CollisionAvoidance: data-fed distance d and unit normal nv of one pair; xd = velocity of the
+ * attached point.  Metric w(d) * H with H = beta * zeta zeta^T + (1 - beta) * I at beta = 0 (rmp.py:311,
+ * helper/rmp_helper.py:67-74) = w(d) * I. */
+static void leaf_collision_avoidance(const float *P, real d, const real nv[3], const real xd[3], real xdd[3],
+                                     real *w_out) {
+  const real eta_rep = P[0], nu_rep = P[1], eta_damp = P[2], nu_damp = P[3], r = P[4];
+  const real alpha_rep = eta_rep * R_EXP(-d / nu_rep);                       /* rmp.py:284 */
+  const real alpha_damp = eta_damp / (d / nu_damp + (real)1e-6);            /* rmp.py:288-289 */
+  real s = -(xd[0] * nv[0] + xd[1] * nv[1] + xd[2] * nv[2]);                /* rmp.py:290 */
+  if (s < 0) s = 0;
+  const real nxd = nv[0] * xd[0] + nv[1] * xd[1] + nv[2] * xd[2];
+  for (int k = 0; k < 3; ++k) {
+    const real f_rep = alpha_rep * nv[k];
+    const real f_damp = alpha_damp * (s * nv[k] * nxd);                     /* P_obs xd, rmp.py:291-292 */
+    xdd[k] = f_rep - f_damp;
+  }
+  const real c2 = (real)-3 / (r * r), c3 = (real)2 / (r * r * r);           /* rmp.py:300-304 */
+  const real spline = c3 * d * d * d + c2 * d * d + (real)1;
+  *w_out = d > r ? (real)0 : spline;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* pull-back of one (J[k][n], A[k][k], xdd[k], c[k]) -> f[n], M[n][n]   rmp.py:165-167     */
 static void pullback(int k, int n, real J[][NMAX], real A[NMAX][NMAX], const real *xdd, const real *c, real *f,
@@ -434,8 +455,8 @@ static int pinv_solve(int n, const double *M, const double *f, double *x) {
 /* ------------------------------------------------------------------------------------ */
 /* One robot: RmpCore.evaluate   rmp.py:133-155                                            */
 static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32, const float *goal,
-                     const rmp2_obstacles *obs, const float *p_link, const float *p_obs, const int32_t *csr_idx,
-                     int csr_n, double *Mc, double *fc) {
+                     const rmp2_obstacles *obs, const float *p_link, const float *p_obs, const float *dist,
+                     const int32_t *csr_idx, int csr_n, double *Mc, double *fc) {
   const rmp2_robot *rb = &desc->robot;
   const int n = rb->n_dof;
   kin_state ks;
@@ -563,6 +584,59 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
           for (int j = 0; j < n; ++j) M[i][j] += Mb[i][j];
         }
       }
+    } else if (lf->taskmap == RMP2_TASKMAP_FK_POINT) {
+      /* chain [FK(frame), TaskmapRelative4x4(relative_pos), 4x4->pos]  (taskmap.py:79-99,150-160,
+       * experiments/two_joint_robot/05_obstacle_avoidance.py:51-61): one point per pair, rigidly attached to
+       * the frame at rel (joint frame):  x = p + R rel,  xd = v + w x r,  c = a + al x r + w x (w x r),
+       * J = geometric Jacobian at x.  fp32 reduce_sum over the pairs (rmp.py:149-150). */
+      if (lf->kind != RMP2_LEAF_COLLISION_AVOIDANCE) continue;
+      const real *Ti = ks.T[lf->frame];
+      const real *v = ks.v[lf->frame], *ab = ks.a[lf->frame], *w = ks.w[lf->frame], *al = ks.al[lf->frame];
+      const int B = (obs && obs->mode == RMP2_OBS_EXPLICIT_PAIRS) ? obs->pair_begin[l + 1] - obs->pair_begin[l] : 0;
+      for (int i = 0; i < n; ++i) {
+        f[i] = 0;
+        for (int j = 0; j < n; ++j) M[i][j] = 0;
+      }
+      for (int b = 0; b < B; ++b) {
+        const int pi = obs->pair_begin[l] + b;
+        const float *rel = p_link + 3 * pi, *nv32 = p_obs + 3 * pi;
+        const real d = (real)dist[pi];
+        real r[3], x[3], xd[3], c[3], t1[3], t2[3], nv[3];
+        for (int k = 0; k < 3; ++k) {
+          r[k] = Ti[4 * k] * (real)rel[0] + Ti[4 * k + 1] * (real)rel[1] + Ti[4 * k + 2] * (real)rel[2];
+          x[k] = Ti[4 * k + 3] + r[k];
+          nv[k] = (real)nv32[k];
+        }
+        cross3(w, r, t1);
+        for (int k = 0; k < 3; ++k) xd[k] = v[k] + t1[k];
+        cross3(w, t1, t2);
+        cross3(al, r, t1);
+        for (int k = 0; k < 3; ++k) c[k] = ab[k] + t1[k] + t2[k];
+        real Jp[3][NMAX];
+        for (int k = 0; k < 3; ++k)
+          for (int dd = 0; dd < n; ++dd) Jp[k][dd] = 0;
+        for (int j = 0; j < rb->n_frames; ++j) {
+          const int dd = rb->q_index[j];
+          if (dd < 0 || rb->joint_type[j] == RMP2_JOINT_FIXED || !is_ancestor_or_self(rb, j, lf->frame)) continue;
+          if (rb->joint_type[j] == RMP2_JOINT_REVOLUTE) {
+            real arm[3], col[3];
+            for (int k = 0; k < 3; ++k) arm[k] = x[k] - ks.T[j][4 * k + 3];
+            cross3(ks.z[j], arm, col);
+            for (int k = 0; k < 3; ++k) Jp[k][dd] = col[k];
+          } else {
+            for (int k = 0; k < 3; ++k) Jp[k][dd] = ks.z[j][k];
+          }
+        }
+        real xdd[3], wgt, A3[NMAX][NMAX], fb[NMAX], Mb[NMAX][NMAX];
+        leaf_collision_avoidance(lf->params, d, nv, xd, xdd, &wgt);
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) A3[i][j] = (i == j) ? wgt : (real)0;
+        pullback(3, n, Jp, A3, xdd, c, fb, Mb);
+        for (int i = 0; i < n; ++i) {
+          f[i] += fb[i];
+          for (int j = 0; j < n; ++j) M[i][j] += Mb[i][j];
+        }
+      }
     } else {
       continue;
     }
@@ -584,18 +658,19 @@ int ORC_NAME(orc_step)(const rmp2_desc *desc, const float *q, const float *qd, c
 #pragma omp parallel for schedule(static)
   for (int r = 0; r < R; ++r) {
     double Mc[NMAX * NMAX], fc[NMAX], x[NMAX];
-    const float *pl = NULL, *po = NULL;
+    const float *pl = NULL, *po = NULL, *pd = NULL;
     const int32_t *ci = NULL;
     int cn = 0;
     if (obs && obs->mode == RMP2_OBS_EXPLICIT_PAIRS) {
       pl = obs->p_link + (size_t)r * obs->n_pairs * 3;
       po = obs->p_obs + (size_t)r * obs->n_pairs * 3;
+      if (obs->dist) pd = obs->dist + (size_t)r * obs->n_pairs;
     } else if (obs && obs->mode == RMP2_OBS_RAGGED_SPHERES) {
       ci = obs->csr_index + obs->csr_offset[r];
       cn = obs->csr_offset[r + 1] - obs->csr_offset[r];
     }
     step_one(desc, q + (size_t)r * n, qd + (size_t)r * n, goal ? goal + (size_t)r * goal_stride : NULL, obs, pl, po,
-             ci, cn, Mc, fc);
+             pd, ci, cn, Mc, fc);
     const int dropped = pinv_solve(n, Mc, fc, x); /* rmp.py:153-154 */
     uint32_t st = dropped ? RMP2_STATUS_RANK_DROP : 0u;
     for (int i = 0; i < n; ++i) {

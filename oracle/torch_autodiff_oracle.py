@@ -237,6 +237,25 @@ class TaskmapJointFrame4x4ToDistance:
         return rmp_differentiate(self.forward)(q.repeat_interleave(B, dim=0), qd.repeat_interleave(B, dim=0))
 
 
+class TaskmapRelative4x4:
+    """taskmap.py:79-99: T_ref @ [I | relative_pos], one relative position per pair."""
+
+    def __init__(self, relative_pos):
+        self.relative_pos = torch.as_tensor(relative_pos, dtype=F32)
+
+    def forward(self, inp):
+        B = self.relative_pos.shape[0]
+        T_ref = inp.reshape(-1, 4, 4)
+        if T_ref.shape[0] != B:
+            T_ref = T_ref.expand(B, 4, 4)
+        T_rel = homogenous_transformation(torch.eye(3).expand(B, 3, 3), self.relative_pos)
+        return (T_ref @ T_rel).reshape(-1, 16)
+
+    def differentiate(self, q, qd):
+        B = self.relative_pos.shape[0]
+        return rmp_differentiate(self.forward)(q.repeat_interleave(B, dim=0), qd.repeat_interleave(B, dim=0))
+
+
 class _Chained:
     def __init__(self, t1, t2):
         self.t1, self.t2 = t1, t2
@@ -378,9 +397,34 @@ LEAF_FN = {1: "target_attractor", 2: "joint_velocity_cap", 3: "joint_damping", 4
            5: "cspace_biasing", 6: "target_policy", 7: "joint_limit_avoidance", 8: "config_space_biasing"}
 
 
+def collision_avoidance(P, d, vec, x, xd):
+    """rmp.py:264-315 (d, vec are the Datamanager's 'distance' / 'normal_vec')."""
+    eta_rep, nu_rep, eta_damp, nu_damp, r, c = [float(p) for p in P]
+    d = torch.as_tensor(d, dtype=F32)
+    vec = torch.as_tensor(vec, dtype=F32)
+
+    def motion(x, xd):
+        alpha_rep = eta_rep * torch.exp(-d / nu_rep)
+        f_rep = alpha_rep[:, None] * vec
+        eps = torch.tensor(1e-6, dtype=F32)
+        alpha_damp = eta_damp / (d / nu_damp + eps)
+        scaling = torch.clamp_min(torch.einsum('...i,...i->...', -xd, vec), 0.)
+        P_obs = torch.einsum('...,...i,...j->...ij', scaling, vec, vec)
+        f_damp = alpha_damp[:, None] * torch.einsum('bij,bj->bi', P_obs, xd)
+        return f_rep - f_damp
+
+    c_2, c_3 = -3 / r ** 2, 2 / r ** 3
+    spline = c_3 * d ** 3 + c_2 * d ** 2 + 0 * d + 1
+    w = torch.where(d > r, torch.zeros_like(spline), spline)
+    f_obs = motion(x, xd)
+    H = directionally_stretched_metric(v=f_obs, c=c, beta=0)
+    return f_obs, w[:, None, None] * H
+
+
 def evaluate_one(fkine, leaves, q, qd, goal, pairs=None):
     """RmpCore.evaluate for ONE robot.  leaves: list of dicts(kind, taskmap, frame(name), params,
-    vec_a, vec_b, goal_offset); pairs: {leaf_index: (p_link[B,3], p_obs[B,3])}.
+    vec_a, vec_b, goal_offset); pairs: {leaf_index: (p_link[B,3], p_obs[B,3])}, or
+    (relative_pos[B,3], normal_vec[B,3], distance[B]) for an attached-point leaf (taskmap 3).
     Returns (qdd fp64 [n], M fp64, f fp64)."""
     n = len(q)
     f_comb, M_comb = np.zeros(n), np.zeros((n, n))
@@ -391,6 +435,12 @@ def evaluate_one(fkine, leaves, q, qd, goal, pairs=None):
             taskmap = IdentityTaskmap()
         elif tm == 1:
             taskmap = chain_taskmaps([TaskmapByForwardKinematic(fkine, lf["frame"]), TaskmapFrom4x4ToPosition()])
+        elif tm == 3:
+            rel, nvec, dist = pairs[li]
+            if len(rel) == 0:
+                continue
+            taskmap = chain_taskmaps([TaskmapByForwardKinematic(fkine, lf["frame"]), TaskmapRelative4x4(rel),
+                                      TaskmapFrom4x4ToPosition()])
         else:
             pl, po = pairs[li]
             if len(pl) == 0:
@@ -416,6 +466,8 @@ def evaluate_one(fkine, leaves, q, qd, goal, pairs=None):
             xdd, A = joint_limit_avoidance(P, lf["vec_a"], lf["vec_b"], x, xd)
         elif kind == 8:
             xdd, A = config_space_biasing(P, lf["vec_a"], x, xd)
+        elif kind == 9:
+            xdd, A = collision_avoidance(P, dist, nvec, x, xd)
         else:
             raise ValueError(kind)
         Jt = J.transpose(1, 2)
@@ -434,7 +486,7 @@ def leaves_from_desc(desc, frame_names):
     out = []
     for i in range(desc.n_leaves):
         lf = desc.leaves[i]
-        npar = {1: 9, 2: 4, 3: 3, 4: 11, 5: 5, 6: 3, 7: 2, 8: 3}[lf.kind]
+        npar = {1: 9, 2: 4, 3: 3, 4: 11, 5: 5, 6: 3, 7: 2, 8: 3, 9: 6}[lf.kind]
         out.append({"kind": lf.kind, "taskmap": lf.taskmap,
                     "frame": frame_names[lf.frame] if lf.frame >= 0 else None,
                     "params": [float(np.float32(lf.params[k])) for k in range(npar)],

@@ -37,6 +37,10 @@ JOINT_LIMIT_PARAMS = [0.3, 1.0]
 # experiments/two_joint_robot/01_target_rmp_only.py:44
 TARGET_POLICY_PARAMS = [0.1, 0.5, 0.1]
 
+# experiments/two_joint_robot/05_obstacle_avoidance.py:48 and :57-58
+EXP05_TARGET_POLICY_PARAMS = [0.1, 0.1, 0.1]
+COLLISION_AVOIDANCE_PARAMS = [0.1 * np.e, 0.3, 1.0, 0.3, 1.1, 1e5]
+
 # 8 of the 10 collision frames, in frame order
 CONTROL_POINT_FRAMES = ["panda_joint2", "panda_joint3", "panda_joint4", "panda_joint5", "panda_joint7",
                         "panda_hand_joint", "panda_finger_joint1", "panda_finger_joint2"]
@@ -94,6 +98,45 @@ def config5_two_joint(solve="auto") -> Tuple[KinematicTable, D.Desc]:
         specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index(fr),
                                 OBSTACLE_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
     return t, D.build_desc(t, specs, solve)
+
+
+def exp05_two_joint(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """experiments/two_joint_robot/05_obstacle_avoidance.py:44-61: TargetPolicy on FK(link_23)->pos plus one
+    CollisionAvoidance per frame on the chain [FK(frame), TaskmapRelative4x4, 4x4->pos]."""
+    t = two_joint_table()
+    specs = [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("link_23"),
+                        EXP05_TARGET_POLICY_PARAMS, goal_len=3, name="target")]
+    for fr in t.frame_names:
+        specs.append(D.LeafSpec(D.LEAF_COLLISION_AVOIDANCE, D.TASKMAP_FK_POINT, t.frame_index(fr),
+                                COLLISION_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
+    return t, D.build_desc(t, specs, solve)
+
+
+def exp05_panda(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """The exp-05 leaf on the 9-dof arm (not a reference script; exercises the attached-point map at n = 9):
+    TargetAttractor + JointDamping + CollisionAvoidance on the 8 control-point frames."""
+    t = panda_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                   TARGET_ATTRACTOR_PARAMS, goal_len=3, name="attractor"),
+        D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, JOINT_DAMPING_PARAMS, name="joint_damping"),
+    ]
+    for fr in CONTROL_POINT_FRAMES:
+        specs.append(D.LeafSpec(D.LEAF_COLLISION_AVOIDANCE, D.TASKMAP_FK_POINT, t.frame_index(fr),
+                                COLLISION_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
+    return t, D.build_desc(t, specs, solve)
+
+
+def sample_point_pairs(rng: np.random.Generator, R: int, n_leaves: int, B: int):
+    """Datamanager fields of the attached-point leaves (data_management.py:14-16) as arrays:
+    relative_position [R, n_leaves*B, 3] (joint frame), normal_vec [R, n_leaves*B, 3] (unit), distance
+    [R, n_leaves*B] (some beyond the metric radius r = 1.1, where the spline weight is cut to 0)."""
+    P = n_leaves * B
+    rel = rng.uniform(-0.15, 0.15, size=(R, P, 3))
+    nv = rng.normal(size=(R, P, 3))
+    nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
+    d = rng.uniform(0.05, 1.3, size=(R, P))
+    return rel.astype(np.float32), nv.astype(np.float32), d.astype(np.float32)
 
 
 # ---- synthetic inputs (SURVEY 8(d) "Value distributions / seeds") -------------------------

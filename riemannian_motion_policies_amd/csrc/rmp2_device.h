@@ -84,6 +84,7 @@ struct ObsArgs {
   const int32_t* __restrict__ csr_offset;
   const int32_t* __restrict__ csr_index;
   const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
+  const float* __restrict__ dist;          // [R][P] distances of the attached-point leaves
 };
 
 // Nearest point of the segment a-b (capsule axis) to the control point p: the point-vs-capsule case of the
@@ -316,6 +317,22 @@ __device__ __forceinline__ void leaf_obstacle_avoidance(const float* __restrict_
 template <int N>
 __device__ __forceinline__ constexpr int sym_idx(int i, int j) {
   return i * N - (i * (i - 1)) / 2 + (j - i);
+}
+
+// rmp.py:264-315 CollisionAvoidance on one attached point: data-fed distance d and unit normal nv; metric
+// w(d) * I (beta = 0, rmp.py:311).
+__device__ __forceinline__ void leaf_collision_avoidance(const float* P, float d, const float nv[3], const float xd[3],
+                                                         float xdd[3], float& wgt) {
+  const float eta_rep = P[0], nu_rep = P[1], eta_damp = P[2], nu_damp = P[3], r = P[4];
+  const float alpha_rep = eta_rep * expf(-d / nu_rep);
+  const float alpha_damp = eta_damp / (d / nu_damp + 1e-6f);
+  const float nxd = nv[0] * xd[0] + nv[1] * xd[1] + nv[2] * xd[2];
+  const float s = fmaxf(-nxd, 0.f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) xdd[k] = alpha_rep * nv[k] - alpha_damp * (s * nv[k] * nxd);
+  const float c2 = -3.f / (r * r), c3 = 2.f / (r * r * r);
+  const float spline = c3 * d * d * d + c2 * d * d + 1.f;
+  wgt = d > r ? 0.f : spline;
 }
 
 template <int N>

@@ -123,28 +123,43 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
       }
       if (op.leaf_count == 0) continue;
 
-      // Jacobian columns of this frame's origin: z_j x (p - o_j) (revolute) or z_j (prismatic)
+      // Jacobian columns of a point moving with this frame: z_j x (pt - o_j) (revolute) or z_j (prismatic)
       float col[N][3];
+      auto fill_cols = [&](const float pt[3]) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if ((op.anc_mask >> j) & 1u) {
-          const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
-          if ((rev_mask >> j) & 1u) {
-            const float d[3] = {cur.p[0] - zo[(j * 6 + 3) * kWave], cur.p[1] - zo[(j * 6 + 4) * kWave],
-                                cur.p[2] - zo[(j * 6 + 5) * kWave]};
-            cross3(zj, d, col[j]);
+        for (int j = 0; j < N; ++j) {
+          if ((op.anc_mask >> j) & 1u) {
+            const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
+            if ((rev_mask >> j) & 1u) {
+              const float d[3] = {pt[0] - zo[(j * 6 + 3) * kWave], pt[1] - zo[(j * 6 + 4) * kWave],
+                                  pt[2] - zo[(j * 6 + 5) * kWave]};
+              cross3(zj, d, col[j]);
+            } else {
+              col[j][0] = zj[0];
+              col[j][1] = zj[1];
+              col[j][2] = zj[2];
+            }
           } else {
-            col[j][0] = zj[0];
-            col[j][1] = zj[1];
-            col[j][2] = zj[2];
+            col[j][0] = col[j][1] = col[j][2] = 0.f;
           }
-        } else {
-          col[j][0] = col[j][1] = col[j][2] = 0.f;
         }
-      }
+      };
+      fill_cols(cur.p);
 
       for (int li = 0; li < op.leaf_count; ++li) {
         const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
+        // attached-point leaves (taskmap.py:79-99 chain) pull every pair back through its own Jacobian:
+        // one trip of the block below per pair; all other leaves take exactly one trip
+        const bool point = lf.taskmap == RMP2_TASKMAP_FK_POINT;
+        int trips = 1;
+        size_t pbase = 0;
+        if (point) {
+          const int pb = obs.pair_begin[lf.index];
+          trips = obs.pair_begin[lf.index + 1] - pb;
+          pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
+        }
+#pragma nounroll
+        for (int trip = 0; trip < trips; ++trip) {
         float S[6], h[3];
         if (lf.taskmap == RMP2_TASKMAP_FK_POSITION) {
           // chain [FK(frame), 4x4 -> position]: x = p, xd = v, c = a_bias (taskmap.py:150-160)
@@ -159,6 +174,33 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
           h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
           h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
           h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+        } else if (point) {
+          // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position] for pair `trip`:
+          //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J = Jacobian at x
+          const float* rel = obs.p_link + (pbase + trip) * 3;
+          const float* nvp = obs.p_obs + (pbase + trip) * 3;
+          const float dd = obs.dist[pbase + trip];
+          float r[3], pt[3], t1[3], t2[3], xdp[3], cp[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            r[c] = cur.R[3 * c] * rel[0] + cur.R[3 * c + 1] * rel[1] + cur.R[3 * c + 2] * rel[2];
+            pt[c] = cur.p[c] + r[c];
+          }
+          cross3(cur.w, r, t1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xdp[c] = cur.v[c] + t1[c];
+          cross3(cur.w, t1, t2);
+          cross3(cur.al, r, t1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) cp[c] = cur.a[c] + t1[c] + t2[c];
+          fill_cols(pt);
+          const float nv[3] = {nvp[0], nvp[1], nvp[2]};
+          float xdd[3], wgt;
+          leaf_collision_avoidance(lf.P, dd, nv, xdp, xdd, wgt);
+          S[0] = S[3] = S[5] = wgt;
+          S[1] = S[2] = S[4] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] = wgt * (xdd[c] - cp[c]);
         } else {
           // chain [FK(frame), 4x4 -> distance] over this leaf's pairs.  Every pair pulls back
           // through the SAME 3 x n Jacobian, so the per-pair rank-1 updates collapse into
@@ -247,6 +289,8 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
           }
         }
         pull_position<N>(col, op.anc_mask, S, h, Ms, fv);
+        }  // trip
+        if (point) fill_cols(cur.p);
       }
     }
 
@@ -671,6 +715,7 @@ struct rmp2_handle {
   DevProgram* d_prog_full = nullptr;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
+  bool has_point = false;  // attached-point leaves (CollisionAvoidance): lane-per-robot kernel only
   int n_id_leaves = 0;
   int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
@@ -866,6 +911,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
         goal_len = 3;
         break;
       case RMP2_TASKMAP_FK_DISTANCE: ok = s.kind == RMP2_LEAF_OBSTACLE_AVOIDANCE; break;
+      case RMP2_TASKMAP_FK_POINT: ok = s.kind == RMP2_LEAF_COLLISION_AVOIDANCE; break;
       default: break;
     }
     if (!ok) return err = "leaf " + std::to_string(l) + ": this (kind, taskmap) pair has no kernel", RMP2_ERR_UNSUPPORTED;
@@ -943,7 +989,9 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
   //    splits 4 ways); the only kernel with the fused rollout loop;
   //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
-  const bool lane = !rollout && (h->kernel_choice == 1 || (h->kernel_choice == 0 && !h->has_distance && R > 16384));
+  //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
+  const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
+                                 (h->kernel_choice == 0 && !h->has_distance && R > 16384));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
     case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
@@ -1015,6 +1063,8 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();
+  for (int l = 0; l < desc->n_leaves; ++l)
+    if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_POINT) h->has_point = true;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&h->d_prog, sizeof(DevProgram));
   if (e == hipSuccess) e = hipMemcpy(h->d_prog, &P, sizeof(DevProgram), hipMemcpyHostToDevice);
@@ -1061,7 +1111,14 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   ObsArgs o;
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;
-  if (h->has_distance) {
+  if (h->has_point) {
+    const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
+    if (rollout) return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: attached-point leaves take per-step pair data");
+    if (o.mode != RMP2_OBS_EXPLICIT_PAIRS || !obs->dist)
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT,
+                  "attached-point leaves need EXPLICIT_PAIRS data: p_link = relative_position, p_obs = normal_vec, dist");
+  }
+  if (h->has_distance || h->has_point) {
     if (o.mode == RMP2_OBS_NONE)
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "this RMP set has distance leaves: obstacles are required");
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) {
@@ -1095,6 +1152,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     o.p_obs = obs->p_obs;
     o.csr_offset = obs->csr_offset;
     o.csr_index = obs->csr_index;
+    o.dist = obs->dist;
     o.pair_begin = h->d_pair_begin;
   }
   OutArgs oa{out->qdd, out->status, out->M, out->f};

@@ -4,8 +4,8 @@ The reference keeps per-frame tf.Variables that PyBullet closest-point tuples ar
 into; the distance task maps hold references to them.  Here the holders are `ArrayVar`s
 (assign()/value), the same per-frame / per-key dictionary is offered, and RmpCore.evaluate
 gathers the pair arrays of all distance leaves into the [R,P,3] device arrays the kernel
-reads.  PyBullet glue (Datamanager.preprocess -> one eager FK per tuple) is out of scope
-(SURVEY section 2 row 9); `update` accepts the same tuple list but only stores the points.
+reads.  `update` accepts the tuple list of the reference's Simulation.calculate_distances and fills
+all five fields, 'relative_position' included (preprocess: one device FK per frame).
 """
 from __future__ import annotations
 
@@ -66,3 +66,8 @@ class Datamanager:
             st["pos_on_obstacle_in_base_frame"].assign(np.stack([d[2] for d in rows]))
             st["normal_vec"].assign(np.stack([d[3] for d in rows]))
             st["distance"].assign(np.asarray([d[4] for d in rows], dtype=np.float32))
+            # data_management.py:33-53 preprocess/_get_relative_pos: the point on the link expressed in the joint
+            # frame, rel = R_base_joint^T (p_link - p_joint); one device FK per frame instead of one per tuple
+            T = np.asarray(self.fkine.forward(np.asarray(q, dtype=np.float32)[None, :], frame))[0]
+            p_link = np.stack([d[1] for d in rows]).astype(np.float32)
+            st["relative_position"].assign((p_link - T[:3, 3][None, :]) @ T[:3, :3])

@@ -29,10 +29,12 @@ LEAF_CSPACE_BIASING = 5
 LEAF_TARGET_POLICY = 6
 LEAF_JOINT_LIMIT_AVOIDANCE = 7
 LEAF_CONFIG_SPACE_BIASING = 8
+LEAF_COLLISION_AVOIDANCE = 9
 
 TASKMAP_IDENTITY = 0
 TASKMAP_FK_POSITION = 1
 TASKMAP_FK_DISTANCE = 2
+TASKMAP_FK_POINT = 3
 
 SOLVE_AUTO = 0
 SOLVE_PINV = 1
@@ -98,6 +100,7 @@ class Obstacles(C.Structure):
         ("p_obs", C.c_void_p),
         ("csr_offset", C.c_void_p),
         ("csr_index", C.c_void_p),
+        ("dist", C.c_void_p),
     ]
 
 
@@ -189,4 +192,5 @@ def build_desc(table: KinematicTable, leaves: Iterable[LeafSpec], solve: str | i
 
 
 def distance_leaf_indices(desc: Desc) -> List[int]:
-    return [i for i in range(desc.n_leaves) if desc.leaves[i].taskmap == TASKMAP_FK_DISTANCE]
+    """Leaves that consume per-pair obstacle data (pair_begin ranges): distance and attached-point maps."""
+    return [i for i in range(desc.n_leaves) if desc.leaves[i].taskmap in (TASKMAP_FK_DISTANCE, TASKMAP_FK_POINT)]

@@ -47,7 +47,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------
     def obstacles(self, *, spheres=None, p_link=None, p_obs=None, pair_counts: Optional[Sequence[int]] = None,
-                  csr_offset=None, csr_index=None):
+                  csr_offset=None, csr_index=None, dist=None):
         """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result)."""
         o = D.Obstacles()
         keep = []
@@ -71,6 +71,12 @@ class Engine:
                     k += 1
             o.p_link, o.p_obs = p_link.data_ptr(), p_obs.data_ptr()
             keep += [p_link, p_obs]
+            if dist is not None:   # attached-point leaves: p_link = relative_position, p_obs = normal_vec
+                dist = _f32(dist, self.device)
+                if tuple(dist.shape) != tuple(p_link.shape[:2]):
+                    raise ValueError("dist must be [R, P]")
+                o.dist = dist.data_ptr()
+                keep.append(dist)
         elif spheres is not None:
             spheres = _f32(spheres, self.device)
             if spheres.dim() != 2 or spheres.shape[1] not in (4, 8):
@@ -214,7 +220,8 @@ class Engine:
         built by obstacles(spheres=...).  The pair arrays can be fed back as obstacles(p_link=, p_obs=)."""
         q = _f32(q, self.device)
         R = q.shape[0]
-        P = len(self._dist_leaves) * int(table.n_spheres)
+        n_dist = sum(1 for i in range(self.desc.n_leaves) if self.desc.leaves[i].taskmap == D.TASKMAP_FK_DISTANCE)
+        P = n_dist * int(table.n_spheres)
         p_link = torch.empty((R, P, 3), dtype=torch.float32, device=self.device)
         p_obs = torch.empty_like(p_link)
         s = torch.cuda.current_stream(self.device).cuda_stream

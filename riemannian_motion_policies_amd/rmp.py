@@ -13,7 +13,7 @@ import torch
 from . import descriptor as D
 from .data_management import as_array
 from .rmp2 import RiemannianMotionPolicy
-from .taskmap import (IdentityTaskmap, TaskmapJointFrame4x4ToDistance, TaskmapSphereDistance, classify)
+from .taskmap import IdentityTaskmap, TaskmapSphereDistance, classify
 from .urdf import KinematicTable
 
 
@@ -108,22 +108,37 @@ class RmpCore:
         if goals:
             goal = np.concatenate([g if g.ndim == 2 else np.broadcast_to(g, (R, g.shape[0])) for g in goals], axis=1) \
                 if per_robot else np.concatenate(goals)
-        # distance data: gather the holders of all distance leaves
+        # obstacle data: gather the holders of all pair-consuming leaves (leaf order)
         obstacles = None
-        dist = [rmp.taskmap.stages()[-1] for rmp in self.rmps.values() if classify(rmp.taskmap)[0] == D.TASKMAP_FK_DISTANCE]
-        if dist:
-            if all(isinstance(t, TaskmapJointFrame4x4ToDistance) for t in dist):
-                pl = [np.asarray(as_array(t.pos_on_link_in_base_frame), np.float32) for t in dist]
-                po = [np.asarray(as_array(t.pos_on_obstacle_in_base_frame), np.float32) for t in dist]
-                pl = [a if a.ndim == 3 else np.broadcast_to(a, (R,) + a.shape) for a in pl]
-                po = [a if a.ndim == 3 else np.broadcast_to(a, (R,) + a.shape) for a in po]
-                obstacles = eng.obstacles(p_link=np.concatenate(pl, axis=1), p_obs=np.concatenate(po, axis=1),
-                                          pair_counts=[a.shape[1] for a in pl])
-            elif all(isinstance(t, TaskmapSphereDistance) for t in dist):
+        pair_rmps = [(rmp, classify(rmp.taskmap)) for rmp in self.rmps.values()]
+        pair_rmps = [(rmp, kind, last) for rmp, (kind, _, last) in pair_rmps
+                     if kind in (D.TASKMAP_FK_DISTANCE, D.TASKMAP_FK_POINT)]
+        if pair_rmps:
+            if all(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
                 sp = spheres if spheres is not None else self.spheres
                 if sp is None:
                     raise ValueError("TaskmapSphereDistance leaves need evaluate(..., spheres=[K,4])")
                 obstacles = eng.obstacles(spheres=as_array(sp) if not isinstance(sp, torch.Tensor) else sp)
+            elif not any(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
+                def fleet(a, nd):
+                    a = np.asarray(as_array(a), np.float32)
+                    return a if a.ndim == nd else np.broadcast_to(a, (R,) + a.shape)
+                pl, po, dd = [], [], []
+                for rmp, kind, last in pair_rmps:
+                    if kind == D.TASKMAP_FK_DISTANCE:   # closest-point pairs (taskmap.py:115-138)
+                        pl.append(fleet(last.pos_on_link_in_base_frame, 3))
+                        po.append(fleet(last.pos_on_obstacle_in_base_frame, 3))
+                        dd.append(np.zeros(pl[-1].shape[:2], np.float32))
+                    else:                               # attached points (taskmap.py:79-99, rmp.py:264-315)
+                        pl.append(fleet(last.relative_pos, 3))
+                        po.append(fleet(rmp.vec, 3))
+                        dd.append(fleet(rmp.d, 2))
+                    if not (pl[-1].shape == po[-1].shape and dd[-1].shape == pl[-1].shape[:2]):
+                        raise ValueError(f"{rmp.name}: pair arrays disagree in shape")
+                has_point = any(kind == D.TASKMAP_FK_POINT for _, kind, _ in pair_rmps)
+                obstacles = eng.obstacles(p_link=np.concatenate(pl, axis=1), p_obs=np.concatenate(po, axis=1),
+                                          dist=np.concatenate(dd, axis=1) if has_point else None,
+                                          pair_counts=[a.shape[1] for a in pl])
             else:
                 raise NotImplementedError("mixing explicit-pair and sphere distance task maps in one core")
         out = eng.step(q2, qd2, goal=goal, obstacles=obstacles)
@@ -157,15 +172,22 @@ class TargetPolicy(RiemannianMotionPolicy):
 
 
 class CollisionAvoidance(RiemannianMotionPolicy):
-    """rmp.py:264-315 -- TwoJoint experiment 05 only; SURVEY 8(f)-4 ("next" row), no kernel yet."""
+    """rmp.py:264-315: repulsion + directional damping away from a data-fed obstacle direction, metric
+    spline(d) * I.  `d` [B] / `vec` [B,3] are array holders (the Datamanager's 'distance' / 'normal_vec'),
+    re-read at every evaluate; the task map must be the chain [FK(frame), TaskmapRelative4x4, 4x4->position]
+    (experiments/two_joint_robot/05_obstacle_avoidance.py:51-61)."""
+    KIND = D.LEAF_COLLISION_AVOIDANCE
 
     def __init__(self, d, vec, eta_rep, nu_rep, eta_damp, nu_damp, r, c, taskmap, name='collision_avoidance'):
         super().__init__(name, taskmap)
         self.d, self.vec = d, vec
         self.eta_rep, self.nu_rep, self.eta_damp, self.nu_damp, self.r, self.c = eta_rep, nu_rep, eta_damp, nu_damp, r, c
 
-    def leaf_spec(self, frame_index_of):
-        raise NotImplementedError("CollisionAvoidance (rmp.py:264-315) is outside the accelerated path (SURVEY 8(f)-4)")
+    def _params(self):
+        return [self.eta_rep, self.nu_rep, self.eta_damp, self.nu_damp, self.r, self.c]
+
+    def _allowed_taskmaps(self):
+        return (D.TASKMAP_FK_POINT,)
 
 
 class ConfigurationSpaceBiasing(RiemannianMotionPolicy):

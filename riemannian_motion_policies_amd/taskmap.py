@@ -83,13 +83,24 @@ class TaskmapFrom4x4ToQuaternions(Taskmap):
 
 
 class TaskmapRelative4x4(Taskmap):
-    """taskmap.py:79-99 -- TwoJoint experiment 05 only; SURVEY 8(f)-4 ("next" row)."""
+    """vec(T_ref) -> vec(T_ref @ [I | relative_pos_b]) for every pair b (taskmap.py:79-99): a point rigidly
+    attached to the reference frame.  Used in the chain [FK(frame), TaskmapRelative4x4, 4x4->position] by the
+    CollisionAvoidance leaves of experiments/two_joint_robot/05_obstacle_avoidance.py:51-61.
+
+    `relative_pos` is an array holder ([B,3] for one robot, [R,B,3] for a fleet; joint-frame coordinates) read
+    at every RmpCore.evaluate, like the reference's tf.Variable (data_management.py:16)."""
 
     def __init__(self, relative_pos):
         self.relative_pos = relative_pos
 
     def forward(self, input):
-        raise NotImplementedError("TaskmapRelative4x4 is outside the accelerated path (SURVEY 8(f)-4)")
+        from .data_management import as_array
+        rel = np.asarray(as_array(self.relative_pos), dtype=np.float32).reshape(-1, 3)
+        T = np.asarray(input, dtype=np.float32).reshape(-1, 4, 4)
+        T = np.broadcast_to(T, (rel.shape[0], 4, 4))
+        T_rel = np.broadcast_to(np.eye(4, dtype=np.float32), (rel.shape[0], 4, 4)).copy()
+        T_rel[:, :3, 3] = rel
+        return (T @ T_rel).reshape(-1, 16)
 
 
 class TaskmapJointFrame4x4ToDistance(Taskmap):
@@ -172,7 +183,10 @@ def classify(taskmap):
             return D.TASKMAP_FK_POSITION, st[0], st[1]
         if isinstance(st[1], (TaskmapJointFrame4x4ToDistance, TaskmapSphereDistance)):
             return D.TASKMAP_FK_DISTANCE, st[0], st[1]
+    if (len(st) == 3 and isinstance(st[0], TaskmapByForwardKinematic) and isinstance(st[1], TaskmapRelative4x4)
+            and isinstance(st[2], TaskmapFrom4x4ToPosition)):
+        return D.TASKMAP_FK_POINT, st[0], st[1]
     names = " -> ".join(type(s).__name__ for s in st)
     raise NotImplementedError(
         f"task-map chain [{names}] has no kernel; supported: IdentityTaskmap, "
-        "[FK, 4x4->position], [FK, 4x4->distance] (SURVEY 8(b))")
+        "[FK, 4x4->position], [FK, 4x4->distance], [FK, relative 4x4, 4x4->position] (SURVEY 8(b))")

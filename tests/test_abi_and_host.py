@@ -114,6 +114,39 @@ def test_class_surface_compiles_to_the_same_descriptor():
     assert "no RMPs in use" in str(rmp.RmpCore())
 
 
+def test_exp05_object_graph_compiles_to_attached_point_leaves():
+    """experiments/two_joint_robot/05_obstacle_avoidance.py:44-61 written against the class surface serialises to
+    configs.exp05_two_joint(): TargetPolicy + one (CollisionAvoidance, FK_POINT) leaf per frame."""
+    from riemannian_motion_policies_amd import rmp, taskmap, urdf
+    from riemannian_motion_policies_amd.data_management import Datamanager
+    from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
+    fk = UrdfForwardKinematic(urdf.TWO_JOINT_URDF, urdf.TWO_JOINT_ORDER)
+    dm = Datamanager(fk)
+    core = rmp.RmpCore()
+    ee = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fk, frame='link_23'), taskmap.TaskmapFrom4x4ToPosition()])
+    core.add_rmp(rmp.TargetPolicy(alpha=0.1, beta=0.1, c=0.1, goal=[1.4, -1.4, 0.1], name='target', taskmap=ee))
+    for frame in fk.frame_names:
+        tm = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fk, frame),
+                                     taskmap.TaskmapRelative4x4(relative_pos=dm[frame]['relative_position']),
+                                     taskmap.TaskmapFrom4x4ToPosition()])
+        assert taskmap.classify(tm)[0] == D.TASKMAP_FK_POINT
+        core.add_rmp(rmp.CollisionAvoidance(d=dm[frame]['distance'], vec=dm[frame]['normal_vec'], eta_rep=0.1 * np.e,
+                                            nu_rep=0.3, eta_damp=1, nu_damp=0.3, r=1.1, c=1e5, taskmap=tm,
+                                            name=f'collision_avoidance_for_{frame}'))
+    specs = [r.leaf_spec(lambda f: fk.table.frame_index(f.frame)) for r in core.rmps.values()]
+    got = D.build_desc(fk.table, specs)
+    _, want = Cf.exp05_two_joint()
+    assert bytes(got) == bytes(want)
+    assert D.distance_leaf_indices(got) == [1, 2, 3]
+    # TaskmapRelative4x4.forward is plain array code: T_ref @ [I | rel]
+    rel = np.array([[0.1, 0.0, 0.0], [0.0, 0.2, 0.0]], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    T[:3, 3] = [1, 2, 3]
+    out = taskmap.TaskmapRelative4x4(rel).forward(T.reshape(1, 16)).reshape(2, 4, 4)
+    assert np.allclose(out[:, :3, 3], [[1, 2.1, 3], [0.8, 2, 3]]) and np.allclose(out[:, :3, :3], T[:3, :3])
+
+
 def test_unsupported_chains_raise():
     from riemannian_motion_policies_amd import rmp, taskmap, urdf
     from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic

@@ -196,3 +196,15 @@ def test_capsule_table_equals_explicit_closest_point_pairs(golden_dir):
     rs = O.step(d, g["q"], g["qd"], g["goal"], spheres=caps[:1, :4])
     rc = O.step(d, g["q"], g["qd"], g["goal"], spheres=caps[:1])
     assert np.array_equal(rs["qdd"], rc["qdd"])
+
+
+@pytest.mark.parametrize("key", ["tj", "pd"])
+def test_golden_exp05_attached_point_leaves(golden_dir, key):
+    """SURVEY 8(a) a11 + a21: chain [FK, TaskmapRelative4x4, 4x4->pos] with CollisionAvoidance; the analytic
+    restatement (lever arm in J, xd and c) against the nested-autograd vectors."""
+    g = np.load(os.path.join(golden_dir, "exp05.npz"))
+    _, d = Cf.exp05_two_joint() if key == "tj" else Cf.exp05_panda()
+    r = O.step(d, g[f"{key}_q"], g[f"{key}_qd"], g[f"{key}_goal"], p_link=g[f"{key}_rel"], p_obs=g[f"{key}_nvec"],
+               dist=g[f"{key}_dist"])
+    assert np.abs(r["M"] - g[f"{key}_M"]).max() < 5e-6 and np.abs(r["f"] - g[f"{key}_f"]).max() < 2e-6
+    _check(r["qdd64"], g[f"{key}_qdd"], f"exp05 {key}")
