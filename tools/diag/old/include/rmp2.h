@@ -1,0 +1,219 @@
+/*
+ * rmp2.h -- C ABI of the MI355X RMP2 evaluation-and-pullback engine (librmp2_hip.so).
+ *
+ * The reference (TomGoesGitHub/Riemannian-Motion-Policies) has no FFI: its seam is the
+ * Python protocol  RmpCore.evaluate(q, qd) -> qdd  (rmp.py:133-155).  This header is the
+ * C boundary that replaces everything below that call -- task-map differentiation
+ * (taskmap.py:13-168, kinematics.py:212-270, helper/rmp_helper.py:3-60), leaf evaluation
+ * (rmp2.py:31-226, rmp.py:226-382), the pull-back and sum (rmp.py:157-180, :142-150) and the
+ * resolve step (rmp.py:153-154) -- for a BATCH of R independent robots of one type.
+ *
+ * Rules of the boundary
+ *   - plain C, plain pointers and sizes; no C++/torch types.
+ *   - the caller owns every buffer; the engine owns its handle, its constant tables and
+ *     nothing else.  rmp2_step() allocates nothing and never synchronises the host.
+ *   - all array arguments of rmp2_step / rmp2_forward_kinematics / rmp2_differentiate are
+ *     DEVICE pointers (HBM), row-major, robot index slowest: q[R][n_dof] etc.
+ *   - every call returns 0 on success or a negative RMP2_ERR_* code; the message is
+ *     available from rmp2_last_error().
+ *   - a handle is bound to one device; calls on one handle must not race (thread-compatible).
+ *   - there is NO host/CPU execution path in this library.  If no HIP device is usable,
+ *     rmp2_create() fails with RMP2_ERR_NO_DEVICE.
+ */
+#ifndef RMP2_H
+#define RMP2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMP2_ABI_VERSION 1
+
+#define RMP2_MAX_FRAMES 32  /* frames (= URDF joints) per robot type                    */
+#define RMP2_MAX_DOF 16     /* actuated joints per robot type (kernels exist for <= 9)   */
+#define RMP2_MAX_LEAVES 48  /* leaf RMPs per set                                          */
+#define RMP2_MAX_PARAMS 12  /* scalar parameters per leaf                                 */
+
+/* ---- error codes --------------------------------------------------------------------- */
+#define RMP2_OK 0
+#define RMP2_ERR_INVALID_ARGUMENT (-1)
+#define RMP2_ERR_UNSUPPORTED (-2) /* e.g. more dof / tree branching than a kernel exists for */
+#define RMP2_ERR_NO_DEVICE (-3)
+#define RMP2_ERR_HIP (-4)         /* a HIP runtime call failed; see rmp2_last_error()      */
+#define RMP2_ERR_ABI_MISMATCH (-5)
+
+/* ---- robot table (output of the URDF "kinematic compiler") ---------------------------
+ * Replaces the tensors built by UrdfForwardKinematic._build (kinematics.py:163-209):
+ * kinematic_chains -> parent[], _q_reordering -> q_index[], T_constant, axis,
+ * is_revolute/is_prismatic/is_fixed -> joint_type[].  Frame order = reference frame order
+ * (breadth-first, helper/urdf_parsing.py:74-97). */
+#define RMP2_JOINT_FIXED 0
+#define RMP2_JOINT_REVOLUTE 1
+#define RMP2_JOINT_PRISMATIC 2
+
+typedef struct rmp2_robot {
+  int32_t n_frames;
+  int32_t n_dof;
+  int32_t parent[RMP2_MAX_FRAMES];     /* parent frame, -1 = attached to the base link      */
+  int32_t joint_type[RMP2_MAX_FRAMES]; /* RMP2_JOINT_*                                      */
+  int32_t q_index[RMP2_MAX_FRAMES];    /* index into q, -1 = evaluated at q = 0             */
+  float axis[RMP2_MAX_FRAMES][3];      /* joint axis in the joint frame                     */
+  float T_const[RMP2_MAX_FRAMES][12];  /* rows 0..2 of the 4x4 T_constant, row-major        */
+} rmp2_robot;
+
+/* ---- leaf policies -------------------------------------------------------------------
+ * kind: which (xdd_des, A) formula; each cites the reference class it reproduces,
+ * quirks included.  params[] order is the reference
+ * constructor's keyword order. */
+#define RMP2_LEAF_TARGET_ATTRACTOR 1 /* rmp2.py:31-83   params: accel_p_gain, accel_d_gain, accel_norm_eps,
+                                        metric_alpha_length_scale, min_metric_alpha, max_metric_scalar,
+                                        min_metric_scalar, proximity_metric_boost_scalar,
+                                        proximity_metric_boost_length_scale ; goal: 3 floats   */
+#define RMP2_LEAF_JOINT_VELOCITY_CAP 2 /* rmp2.py:86-112  params: max_velocity, velocity_damping_region,
+                                        damping_gain, metric_weight                          */
+#define RMP2_LEAF_JOINT_DAMPING 3    /* rmp2.py:115-137 params: accel_d_gain, metric_scalar, inertia */
+#define RMP2_LEAF_OBSTACLE_AVOIDANCE 4 /* rmp2.py:140-196 params: margin, damping_gain, damping_std_dev,
+                                        damping_robustness_eps, damping_velocity_gate_length_scale,
+                                        repulsion_gain, repulsion_std_dev, metric_modulation_radius,
+                                        metric_scalar, metric_exploder_std_dev, metric_exploder_eps */
+#define RMP2_LEAF_CSPACE_BIASING 5   /* rmp2.py:198-226 params: metric_scalar, position_gain, damping_gain,
+                                        robust_position_term_thresh, inertia ; vec_a = goal q0 */
+#define RMP2_LEAF_TARGET_POLICY 6    /* rmp.py:226-260  params: alpha, beta, c ; goal: k floats
+                                        (k = 3 on an FK position map, n_dof on the identity map) */
+#define RMP2_LEAF_JOINT_LIMIT_AVOIDANCE 7 /* rmp.py:349-382 params: gamma_p, gamma_d ;
+                                        vec_a = lower limits, vec_b = upper limits             */
+#define RMP2_LEAF_CONFIG_SPACE_BIASING 8 /* rmp.py:318-347 params: gamma_p, gamma_d, w ; vec_a = q0 */
+
+/* task map of a leaf (the chains the reference's experiments build with chain_taskmaps,
+ * taskmap.py:142-168) */
+#define RMP2_TASKMAP_IDENTITY 0    /* IdentityTaskmap                  taskmap.py:13-20        */
+#define RMP2_TASKMAP_FK_POSITION 1 /* FK(frame) -> 4x4 -> position     taskmap.py:22-31,45-54  */
+#define RMP2_TASKMAP_FK_DISTANCE 2 /* FK(frame) -> 4x4 -> distance     taskmap.py:22-31,115-138 */
+
+typedef struct rmp2_leaf {
+  int32_t kind;        /* RMP2_LEAF_*                                                     */
+  int32_t taskmap;     /* RMP2_TASKMAP_*                                                  */
+  int32_t frame;       /* frame index for FK task maps, else -1                           */
+  int32_t goal_offset; /* float offset of this leaf's goal inside one robot's goal row, -1 = none */
+  float params[RMP2_MAX_PARAMS];
+  float vec_a[RMP2_MAX_DOF];
+  float vec_b[RMP2_MAX_DOF];
+} rmp2_leaf;
+
+/* ---- resolve step ------------------------------------------------------------------ */
+#define RMP2_SOLVE_AUTO 0 /* fp64 LU with threshold pivoting; robots whose metric is (numerically)
+                             singular fall through to the PINV path.  Same result as PINV to fp64
+                             rounding whenever M is well conditioned.                         */
+#define RMP2_SOLVE_PINV 1 /* reference-faithful: fp64 Moore-Penrose pseudo-inverse by one-sided Jacobi
+                             SVD with TensorFlow's cutoff 10*n*eps*sigma_max (rmp.py:153)     */
+
+typedef struct rmp2_desc {
+  int32_t abi_version; /* must be RMP2_ABI_VERSION */
+  int32_t solve_mode;  /* RMP2_SOLVE_* */
+  int32_t n_leaves;
+  int32_t goal_floats; /* floats per robot in the goal array (sum over goal-bearing leaves) */
+  rmp2_robot robot;
+  rmp2_leaf leaves[RMP2_MAX_LEAVES];
+} rmp2_desc;
+
+/* ---- per-step obstacle input (data of the distance task maps) -----------------------
+ * The reference feeds closest-point pairs through Datamanager tf.Variables
+ * (data_management.py:8-17, taskmap.py:115-138).  Two array-backed forms:
+ *   EXPLICIT_PAIRS (reference-faithful): for every FK_DISTANCE leaf l a block of pairs
+ *     p_link[r][pair_begin[l] .. pair_begin[l+1])[3], p_obs[...] in the robot base frame.
+ *     value d = |p_link - p_obs|; derivative w.r.t. the FRAME ORIGIN only (quirk Q5).
+ *   SHARED_SPHERES: one table spheres[K][4] = (cx, cy, cz, radius) for the whole fleet;
+ *     every FK_DISTANCE leaf sees K pairs: control point = its frame origin,
+ *     d = |origin - c| - radius, direction (origin - c)/|origin - c|.
+ *   RAGGED_SPHERES: as SHARED_SPHERES but robot r only sees the spheres
+ *     csr_index[csr_offset[r] .. csr_offset[r+1]) .
+ */
+#define RMP2_OBS_NONE 0
+#define RMP2_OBS_EXPLICIT_PAIRS 1
+#define RMP2_OBS_SHARED_SPHERES 2
+#define RMP2_OBS_RAGGED_SPHERES 3
+
+typedef struct rmp2_obstacles {
+  int32_t mode;
+  int32_t n_spheres;                       /* K */
+  int32_t n_pairs;                         /* P = pairs per robot, EXPLICIT_PAIRS            */
+  int32_t pair_begin[RMP2_MAX_LEAVES + 1]; /* indexed by LEAF index; non-distance leaves: empty range */
+  const float *spheres;                    /* device [K][4]                                  */
+  const float *p_link;                     /* device [R][P][3]                               */
+  const float *p_obs;                      /* device [R][P][3]                               */
+  const int32_t *csr_offset;               /* device [R+1]                                   */
+  const int32_t *csr_index;                /* device [csr_offset[R]]                         */
+} rmp2_obstacles;
+
+/* ---- outputs ----------------------------------------------------------------------- */
+#define RMP2_STATUS_NONFINITE 1u /* qdd contains NaN/Inf (e.g. JointVelocityCap pole, quirk Q4) */
+#define RMP2_STATUS_RANK_DROP 2u /* the pseudo-inverse dropped at least one singular value  */
+#define RMP2_STATUS_PINV_PATH 4u /* AUTO mode: this robot was resolved on the PINV path      */
+
+typedef struct rmp2_outputs {
+  float *qdd;       /* device [R][n_dof]                      required                     */
+  uint32_t *status; /* device [R]                             optional (NULL)              */
+  double *M;        /* device [R][n_dof][n_dof] combined metric,   optional (NULL)         */
+  double *f;        /* device [R][n_dof]        combined force,    optional (NULL)         */
+} rmp2_outputs;
+
+typedef struct rmp2_handle rmp2_handle;
+
+/* Library/ABI identification (bindings check these before anything else). */
+int rmp2_abi_version(void);
+size_t rmp2_sizeof_desc(void);
+size_t rmp2_sizeof_obstacles(void);
+
+/* Build an engine for one robot type + one RMP set on HIP device `device`.
+ * Replaces: UrdfForwardKinematic.__init__ tables (kinematics.py:157-209) + the RmpCore
+ * registry contents (rmp.py:114-131) as a flat, immutable "program".               */
+int rmp2_create(const rmp2_desc *desc, int device, rmp2_handle **out);
+int rmp2_destroy(rmp2_handle *h);
+
+/* Last error message of `h` (or of the last failed rmp2_create when h == NULL). */
+const char *rmp2_last_error(const rmp2_handle *h);
+
+/* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
+ *   q, qd       device [R][n_dof] fp32
+ *   goal        device [R][goal_floats] (goal_stride = goal_floats) or one shared row
+ *               (goal_stride = 0); may be NULL when no leaf has a goal.
+ *   obs         obstacle data (host struct holding device pointers); NULL = RMP2_OBS_NONE
+ *   stream      hipStream_t (NULL = default stream); the call is asynchronous.          */
+int rmp2_step(rmp2_handle *h, const float *q, const float *qd, const float *goal, int32_t goal_stride,
+              const rmp2_obstacles *obs, const rmp2_outputs *out, int32_t R, void *stream);
+
+/* Closed-loop rollout of the fleet inside ONE launch (the reference's control loop
+ * experiments/franka_panda/06_cluttered_environment.py:120-131 with simulation.step tracking qdd):
+ *   repeat n_control_steps times:  qdd = control step(q, qd);
+ *                                  repeat substeps times:  qd += dt * qdd;  q += dt * qd;
+ * q and qd (device, [R][n_dof]) are advanced IN PLACE; out->qdd receives the last qdd, out->status the
+ * OR of the per-step status words.  Goals and the sphere table are constant during the rollout;
+ * RMP2_OBS_EXPLICIT_PAIRS is rejected (closest-point pairs are only valid for the state they were
+ * computed at).  Resolve semantics are those of RMP2_SOLVE_AUTO. */
+typedef struct rmp2_rollout_cfg {
+  int32_t n_control_steps;
+  int32_t substeps;
+  float dt;
+} rmp2_rollout_cfg;
+
+int rmp2_rollout(rmp2_handle *h, float *q, float *qd, const float *goal, int32_t goal_stride,
+                 const rmp2_obstacles *obs, const rmp2_rollout_cfg *cfg, const rmp2_outputs *out, int32_t R,
+                 void *stream);
+
+/* Forward kinematics of every frame: T[R][n_frames][16] row-major 4x4
+ * (UrdfForwardKinematic.forward, kinematics.py:212-247, for all frames at once).      */
+int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R, void *stream);
+
+/* Task-map differentiation of the FK map of `frame`
+ * (UrdfForwardKinematic.differentiate, kinematics.py:250-270):
+ *   x[R][16] = vec(T), xd[R][16] = J qd, J[R][16][n_dof], c[R][16] = Jdot qd.       */
+int rmp2_differentiate(rmp2_handle *h, const float *q, const float *qd, int32_t frame, float *x, float *xd,
+                       float *J, float *c, int32_t R, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMP2_H */

@@ -1,0 +1,58 @@
+"""Loader of the HIP engine library (librmp2_hip.so) -- the ONLY compute backend.
+
+There is deliberately no CPU / PyTorch fallback: if the library is missing, was built for a
+different ABI, or no HIP device is usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import descriptor as D
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("RMP2_LIB", os.path.join(_PKG, "librmp2_hip.so"))  # RMP2_LIB: diagnostic builds only
+
+_lib = None
+
+
+class Rmp2Error(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Rmp2Error(
+            f"{LIB_PATH} not found: the HIP engine is not built.  Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` at the repo root (needs hipcc). "
+            "There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    l.rmp2_abi_version.restype = C.c_int
+    l.rmp2_sizeof_desc.restype = C.c_size_t
+    l.rmp2_sizeof_obstacles.restype = C.c_size_t
+    l.rmp2_last_error.restype = C.c_char_p
+    l.rmp2_last_error.argtypes = [C.c_void_p]
+    l.rmp2_create.argtypes = [C.POINTER(D.Desc), C.c_int, C.POINTER(C.c_void_p)]
+    l.rmp2_destroy.argtypes = [C.c_void_p]
+    l.rmp2_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
+                            C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
+    l.rmp2_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
+                               C.POINTER(D.RolloutCfg), C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
+    l.rmp2_forward_kinematics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    l.rmp2_differentiate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    if l.rmp2_abi_version() != D.ABI_VERSION:
+        raise Rmp2Error(f"ABI mismatch: library {l.rmp2_abi_version()} vs bindings {D.ABI_VERSION}")
+    if l.rmp2_sizeof_desc() != C.sizeof(D.Desc) or l.rmp2_sizeof_obstacles() != C.sizeof(D.Obstacles):
+        raise Rmp2Error("struct layout mismatch between include/rmp2.h and descriptor.py")
+    _lib = l
+    return l
+
+
+def check(rc: int, handle=None):
+    if rc != 0:
+        msg = lib().rmp2_last_error(handle)
+        raise Rmp2Error(f"rmp2 error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,146 @@
+"""The BASELINE.json workload configurations as data: RMP sets (parameters copied from the
+reference's experiment scripts) and the synthetic input distributions of SURVEY section 8(d).
+
+Used by bench.py, the parity tests and the golden-fixture generator so that all three see the
+same sets and the same seeded inputs.  Nothing here computes on the hot path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import descriptor as D
+from .urdf import KinematicTable, panda_table, two_joint_table
+
+# simulation.py:137-139 (FrankaPanda) restricted to idx_controllable = [0..6, 9, 10]
+PANDA_Q_READY = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4, 0.02, 0.02], dtype=np.float64)
+PANDA_Q_LOW = np.array([-2.9671, -1.8326, -2.9671, -3.1416, -2.9671, -0.0873, -2.9671, 0.0, 0.0])
+PANDA_Q_HIGH = np.array([2.9671, 1.8326, 2.9671, 0.0, 2.9671, 3.8223, 2.9671, 0.04, 0.04])
+# simulation.py:84-86 (TwoJointRobot)
+TWO_JOINT_Q_LOW = np.array([-np.pi, -np.pi])
+TWO_JOINT_Q_HIGH = np.array([np.pi, np.pi])
+
+# experiments/franka_panda/06_cluttered_environment.py:70-75
+TARGET_ATTRACTOR_PARAMS = [0.3, 0.6, 0.075, 0.05, 0.03, 1.0, 0.5, 1.0, 0.02]
+# :78-80
+JOINT_VELOCITY_CAP_PARAMS = [0.5, 0.15, 5.0, 0.05]
+# :83-85
+JOINT_DAMPING_PARAMS = [1.0, 0.005, 0.3]
+# :88-92   (metric_scalar, position_gain, damping_gain, robust_position_term_thresh, inertia)
+CSPACE_BIASING_PARAMS = [0.005, 1.0, 2.0, 0.5, 0.0001]
+CSPACE_BIASING_GOAL = [0.0, -0.9, 0.0, -2.8, 0.0, 2.0, 0.7853981633974483, 0.02, 0.02]
+# :109-114
+OBSTACLE_AVOIDANCE_PARAMS = [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001]
+# experiments/two_joint_robot/03_jointlimit_avoiding.py:36
+JOINT_LIMIT_PARAMS = [0.3, 1.0]
+# experiments/two_joint_robot/01_target_rmp_only.py:44
+TARGET_POLICY_PARAMS = [0.1, 0.5, 0.1]
+
+# 8 of the 10 collision frames, in frame order
+CONTROL_POINT_FRAMES = ["panda_joint2", "panda_joint3", "panda_joint4", "panda_joint5", "panda_joint7",
+                        "panda_hand_joint", "panda_finger_joint1", "panda_finger_joint2"]
+TWO_JOINT_CONTROL_POINT_FRAMES = ["joint_1", "joint_2", "link_23"]
+N_SPHERES = 32
+
+
+def config1(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """TwoJoint, TargetPolicy on FK(link_23)->pos   (BASELINE config 1)."""
+    t = two_joint_table()
+    specs = [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("link_23"),
+                        TARGET_POLICY_PARAMS, goal_len=3, name="target")]
+    return t, D.build_desc(t, specs, solve)
+
+
+def config2(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """Panda: TargetAttractor + JointLimitAvoidance + JointDamping   (BASELINE config 2)."""
+    t = panda_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                   TARGET_ATTRACTOR_PARAMS, goal_len=3, name="attractor"),
+        D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, JOINT_LIMIT_PARAMS,
+                   vec_a=PANDA_Q_LOW, vec_b=PANDA_Q_HIGH, name="joint_limit_avoidance"),
+        D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, JOINT_DAMPING_PARAMS, name="joint_damping"),
+    ]
+    return t, D.build_desc(t, specs, solve)
+
+
+def config3(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """Panda cluttered environment: the experiment-06 set with ObstacleAvoidance on 8
+    control-point frames (BASELINE configs 3/4).  The same descriptor serves the shared-sphere
+    and the explicit-pair obstacle interfaces (the mode is a per-step input)."""
+    t = panda_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                   TARGET_ATTRACTOR_PARAMS, goal_len=3, name="attractor"),
+        D.LeafSpec(D.LEAF_JOINT_VELOCITY_CAP, D.TASKMAP_IDENTITY, -1, JOINT_VELOCITY_CAP_PARAMS,
+                   name="joint_velocity_cap"),
+        D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, JOINT_DAMPING_PARAMS, name="joint_damping"),
+        D.LeafSpec(D.LEAF_CSPACE_BIASING, D.TASKMAP_IDENTITY, -1, CSPACE_BIASING_PARAMS,
+                   vec_a=CSPACE_BIASING_GOAL, name="cspace_target"),
+    ]
+    for fr in CONTROL_POINT_FRAMES:
+        specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index(fr),
+                                OBSTACLE_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
+    return t, D.build_desc(t, specs, solve)
+
+
+def config5_two_joint(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """TwoJoint half of the mixed fleet: config-1 set + obstacle leaves on its 3 frames."""
+    t = two_joint_table()
+    specs = [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("link_23"),
+                        TARGET_POLICY_PARAMS, goal_len=3, name="target")]
+    for fr in TWO_JOINT_CONTROL_POINT_FRAMES:
+        specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index(fr),
+                                OBSTACLE_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
+    return t, D.build_desc(t, specs, solve)
+
+
+# ---- synthetic inputs (SURVEY 8(d) "Value distributions / seeds") -------------------------
+
+def sample_panda_states(rng: np.random.Generator, R: int) -> Dict[str, np.ndarray]:
+    q = np.empty((R, 9))
+    q[:, :7] = PANDA_Q_READY[:7] + rng.uniform(-0.5, 0.5, size=(R, 7))
+    q[:, 7:] = rng.uniform(0.0, 0.04, size=(R, 2))
+    q = np.clip(q, PANDA_Q_LOW, PANDA_Q_HIGH)
+    qd = rng.uniform(-0.1, 0.1, size=(R, 9))
+    goal = rng.uniform([0.3, -0.7, 0.3], [0.7, 0.7, 0.7], size=(R, 3))
+    return {"q": q.astype(np.float32), "qd": qd.astype(np.float32), "goal": goal.astype(np.float32)}
+
+
+def sample_two_joint_states(rng: np.random.Generator, R: int) -> Dict[str, np.ndarray]:
+    q = rng.uniform(-np.pi, np.pi, size=(R, 2))
+    qd = rng.uniform(-0.1, 0.1, size=(R, 2))
+    goal = np.stack([rng.uniform(0.1, 1.4, R), rng.uniform(-1.4, 1.4, R), np.full(R, 0.1)], axis=1)
+    return {"q": q.astype(np.float32), "qd": qd.astype(np.float32), "goal": goal.astype(np.float32)}
+
+
+def sample_spheres(rng: np.random.Generator, K: int = N_SPHERES) -> np.ndarray:
+    """simulation.py:496-498: centre cylindrical r~U(.4,.9), phi~U(0,2pi), z~U(0,1); radius U(.05,.1)."""
+    r, phi, z = rng.uniform(0.4, 0.9, K), rng.uniform(0, 2 * np.pi, K), rng.uniform(0, 1, K)
+    rad = rng.uniform(0.05, 0.1, K)
+    return np.stack([r * np.cos(phi), r * np.sin(phi), z, rad], axis=1).astype(np.float32)
+
+
+def pairs_from_spheres(origins: np.ndarray, spheres: np.ndarray):
+    """Explicit closest-point pairs equivalent to the sphere table: origins [R, C, 3] (control
+    point = frame origin), spheres [K,4] -> p_link, p_obs [R, C*K, 3] (fp32)."""
+    R, Cn, _ = origins.shape
+    K = spheres.shape[0]
+    o = origins.astype(np.float32)[:, :, None, :]
+    c = spheres[None, None, :, :3].astype(np.float32)
+    diff = o - c
+    dist = np.sqrt((diff * diff).sum(-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+    p_obs = (c + spheres[None, None, :, 3:4] * (diff / dist)).astype(np.float32)
+    p_link = np.broadcast_to(o, (R, Cn, K, 3)).astype(np.float32)
+    return p_link.reshape(R, Cn * K, 3).copy(), p_obs.reshape(R, Cn * K, 3).copy()
+
+
+def sample_ragged(rng: np.random.Generator, R: int, K: int = N_SPHERES):
+    """Config 5: per-robot obstacle count k_r ~ U{0..K} as a CSR index list into the shared table."""
+    counts = rng.integers(0, K + 1, size=R)
+    offset = np.zeros(R + 1, np.int32)
+    offset[1:] = np.cumsum(counts)
+    index = np.concatenate([rng.permutation(K)[:c] for c in counts]).astype(np.int32) if offset[-1] else \
+        np.zeros(0, np.int32)
+    return offset, index

@@ -1,0 +1,323 @@
+// rmp2_device.h -- device-side building blocks of the RMP2 control step (gfx950).
+//
+// Execution model: ONE LANE OWNS ONE ROBOT.  A wave walks the kinematic tree once
+// (depth-first schedule compiled on the host), keeps the running frame state in VGPRs,
+// the per-dof joint axes/origins and the q/qd tile in LDS (lane-private columns, bank
+// conflict free), evaluates every leaf attached to a frame while the walk passes it, and
+// accumulates the pulled-back metric in fp64 registers.  Everything that is identical for
+// all robots of the fleet (the program, leaf parameters, the shared obstacle table) is
+// wave-uniform and is fetched through the scalar cache (s_load) -- no VGPR, no LDS.
+//
+// Reference restated (file:line) -- see also include/rmp2.h:
+//   local/world transforms   kinematics.py:214-247 (T_constant @ T_variable, ordered product)
+//   x, xd, J, c of FK maps   kinematics.py:250-270, helper/rmp_helper.py:50-60 (autodiff there,
+//                            geometric Jacobian + bias-acceleration recursion here)
+//   distance task map        taskmap.py:115-138 (quirk Q5: derivative of the FRAME ORIGIN)
+//   leaves                   rmp2.py:31-226, rmp.py:226-382
+//   pull-back / sum          rmp.py:142-150,165-167
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rmp2.h"
+
+namespace rmp2 {
+
+constexpr int kWave = 64;
+constexpr int kMaxOps = RMP2_MAX_FRAMES;
+
+// ---- the compiled program (device memory, read with wave-uniform addresses) ------------
+struct DevOp {
+  int32_t frame;    // reference frame index
+  int32_t restore;  // -2: start from the base, -1: continue from the previous frame, >=0: slot
+  int32_t save;     // -1 or slot to save the state into after the visit
+  int32_t jtype;    // RMP2_JOINT_*
+  int32_t qidx;     // index into q or -1 (evaluated at 0)
+  uint32_t anc_mask;  // bit j: dof j moves this frame
+  int32_t leaf_begin, leaf_count;  // range in DevProgram::fk_leaves
+  float axis[3];
+  float Tc[12];
+  int32_t pad_;  // 96 bytes: 16-byte multiples so that the program can be staged with dwordx4 copies
+};
+
+struct DevLeaf {
+  // head: fetched with ONE 64-byte scalar load (s_load_dwordx16)
+  int32_t kind, taskmap, frame, goal_offset;
+  float P[RMP2_MAX_PARAMS];
+  float va[RMP2_MAX_DOF];
+  float vb[RMP2_MAX_DOF];
+  int32_t index;  // leaf index in the caller's descriptor (pair_begin is indexed by it)
+  int32_t pad_[3];  // 208 bytes
+};
+// the 64-byte head of a leaf / the 32-byte control block of an op, as value types: copying
+// them makes the compiler issue one wide scalar load instead of one dependent s_load per field
+struct LeafHead {
+  int32_t kind, taskmap, frame, goal_offset;
+  float P[RMP2_MAX_PARAMS];
+};
+struct OpCtl {
+  int32_t frame, restore, save, jtype, qidx;
+  uint32_t anc_mask;
+  int32_t leaf_begin, leaf_count;
+};
+static_assert(sizeof(DevOp) % 16 == 0 && sizeof(DevLeaf) % 16 == 0, "program records must be 16-byte multiples");
+
+struct DevProgram {
+  int32_t n_ops, n_dof, n_frames, n_leaves;
+  int32_t n_fk_leaves, n_id_leaves, goal_floats, solve_mode;
+  uint32_t rev_mask;  // bit j: dof j is revolute (else prismatic)
+  int32_t pad_[3];
+  DevOp ops[kMaxOps];
+  DevLeaf leaves[RMP2_MAX_LEAVES];
+  int32_t fk_leaves[RMP2_MAX_LEAVES];  // leaf ids grouped by op
+  int32_t id_leaves[RMP2_MAX_LEAVES];  // identity-task-map leaves, caller's order
+  int32_t n_leaf_ops;
+  int32_t leaf_ops[kMaxOps];  // schedule positions of the frames that carry leaves
+};
+
+struct ObsArgs {
+  int32_t mode, n_spheres, n_pairs;
+  const float* __restrict__ spheres;
+  const float* __restrict__ p_link;
+  const float* __restrict__ p_obs;
+  const int32_t* __restrict__ csr_offset;
+  const int32_t* __restrict__ csr_index;
+  const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
+};
+
+struct OutArgs {
+  float* __restrict__ qdd;
+  uint32_t* __restrict__ status;
+  double* __restrict__ M;
+  double* __restrict__ f;
+};
+
+// ---- small vector helpers ------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float a[3], const float b[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// running state of the frame being visited (world coordinates)
+struct FrameState {
+  float R[9];   // rotation, row-major
+  float p[3];   // origin
+  float w[3];   // angular velocity
+  float al[3];  // angular bias acceleration (qdd = 0)
+  float v[3];   // linear velocity of the origin
+  float a[3];   // linear bias acceleration of the origin
+};
+
+// Visit one frame: s (parent state, ignored when from_base) -> s (this frame's state).
+// Returns the joint's world axis in z.   kinematics.py:214-247 + the analytic counterpart of
+// the two jacobian_vector_product calls at kinematics.py:265,267.
+template <bool kWithVelocity>
+__device__ __forceinline__ void visit_frame(FrameState& s, const DevOp& op, float qv, float qdv, bool from_base,
+                                            float z[3]) {
+  const float ax[3] = {op.axis[0], op.axis[1], op.axis[2]};
+  float Rl[9], tl[3];
+  if (op.jtype == RMP2_JOINT_REVOLUTE) {
+    // T_variable = [Rodrigues(axis, q) | 0]; Rodrigues = cos*I + sin*[u]x + (1-cos)*u u^T
+    float sn, cs;
+    sincosf(qv, &sn, &cs);
+    const float omc = 1.0f - cs;
+    const float ut[9] = {0.f, -ax[2], ax[1], ax[2], 0.f, -ax[0], -ax[1], ax[0], 0.f};
+    float Rv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        Rv[3 * r + k] = cs * (r == k ? 1.f : 0.f) + sn * ut[3 * r + k] + omc * (ax[r] * ax[k]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        Rl[3 * r + k] = op.Tc[4 * r + 0] * Rv[k] + op.Tc[4 * r + 1] * Rv[3 + k] + op.Tc[4 * r + 2] * Rv[6 + k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tl[r] = op.Tc[4 * r + 3];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Rl[3 * r + k] = op.Tc[4 * r + k];
+      tl[r] = op.Tc[4 * r + 3];
+    }
+    if (op.jtype == RMP2_JOINT_PRISMATIC) {
+      const float tv[3] = {qv * ax[0], qv * ax[1], qv * ax[2]};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        tl[r] = op.Tc[4 * r + 0] * tv[0] + op.Tc[4 * r + 1] * tv[1] + op.Tc[4 * r + 2] * tv[2] + op.Tc[4 * r + 3];
+    }
+  }
+  float wp[3] = {0.f, 0.f, 0.f}, alp[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, ap[3] = {0.f, 0.f, 0.f};
+  float r[3];
+  if (from_base) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.R[k] = Rl[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s.p[k] = tl[k];
+      r[k] = tl[k];
+    }
+  } else {
+    float Rn[9], pn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        Rn[3 * i + k] = s.R[3 * i + 0] * Rl[k] + s.R[3 * i + 1] * Rl[3 + k] + s.R[3 * i + 2] * Rl[6 + k];
+      pn[i] = s.R[3 * i + 0] * tl[0] + s.R[3 * i + 1] * tl[1] + s.R[3 * i + 2] * tl[2] + s.p[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      r[k] = pn[k] - s.p[k];
+      s.p[k] = pn[k];
+      if (kWithVelocity) {
+        wp[k] = s.w[k];
+        alp[k] = s.al[k];
+        vp[k] = s.v[k];
+        ap[k] = s.a[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.R[k] = Rn[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) z[k] = s.R[3 * k + 0] * ax[0] + s.R[3 * k + 1] * ax[1] + s.R[3 * k + 2] * ax[2];
+  if (kWithVelocity) {
+    float t1[3], t2[3], t3[3];
+    cross3(wp, r, t1);
+    cross3(alp, r, t2);
+    cross3(wp, t1, t3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s.w[k] = wp[k];
+      s.al[k] = alp[k];
+      s.v[k] = vp[k] + t1[k];
+      s.a[k] = ap[k] + t2[k] + t3[k];
+    }
+    if (op.jtype != RMP2_JOINT_FIXED) {
+      const float zq[3] = {z[0] * qdv, z[1] * qdv, z[2] * qdv};
+      float t4[3];
+      cross3(wp, zq, t4);
+      if (op.jtype == RMP2_JOINT_REVOLUTE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s.w[k] += zq[k];
+          s.al[k] += t4[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s.v[k] += zq[k];
+          s.a[k] += 2.0f * t4[k];
+        }
+      }
+    }
+  }
+}
+
+// ---- leaves on a 3-d position task space ----------------------------------------------
+// symmetric 3x3 stored as {xx, xy, xz, yy, yz, zz}
+
+// rmp2.py:52-83
+__device__ __forceinline__ void leaf_target_attractor(const float* __restrict__ P, const float x[3], const float xd[3],
+                                                      const float g[3], float xdd[3], float A[6]) {
+  const float kp = P[0], kd = P[1], eps = P[2], ell = P[3], amin = P[4], smax = P[5], smin = P[6], sb = P[7],
+              ellb = P[8];
+  float delta[3], dhat[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) delta[i] = g[i] - x[i];
+  const float dn = sqrtf(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+  const float soft = fmaxf(dn, eps / 10.0f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dhat[i] = delta[i] / soft;
+    xdd[i] = kp * delta[i] / (dn + eps) - kd * xd[i];
+  }
+  const float sd = dn / ell;
+  const float a = (1.0f - amin) * expf(-0.5f * sd * sd) + amin;
+  const float bsd = dn / ellb;
+  const float ba = expf(-0.5f * bsd * bsd);
+  const float boost = ba * sb + (1.0f - ba) * 1.0f;
+  const float wI = a * smax, wS = (1.0f - a) * smin;
+  A[0] = boost * (wI + wS * (dhat[0] * dhat[0]));
+  A[1] = boost * (wS * (dhat[0] * dhat[1]));
+  A[2] = boost * (wS * (dhat[0] * dhat[2]));
+  A[3] = boost * (wI + wS * (dhat[1] * dhat[1]));
+  A[4] = boost * (wS * (dhat[1] * dhat[2]));
+  A[5] = boost * (wI + wS * (dhat[2] * dhat[2]));
+}
+
+// rmp.py:241-260 on a 3-d task space (quirk Q8 kept: c*log in h, (1/c)*log in soft_norm)
+__device__ __forceinline__ void leaf_target_policy3(const float* __restrict__ P, const float x[3], const float xd[3],
+                                                    const float g[3], float xdd[3], float A[6]) {
+  const float alpha = P[0], beta_d = P[1], c = P[2];
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = g[i] - x[i];
+  const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float h = vn + c * logf(1.0f + expf(-2.0f * c * vn));
+  const float inv_h = 1.0f / h;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xdd[i] = alpha * (inv_h * v[i]) - beta_d * xd[i];
+  const float beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
+  const float fn = sqrtf(xdd[0] * xdd[0] + xdd[1] * xdd[1] + xdd[2] * xdd[2]);
+  const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+  const float ze[3] = {xdd[0] / hs, xdd[1] / hs, xdd[2] / hs};
+  const float w = expf(-vn / 3.0f);
+  const float omb = 1.0f - beta;
+  A[0] = w * (beta * (ze[0] * ze[0]) + omb);
+  A[1] = w * (beta * (ze[0] * ze[1]));
+  A[2] = w * (beta * (ze[0] * ze[2]));
+  A[3] = w * (beta * (ze[1] * ze[1]) + omb);
+  A[4] = w * (beta * (ze[1] * ze[2]));
+  A[5] = w * (beta * (ze[2] * ze[2]) + omb);
+}
+
+// rmp2.py:183-196 on one (distance, distance-rate) pair
+__device__ __forceinline__ void leaf_obstacle_avoidance(const float* __restrict__ P, float x, float xd, float& accel,
+                                                        float& metric) {
+  const float margin = P[0], dgain = P[1], dstd = P[2], deps = P[3], gate_len = P[4], rgain = P[5], rstd = P[6],
+              radius = P[7], mscal = P[8], estd = P[9], eeps = P[10];
+  x = fmaxf(x - margin, 0.0f);
+  const float base = mscal / (x / estd + eeps);
+  const float gate = x * x / (radius * radius) - 2.0f * x / radius + 1.0f;
+  const float repel = rgain * expf(-(x / rstd));
+  const float sig = 1.0f / (1.0f + expf(-(xd / gate_len)));
+  const float damp = -(1.0f - sig) * dgain * xd / (x / dstd + deps);
+  accel = repel + damp;
+  metric = (x > radius) ? 0.0f : (1.0f - sig) * (base * gate);
+}
+
+// ---- pull-back of a position-type leaf into the fp64 accumulators ------------------------
+// col[j] = J[:, j] (3-vector per dof), S = leaf metric (sym 3x3), h = S (xdd - c)  [or the
+// pair sum  sum_b a_b (xdd_b - c_b) n_b  for distance leaves].
+//   f += J^T h ,  M += J^T S J      (rmp.py:165-167; fp32 products, fp64 accumulation :149-150)
+// Ms holds the upper triangle, row-major: idx(i,j) = i*N - i*(i-1)/2 + (j-i), i <= j.
+template <int N>
+__device__ __forceinline__ constexpr int sym_idx(int i, int j) {
+  return i * N - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <int N>
+__device__ __forceinline__ void pull_position(const float (&col)[N][3], uint32_t active, const float S[6],
+                                              const float h[3], double (&Ms)[N * (N + 1) / 2], double (&fv)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (!((active >> j) & 1u)) continue;  // wave-uniform: dof j does not move this frame
+    fv[j] += (double)dot3(col[j], h);
+    const float t[3] = {S[0] * col[j][0] + S[1] * col[j][1] + S[2] * col[j][2],
+                        S[1] * col[j][0] + S[3] * col[j][1] + S[4] * col[j][2],
+                        S[2] * col[j][0] + S[4] * col[j][1] + S[5] * col[j][2]};
+#pragma unroll
+    for (int i = 0; i <= j; ++i)
+      if ((active >> i) & 1u) Ms[sym_idx<N>(i, j)] += (double)dot3(col[i], t);
+  }
+}
+
+}  // namespace rmp2

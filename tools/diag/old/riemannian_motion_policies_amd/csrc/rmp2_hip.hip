@@ -41,33 +41,7 @@ struct Lds {
   static constexpr int kFloats = 3 * kWave * N + 6 * N * kWave;
 };
 
-// Jacobian columns of a point pt moving with a frame: z_j x (pt - o_j) (revolute ancestors), z_j (prismatic),
-// 0 for joints that do not move the frame.  zo = this lane's column of the LDS z/o table.
-template <int N>
-__device__ __forceinline__ void fill_cols(float (&col)[N][3], const float* zo, uint32_t anc_mask, uint32_t rev_mask,
-                                          const float pt[3]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    if ((anc_mask >> j) & 1u) {
-      const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
-      if ((rev_mask >> j) & 1u) {
-        const float d[3] = {pt[0] - zo[(j * 6 + 3) * kWave], pt[1] - zo[(j * 6 + 4) * kWave],
-                            pt[2] - zo[(j * 6 + 5) * kWave]};
-        cross3(zj, d, col[j]);
-      } else {
-        col[j][0] = zj[0];
-        col[j][1] = zj[1];
-        col[j][2] = zj[2];
-      }
-    } else {
-      col[j][0] = col[j][1] = col[j][2] = 0.f;
-    }
-  }
-}
-
-// EXT = build with the rarely used extensions (attached-point leaves, capsule primitives); the EXT = false
-// build is the hot one and carries none of their code.
-template <int N, int SLOTS, bool STRICT, bool EXT>
+template <int N, int SLOTS, bool STRICT>
 __global__ void __launch_bounds__(kWave)
 rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const float* __restrict__ qd,
                  const float* __restrict__ goal, int goal_stride, ObsArgs obs, OutArgs out, int R) {
@@ -151,22 +125,26 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
 
       // Jacobian columns of this frame's origin: z_j x (p - o_j) (revolute) or z_j (prismatic)
       float col[N][3];
-      fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if ((op.anc_mask >> j) & 1u) {
+          const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
+          if ((rev_mask >> j) & 1u) {
+            const float d[3] = {cur.p[0] - zo[(j * 6 + 3) * kWave], cur.p[1] - zo[(j * 6 + 4) * kWave],
+                                cur.p[2] - zo[(j * 6 + 5) * kWave]};
+            cross3(zj, d, col[j]);
+          } else {
+            col[j][0] = zj[0];
+            col[j][1] = zj[1];
+            col[j][2] = zj[2];
+          }
+        } else {
+          col[j][0] = col[j][1] = col[j][2] = 0.f;
+        }
+      }
 
       for (int li = 0; li < op.leaf_count; ++li) {
         const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
-        // attached-point leaves (taskmap.py:79-99 chain) pull every pair back through its own Jacobian:
-        // one trip of the block below per pair; all other leaves take exactly one trip
-        const bool point = EXT && lf.taskmap == RMP2_TASKMAP_FK_POINT;
-        int trips = 1;
-        size_t pbase = 0;
-        if (EXT && point) {
-          const int pb = obs.pair_begin[lf.index];
-          trips = obs.pair_begin[lf.index + 1] - pb;
-          pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
-        }
-#pragma nounroll
-        for (int trip = 0; trip < trips; ++trip) {
         float S[6], h[3];
         if (lf.taskmap == RMP2_TASKMAP_FK_POSITION) {
           // chain [FK(frame), 4x4 -> position]: x = p, xd = v, c = a_bias (taskmap.py:150-160)
@@ -181,33 +159,6 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
           h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
           h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
           h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
-        } else if (EXT && point) {
-          // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position] for pair `trip`:
-          //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J = Jacobian at x
-          const float* rel = obs.p_link + (pbase + trip) * 3;
-          const float* nvp = obs.p_obs + (pbase + trip) * 3;
-          const float dd = obs.dist[pbase + trip];
-          float r[3], pt[3], t1[3], t2[3], xdp[3], cp[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            r[c] = cur.R[3 * c] * rel[0] + cur.R[3 * c + 1] * rel[1] + cur.R[3 * c + 2] * rel[2];
-            pt[c] = cur.p[c] + r[c];
-          }
-          cross3(cur.w, r, t1);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) xdp[c] = cur.v[c] + t1[c];
-          cross3(cur.w, t1, t2);
-          cross3(cur.al, r, t1);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) cp[c] = cur.a[c] + t1[c] + t2[c];
-          fill_cols<N>(col, zo, op.anc_mask, rev_mask, pt);
-          const float nv[3] = {nvp[0], nvp[1], nvp[2]};
-          float xdd[3], wgt;
-          leaf_collision_avoidance(lf.P, dd, nv, xdp, xdd, wgt);
-          S[0] = S[3] = S[5] = wgt;
-          S[1] = S[2] = S[4] = 0.f;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) h[c] = wgt * (xdd[c] - cp[c]);
         } else {
           // chain [FK(frame), 4x4 -> distance] over this leaf's pairs.  Every pair pulls back
           // through the SAME 3 x n Jacobian, so the per-pair rank-1 updates collapse into
@@ -260,18 +211,10 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
                 on = b < count;
                 sidx = on ? ci[b] : 0;
               }
-              float4 sp;
-              float ctr[3];
-              if (EXT && obs.capsule) {
-                sp = reinterpret_cast<const float4*>(obs.spheres)[2 * sidx];
-                capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * sidx + 1], cur.p, ctr);
-              } else {
-                sp = reinterpret_cast<const float4*>(obs.spheres)[sidx];
-                ctr[0] = sp.x, ctr[1] = sp.y, ctr[2] = sp.z;
-              }
-              diff[0] = cur.p[0] - ctr[0];
-              diff[1] = cur.p[1] - ctr[1];
-              diff[2] = cur.p[2] - ctr[2];
+              const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[sidx];
+              diff[0] = cur.p[0] - sp.x;
+              diff[1] = cur.p[1] - sp.y;
+              diff[2] = cur.p[2] - sp.z;
               const float dc = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
               d = dc - sp.w;
 #pragma unroll
@@ -296,8 +239,6 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
           }
         }
         pull_position<N>(col, op.anc_mask, S, h, Ms, fv);
-        }  // trip
-        if (EXT && point) fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p);
       }
     }
 
@@ -575,57 +516,6 @@ rmp2_fk_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q,
   }
 }
 
-// Closest-point stage on its own: control point = frame origin of each distance leaf, nearest surface
-// point of every primitive of the shared table (simulation.py:462-484 calculate_distances; lane per robot).
-template <int SLOTS>
-__global__ void __launch_bounds__(kWave)
-rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const ObsArgs obs,
-                    float* __restrict__ p_link, float* __restrict__ p_obs, int R) {
-  const int robot = blockIdx.x * kWave + threadIdx.x;
-  if (robot >= R) return;
-  const float* my_q = q + (size_t)robot * prog->n_dof;
-  FrameState cur;
-  FrameState slot[SLOTS > 0 ? SLOTS : 1];
-  for (int k = 0; k < prog->n_ops; ++k) {
-    const DevOp& op = prog->ops[k];
-    if (SLOTS > 0 && op.restore >= 0) {
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        if (op.restore == s) cur = slot[s];
-    }
-    float z[3];
-    visit_frame<false>(cur, op, op.qidx >= 0 ? my_q[op.qidx] : 0.f, 0.f, op.restore == -2, z);
-    if (SLOTS > 0 && op.save >= 0) {
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        if (op.save == s) slot[s] = cur;
-    }
-    for (int li = 0; li < op.leaf_count; ++li) {
-      const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
-      if (lf.taskmap != RMP2_TASKMAP_FK_DISTANCE) continue;
-      const size_t base = ((size_t)robot * obs.n_pairs + obs.pair_begin[lf.index]) * 3;
-      for (int b = 0; b < obs.n_spheres; ++b) {
-        float4 sp;
-        float ctr[3];
-        if (obs.capsule) {
-          sp = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
-          capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1], cur.p, ctr);
-        } else {
-          sp = reinterpret_cast<const float4*>(obs.spheres)[b];
-          ctr[0] = sp.x, ctr[1] = sp.y, ctr[2] = sp.z;
-        }
-        const float diff[3] = {cur.p[0] - ctr[0], cur.p[1] - ctr[1], cur.p[2] - ctr[2]};
-        const float dc = sqrtf(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          p_link[base + 3 * b + c] = cur.p[c];
-          p_obs[base + 3 * b + c] = ctr[c] + sp.w * (diff[c] / dc);
-        }
-      }
-    }
-  }
-}
-
 // x = vec(T_frame), xd = J qd, J = d vec(T)/dq, c = Jdot qd   (kinematics.py:250-270)
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave)
@@ -722,7 +612,6 @@ struct rmp2_handle {
   DevProgram* d_prog_full = nullptr;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
-  bool has_point = false;  // attached-point leaves (CollisionAvoidance): lane-per-robot kernel only
   int n_id_leaves = 0;
   int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
@@ -918,7 +807,6 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
         goal_len = 3;
         break;
       case RMP2_TASKMAP_FK_DISTANCE: ok = s.kind == RMP2_LEAF_OBSTACLE_AVOIDANCE; break;
-      case RMP2_TASKMAP_FK_POINT: ok = s.kind == RMP2_LEAF_COLLISION_AVOIDANCE; break;
       default: break;
     }
     if (!ok) return err = "leaf " + std::to_string(l) + ": this (kind, taskmap) pair has no kernel", RMP2_ERR_UNSUPPORTED;
@@ -947,12 +835,8 @@ template <int N, int SLOTS, bool STRICT>
 void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                  const OutArgs& out, int R, hipStream_t s) {
   const int blocks = (R + kWave - 1) / kWave;
-  if (h->has_point || o.capsule)
-    hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT, true>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
-                       o, out, R);
-  else
-    hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT, false>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
-                       o, out, R);
+  hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs, o, out,
+                     R);
 }
 
 template <int N, bool STRICT>
@@ -972,23 +856,18 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + (o.capsule ? 8 : 4) * n_sph_lds);
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + 4 * n_sph_lds);
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
-  const bool latency = blocks <= 1024 && h->goal_floats <= 16;
-  const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
-#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP)                                                                              \
-  hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, \
-                     hdr, q, qd, goal, gs, o, out, ro, R)
-  if (latency) {
-    if (o.capsule) RMP2_QUAD_LAUNCH(1, true, true); else RMP2_QUAD_LAUNCH(1, true, false);
-  } else {
-    if (o.capsule) RMP2_QUAD_LAUNCH(2, false, true); else RMP2_QUAD_LAUNCH(2, false, false);
-  }
-#undef RMP2_QUAD_LAUNCH
+  if (blocks <= 1024 && h->goal_floats <= 16)
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 1, true>), dim3(blocks), dim3(kWave), lds_bytes + stage_bytes, s,
+                       h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);
+  else
+    hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, 2, false>), dim3(blocks), dim3(kWave), lds_bytes, s, h->d_prog,
+                       hdr, q, qd, goal, gs, o, out, ro, R);
 }
 
 template <int N>
@@ -1005,9 +884,7 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
   //    splits 4 ways); the only kernel with the fused rollout loop;
   //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
-  //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
-  const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
-                                 (h->kernel_choice == 0 && !h->has_distance && R > 16384));
+  const bool lane = !rollout && (h->kernel_choice == 1 || (h->kernel_choice == 0 && !h->has_distance && R > 16384));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
     case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
@@ -1079,8 +956,6 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();
-  for (int l = 0; l < desc->n_leaves; ++l)
-    if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_POINT) h->has_point = true;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&h->d_prog, sizeof(DevProgram));
   if (e == hipSuccess) e = hipMemcpy(h->d_prog, &P, sizeof(DevProgram), hipMemcpyHostToDevice);
@@ -1127,14 +1002,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   ObsArgs o;
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;
-  if (h->has_point) {
-    const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
-    if (rollout) return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: attached-point leaves take per-step pair data");
-    if (o.mode != RMP2_OBS_EXPLICIT_PAIRS || !obs->dist)
-      return fail(h, RMP2_ERR_INVALID_ARGUMENT,
-                  "attached-point leaves need EXPLICIT_PAIRS data: p_link = relative_position, p_obs = normal_vec, dist");
-  }
-  if (h->has_distance || h->has_point) {
+  if (h->has_distance) {
     if (o.mode == RMP2_OBS_NONE)
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "this RMP set has distance leaves: obstacles are required");
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) {
@@ -1153,8 +1021,6 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     } else if (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES) {
       if (obs->n_spheres < 0 || (obs->n_spheres > 0 && !obs->spheres))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "sphere table missing");
-      if (obs->primitive != RMP2_PRIM_SPHERE && obs->primitive != RMP2_PRIM_CAPSULE)
-        return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
       if (o.mode == RMP2_OBS_RAGGED_SPHERES && (!obs->csr_offset || (!obs->csr_index && obs->n_spheres > 0)))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
     } else {
@@ -1162,13 +1028,11 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     }
     o.n_spheres = obs->n_spheres;
     o.n_pairs = obs->n_pairs;
-    o.capsule = (o.mode != RMP2_OBS_EXPLICIT_PAIRS && obs->primitive == RMP2_PRIM_CAPSULE) ? 1 : 0;
     o.spheres = obs->spheres;
     o.p_link = obs->p_link;
     o.p_obs = obs->p_obs;
     o.csr_offset = obs->csr_offset;
     o.csr_index = obs->csr_index;
-    o.dist = obs->dist;
     o.pair_begin = h->d_pair_begin;
   }
   OutArgs oa{out->qdd, out->status, out->M, out->f};
@@ -1210,51 +1074,6 @@ int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R,
     case 0: hipLaunchKernelGGL((rmp2_fk_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
     case 1: hipLaunchKernelGGL((rmp2_fk_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
     default: hipLaunchKernelGGL((rmp2_fk_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, T, R); break;
-  }
-  HIP_TRY(h, hipGetLastError());
-  return RMP2_OK;
-}
-
-int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* table, float* p_link, float* p_obs,
-                        int32_t R, void* stream) {
-  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
-  if (!q || !table || !p_link || !p_obs || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
-  if (table->mode != RMP2_OBS_SHARED_SPHERES || table->n_spheres < 0 || (table->n_spheres > 0 && !table->spheres))
-    return fail(h, RMP2_ERR_INVALID_ARGUMENT, "closest_points needs a SHARED_SPHERES primitive table");
-  if (table->primitive != RMP2_PRIM_SPHERE && table->primitive != RMP2_PRIM_CAPSULE)
-    return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
-  if (R == 0 || !h->has_distance || table->n_spheres == 0) return RMP2_OK;
-  hipStream_t s = (hipStream_t)stream;
-  {
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
-  }
-  // pair layout of the arrays written here: the i-th distance leaf owns pairs [i*K, (i+1)*K)
-  int32_t pb[RMP2_MAX_LEAVES + 1];
-  int acc = 0;
-  for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) {
-    pb[l] = acc;
-    if (l < h->n_leaves && std::find(h->distance_leaves.begin(), h->distance_leaves.end(), l) != h->distance_leaves.end())
-      acc += table->n_spheres;
-  }
-  if (!h->pair_begin_valid || std::memcmp(h->h_pair_begin, pb, sizeof(pb)) != 0) {
-    std::memcpy(h->h_pair_begin, pb, sizeof(pb));
-    HIP_TRY(h, hipMemcpyAsync(h->d_pair_begin, h->h_pair_begin, sizeof(h->h_pair_begin), hipMemcpyHostToDevice, s));
-    h->pair_begin_valid = true;
-  }
-  ObsArgs o;
-  std::memset(&o, 0, sizeof(o));
-  o.mode = table->mode;
-  o.n_spheres = table->n_spheres;
-  o.n_pairs = acc;
-  o.capsule = table->primitive == RMP2_PRIM_CAPSULE ? 1 : 0;
-  o.spheres = table->spheres;
-  o.pair_begin = h->d_pair_begin;
-  const int blocks = (R + kWave - 1) / kWave;
-  switch (h->n_slots) {
-    case 0: hipLaunchKernelGGL((rmp2_closest_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
-    case 1: hipLaunchKernelGGL((rmp2_closest_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
-    default: hipLaunchKernelGGL((rmp2_closest_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
   }
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;

@@ -162,11 +162,10 @@ __device__ __forceinline__ void target_attractor_fast(const float* P, const floa
 constexpr int kPairsExplicit = 0, kPairsSharedLds = 1, kPairsSharedGlobal = 2, kPairsRaggedLds = 3,
               kPairsRaggedGlobal = 4;
 
-template <int MODE, bool CAP>
+template <int MODE>
 __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, const float* po, const int32_t* ci,
-                                          int count, int max_count, int sub, const float P3[3],
-                                          const float V3[3], const float A3[3], const float* P, const float* IP,
-                                          float S[6], float h[3]) {
+                                          int count, int max_count, int sub, const float P3[3], const float V3[3],
+                                          const float A3[3], const float* P, const float* IP, float S[6], float h[3]) {
   const float vv = dot3(V3, V3);
   const int trips = (max_count + kQuad - 1) / kQuad;  // wave-uniform trip count
   // the obstacle record of the NEXT trip is fetched while the current one is evaluated
@@ -184,12 +183,7 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
     } else {
       int sidx = b;
       if (MODE == kPairsRaggedLds || MODE == kPairsRaggedGlobal) sidx = (b_raw < count) ? ci[b] : 0;
-      if (CAP) {  // 8-float capsule records
-        a = reinterpret_cast<const float4*>(sph)[2 * sidx];
-        b2 = reinterpret_cast<const float4*>(sph)[2 * sidx + 1];
-      } else {
-        a = reinterpret_cast<const float4*>(sph)[sidx];
-      }
+      a = reinterpret_cast<const float4*>(sph)[sidx];
     }
   };
   float4 na, nb;
@@ -216,17 +210,7 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
 #pragma unroll
       for (int c = 0; c < 3; ++c) nh[c] = diff[c] * inv;
     } else {
-      float ctr[3] = {ca.x, ca.y, ca.z};
-      if (CAP) {  // nearest point of the capsule axis a-b to the control point (rmp2_device.h capsule_centre)
-        const float u[3] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
-        const float w[3] = {P3[0] - ca.x, P3[1] - ca.y, P3[2] - ca.z};
-        const float uu = dot3(u, u);
-        float t = uu > 0.f ? dot3(w, u) * rcp1(uu) : 0.f;
-        t = fminf(fmaxf(t, 0.f), 1.f);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ctr[c] = fmaf(t, u[c], ctr[c]);
-      }
-      const float diff[3] = {P3[0] - ctr[0], P3[1] - ctr[1], P3[2] - ctr[2]};
+      const float diff[3] = {P3[0] - ca.x, P3[1] - ca.y, P3[2] - ca.z};
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
       const float inv = rsq0(d2);
       d = d2 * inv - ca.w;
@@ -303,7 +287,7 @@ __device__ __forceinline__ int uni(int v) {
   return STAGE ? __builtin_amdgcn_readfirstlane(v) : v;
 }
 
-template <int N, int SLOTS, int MINW, bool STAGE, bool CAP>
+template <int N, int SLOTS, int MINW, bool STAGE>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
@@ -337,7 +321,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   float* const sph_lds_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops;  // 16-byte aligned
   const uint32_t rev_mask = hdr.rev_mask;
   // staged copies (STAGE) live behind the local-transform records
-  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops + (CAP ? 8 : 4) * n_sph_lds;
+  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops + 4 * n_sph_lds;
   DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
@@ -368,7 +352,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
     if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
-      const int nf = (CAP ? 8 : 4) * n_sph_lds;
+      const int nf = 4 * n_sph_lds;
       for (int i = lane; i < nf; i += kWave) sph_lds_base[i] = obs.spheres[i];
     }
     if (STAGE) {
@@ -643,18 +627,18 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const float* sph_lds = sph_lds_base;
           if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds)
-              pair_loop<kPairsSharedLds, CAP>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
-                                         A3, lh.P, IP, S, h);
+              pair_loop<kPairsSharedLds>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3,
+                                         lh.P, IP, S, h);
             else
-              pair_loop<kPairsSharedGlobal, CAP>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
-                                            P3, V3, A3, lh.P, IP, S, h);
+              pair_loop<kPairsSharedGlobal>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                            V3, A3, lh.P, IP, S, h);
           } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
             const int lidx = uni<STAGE>(lf.index);
             const int pb = obs.pair_begin[lidx];
             const int count = obs.pair_begin[lidx + 1] - pb;
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
-            pair_loop<kPairsExplicit, false>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3,
-                                      A3, lh.P, IP, S, h);
+            pair_loop<kPairsExplicit>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3, A3,
+                                      lh.P, IP, S, h);
           } else {
             const int b0 = obs.csr_offset[live ? robot : 0];
             const int count = live ? obs.csr_offset[robot + 1] - b0 : 0;
@@ -662,11 +646,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #pragma unroll
             for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
             if (spheres_in_lds)
-              pair_loop<kPairsRaggedLds, CAP>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3,
-                                         A3, lh.P, IP, S, h);
+              pair_loop<kPairsRaggedLds>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3, A3,
+                                         lh.P, IP, S, h);
             else
-              pair_loop<kPairsRaggedGlobal, CAP>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
-                                            P3, V3, A3, lh.P, IP, S, h);
+              pair_loop<kPairsRaggedGlobal>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3,
+                                            V3, A3, lh.P, IP, S, h);
           }
 #pragma unroll
           for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);

@@ -1,0 +1,217 @@
+"""Engine: one robot type + one RMP set on one MI355X, driven through the C ABI.
+
+PyTorch is used for device memory, streams and (in fleet.py) torch.distributed only; all
+arithmetic happens inside librmp2_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+from . import descriptor as D
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.ascontiguousarray(t, dtype=np.float32))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    def __init__(self, desc: D.Desc, device: int | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise _native.Rmp2Error("no HIP device visible; the RMP2 engine has no CPU fallback")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.desc = desc
+        self.n_dof = desc.robot.n_dof
+        self.n_frames = desc.robot.n_frames
+        self._h = C.c_void_p()
+        self._lib = _native.lib()
+        _native.check(self._lib.rmp2_create(C.byref(desc), self.device.index or 0, C.byref(self._h)))
+        self._dist_leaves = D.distance_leaf_indices(desc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rmp2_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------
+    def obstacles(self, *, spheres=None, p_link=None, p_obs=None, pair_counts: Optional[Sequence[int]] = None,
+                  csr_offset=None, csr_index=None):
+        """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result)."""
+        o = D.Obstacles()
+        keep = []
+        if p_link is not None:
+            p_link, p_obs = _f32(p_link, self.device), _f32(p_obs, self.device)
+            if p_link.shape != p_obs.shape or p_link.dim() != 3 or p_link.shape[2] != 3:
+                raise ValueError("p_link / p_obs must both be [R, P, 3]")
+            o.mode, o.n_pairs = D.OBS_EXPLICIT_PAIRS, p_link.shape[1]
+            dl = self._dist_leaves
+            if pair_counts is None:
+                if not dl or o.n_pairs % len(dl):
+                    raise ValueError("pair_counts required: pairs do not split evenly over the distance leaves")
+                pair_counts = [o.n_pairs // len(dl)] * len(dl)
+            if len(pair_counts) != len(dl) or sum(pair_counts) != o.n_pairs:
+                raise ValueError("pair_counts must have one entry per distance leaf and sum to P")
+            acc, k = 0, 0
+            for i in range(self.desc.n_leaves + 1):
+                o.pair_begin[i] = acc
+                if i < self.desc.n_leaves and i in dl:
+                    acc += int(pair_counts[k])
+                    k += 1
+            o.p_link, o.p_obs = p_link.data_ptr(), p_obs.data_ptr()
+            keep += [p_link, p_obs]
+        elif spheres is not None:
+            spheres = _f32(spheres, self.device)
+            if spheres.dim() != 2 or spheres.shape[1] != 4:
+                raise ValueError("spheres must be [K, 4] = (cx, cy, cz, radius)")
+            o.n_spheres, o.spheres = spheres.shape[0], spheres.data_ptr()
+            keep.append(spheres)
+            if csr_offset is not None:
+                csr_offset = csr_offset.to(device=self.device, dtype=torch.int32).contiguous()
+                csr_index = csr_index.to(device=self.device, dtype=torch.int32).contiguous()
+                o.mode, o.csr_offset, o.csr_index = D.OBS_RAGGED_SPHERES, csr_offset.data_ptr(), csr_index.data_ptr()
+                keep += [csr_offset, csr_index]
+            else:
+                o.mode = D.OBS_SHARED_SPHERES
+        else:
+            o.mode = D.OBS_NONE
+        o._keep = keep
+        return o
+
+    def step(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
+             out: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+             M: Optional[torch.Tensor] = None, f: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """One control step for the R robots in q/qd ([R, n_dof] fp32 device tensors).
+        Asynchronous on `stream` (default: torch's current stream)."""
+        q, qd = _f32(q, self.device), _f32(qd, self.device)
+        if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
+            raise ValueError(f"q and qd must be [R, {self.n_dof}], got {tuple(q.shape)} / {tuple(qd.shape)}")
+        R = q.shape[0]
+        goal_ptr, goal_stride = None, 0
+        if self.desc.goal_floats:
+            if goal is None:
+                raise ValueError("this RMP set has goal-bearing leaves: pass goal")
+            goal = _f32(goal, self.device)
+            if goal.dim() == 1:
+                if goal.shape[0] != self.desc.goal_floats:
+                    raise ValueError(f"goal must have {self.desc.goal_floats} floats")
+            elif tuple(goal.shape) == (R, self.desc.goal_floats):
+                goal_stride = self.desc.goal_floats
+            else:
+                raise ValueError(f"goal must be [{self.desc.goal_floats}] or [R, {self.desc.goal_floats}]")
+            goal_ptr = goal.data_ptr()
+        if self._dist_leaves and (obstacles is None or obstacles.mode == D.OBS_NONE):
+            raise ValueError("this RMP set has distance leaves: pass obstacles=engine.obstacles(...)")
+        if out is None:
+            out = torch.empty((R, self.n_dof), dtype=torch.float32, device=self.device)
+        elif out.shape != q.shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 [R, n_dof] tensor")
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        if status is not None:
+            assert status.dtype in (torch.int32, torch.uint32) and status.numel() == R
+            o.status = status.data_ptr()
+        if M is not None:
+            assert M.dtype == torch.float64 and M.numel() == R * self.n_dof * self.n_dof
+            o.M = M.data_ptr()
+        if f is not None:
+            assert f.dtype == torch.float64 and f.numel() == R * self.n_dof
+            o.f = f.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        obs = obstacles if obstacles is not None else None
+        rc = self._lib.rmp2_step(self._h, q.data_ptr(), qd.data_ptr(), goal_ptr, goal_stride,
+                                 C.byref(obs) if obs is not None else None, C.byref(o), R, s)
+        _native.check(rc, self._h)
+        return out
+
+    def bind(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
+             out: Optional[torch.Tensor] = None, stream=None):
+        """Pre-validate and pre-marshal one step on FIXED device buffers (the usual control loop:
+        the simulator writes q/qd in place, the engine writes qdd in place).  Returns
+        (launch, out): `launch()` is a bare C-ABI call (~2 us of host time)."""
+        out = self.step(q, qd, goal, obstacles=obstacles, out=out, stream=stream)  # validates + warms up
+        q, qd = _f32(q, self.device), _f32(qd, self.device)
+        R = q.shape[0]
+        goal_ptr, goal_stride = None, 0
+        keep = [q, qd, out, obstacles]
+        if self.desc.goal_floats:
+            goal = _f32(goal, self.device)
+            goal_stride = 0 if goal.dim() == 1 else self.desc.goal_floats
+            goal_ptr = goal.data_ptr()
+            keep.append(goal)
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        obs_ref = C.byref(obstacles) if obstacles is not None else None
+        out_ref = C.byref(o)
+        fn, h, qp, qdp = self._lib.rmp2_step, self._h, q.data_ptr(), qd.data_ptr()
+        keep.append(o)
+
+        def launch(_keep=keep):
+            rc = fn(h, qp, qdp, goal_ptr, goal_stride, obs_ref, out_ref, R, s)
+            if rc:
+                _native.check(rc, h)
+        return launch, out
+
+    def rollout(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
+                n_control_steps: int = 1, substeps: int = 10, dt: float = 0.01, out: Optional[torch.Tensor] = None,
+                status: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """Closed-loop rollout in ONE launch: `n_control_steps` x (control step, then `substeps` semi-implicit
+        Euler ticks of `dt` with qdd held).  q and qd (contiguous fp32 device tensors) are advanced IN PLACE;
+        returns the last qdd."""
+        for t in (q, qd):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("rollout needs contiguous fp32 CUDA tensors (they are updated in place)")
+        if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
+            raise ValueError(f"q and qd must be [R, {self.n_dof}]")
+        R = q.shape[0]
+        goal_ptr, goal_stride = None, 0
+        if self.desc.goal_floats:
+            if goal is None:
+                raise ValueError("this RMP set has goal-bearing leaves: pass goal")
+            goal = _f32(goal, self.device)
+            goal_stride = 0 if goal.dim() == 1 else self.desc.goal_floats
+            goal_ptr = goal.data_ptr()
+        if self._dist_leaves and (obstacles is None or obstacles.mode == D.OBS_NONE):
+            raise ValueError("this RMP set has distance leaves: pass obstacles=engine.obstacles(...)")
+        if out is None:
+            out = torch.empty((R, self.n_dof), dtype=torch.float32, device=self.device)
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        if status is not None:
+            o.status = status.data_ptr()
+        cfg = D.RolloutCfg(int(n_control_steps), int(substeps), float(dt))
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.rmp2_rollout(self._h, q.data_ptr(), qd.data_ptr(), goal_ptr, goal_stride,
+                                    C.byref(obstacles) if obstacles is not None else None, C.byref(cfg), C.byref(o), R, s)
+        _native.check(rc, self._h)
+        return out
+
+    def forward_kinematics(self, q: torch.Tensor) -> torch.Tensor:
+        q = _f32(q, self.device)
+        R = q.shape[0]
+        T = torch.empty((R, self.n_frames, 4, 4), dtype=torch.float32, device=self.device)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(self._lib.rmp2_forward_kinematics(self._h, q.data_ptr(), T.data_ptr(), R, s), self._h)
+        return T
+
+    def differentiate(self, q: torch.Tensor, qd: torch.Tensor, frame: int):
+        q, qd = _f32(q, self.device), _f32(qd, self.device)
+        R, n = q.shape
+        x, xd, c = (torch.empty((R, 16), dtype=torch.float32, device=self.device) for _ in range(3))
+        J = torch.empty((R, 16, n), dtype=torch.float32, device=self.device)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(self._lib.rmp2_differentiate(self._h, q.data_ptr(), qd.data_ptr(), int(frame), x.data_ptr(),
+                                                   xd.data_ptr(), J.data_ptr(), c.data_ptr(), R, s), self._h)
+        return x, xd, J, c

@@ -1,0 +1,170 @@
+"""Drop-in class surface on the GPU: scripts written against the reference's modules
+(`from rmp import RmpCore`, ...) run through compat/ and produce the oracle's numbers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ATOL = 1e-5
+
+
+def _import_compat():
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    import data_management
+    import kinematics
+    import rmp
+    import rmp2
+    import taskmap
+    return rmp, rmp2, taskmap, kinematics, data_management
+
+
+def test_experiment06_style_script(golden_dir, hip_lib):
+    """experiments/franka_panda/06_cluttered_environment.py:55-131 written against the compat modules,
+    fed with the golden config-3 closest-point pairs through the Datamanager holders."""
+    rmp, rmp2, taskmap, kinematics, data_management = _import_compat()
+    from riemannian_motion_policies_amd import configs as Cf, urdf
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    fkine = kinematics.UrdfForwardKinematic(urdf_filepath=urdf.PANDA_URDF, order=urdf.PANDA_ORDER)
+    data_manager = data_management.Datamanager(fkine)
+    core = rmp.RmpCore()
+    ee = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fkine, frame='panda_grasptarget_hand'),
+                                 taskmap.TaskmapFrom4x4ToPosition()])
+    target_rmp = rmp2.TargetAttractor(goal=[0.2, -0.2, 0.5], accel_p_gain=0.3, accel_d_gain=0.6, accel_norm_eps=0.075,
+                                      metric_alpha_length_scale=0.05, min_metric_alpha=0.03, max_metric_scalar=1,
+                                      min_metric_scalar=0.5, proximity_metric_boost_scalar=1.,
+                                      proximity_metric_boost_length_scale=0.02, taskmap=ee, name='attractor')
+    core.add_rmp(target_rmp)
+    core.add_rmp(rmp2.JointVelocityCap(max_velocity=0.5, velocity_damping_region=0.15, damping_gain=5.0, metric_weight=0.05))
+    core.add_rmp(rmp2.JointDamping(accel_d_gain=1, metric_scalar=0.005, inertia=0.3))
+    core.add_rmp(rmp2.CSpaceBiasing(goal=Cf.CSPACE_BIASING_GOAL, metric_scalar=0.005, position_gain=1, damping_gain=2,
+                                    robust_position_term_thresh=0.5, inertia=0.0001))
+    for frame in Cf.CONTROL_POINT_FRAMES:
+        tm = taskmap.chain_taskmaps([
+            taskmap.TaskmapByForwardKinematic(fkine, frame),
+            taskmap.TaskmapJointFrame4x4ToDistance(
+                pos_on_link_in_base_frame=data_manager[frame]['pos_on_link_in_base_frame'],
+                pos_on_obstacle_in_base_frame=data_manager[frame]['pos_on_obstacle_in_base_frame'])])
+        core.add_rmp(rmp2.ObstacleAvoidance(margin=0., damping_gain=50, damping_std_dev=0.04, damping_robustness_eps=0.01,
+                                            damping_velocity_gate_length_scale=0.01, repulsion_gain=800,
+                                            repulsion_std_dev=0.01, metric_modulation_radius=0.5, metric_scalar=1,
+                                            metric_exploder_std_dev=0.02, metric_exploder_eps=0.001, taskmap=tm,
+                                            name=f'collision_avoidance_for_{frame}'))
+    pl, po = Cf.pairs_from_spheres(g["origins"], g["spheres"])
+    K = len(g["spheres"])
+    for r in range(4):  # one robot per call, exactly like the reference's control loop
+        distance_data = [(fr, pl[r, c * K + b], po[r, c * K + b], np.zeros(3), 0.0, "")
+                         for c, fr in enumerate(Cf.CONTROL_POINT_FRAMES) for b in range(K)]
+        data_manager.update(g["q"][r], distance_data)
+        target_rmp.goal = g["goal"][r]                 # goals are mutable attributes (01_target_rmp_only.py:61-63)
+        qdd = core.evaluate(g["q"][r], g["qd"][r]).numpy()
+        assert qdd.shape == (9,)
+        assert np.abs(qdd - g["qdd"][r]).max() <= ATOL * max(1.0, np.abs(g["qdd"][r]).max())
+    # FK entry used by the scripts' termination test (06_cluttered_environment.py:125-126)
+    x = fkine.forward(g["q"][:1], 'panda_grasptarget_hand')[0, :3, 3]
+    import oracle as O
+    _, d3 = Cf.config3()
+    assert np.abs(x - O.forward_kinematics(d3, g["q"][:1])[0, 11, :3, 3]).max() < 1e-6
+    xx, xd, J, c = ee.differentiate(g["q"][:1], g["qd"][:1])
+    assert xx.shape == (1, 3) and J.shape == (1, 3, 9) and np.abs(xx[0] - x).max() < 1e-6
+
+
+def test_two_joint_script_and_fleet_evaluate(golden_dir, hip_lib):
+    """experiments/two_joint_robot/01_target_rmp_only.py:31-53 + 03_jointlimit_avoiding.py:36 (identity-only set),
+    and the additive fleet form q[R, n]."""
+    rmp, rmp2, taskmap, kinematics, data_management = _import_compat()
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf
+    g = np.load(os.path.join(golden_dir, "config1.npz"))
+    fkine = kinematics.UrdfForwardKinematic(urdf.TWO_JOINT_URDF, urdf.TWO_JOINT_ORDER)
+    core = rmp.RmpCore()
+    ee = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fkine, frame='link_23'), taskmap.TaskmapFrom4x4ToPosition()])
+    target = rmp.TargetPolicy(alpha=0.1, beta=0.5, c=0.1, goal=g["goal"], name='target', taskmap=ee)  # per-robot goals
+    core.add_rmp(target)
+    qdd = core.evaluate(g["q"], g["qd"])
+    err = np.abs(qdd.numpy() - g["qdd"]).max(axis=1)
+    assert (err <= ATOL * np.maximum(1.0, np.abs(g["qdd"]).max(axis=1))).all()
+    # identity-only set: no kinematics object at all
+    core2 = rmp.RmpCore()
+    core2.add_rmp(rmp.JointLimitAvoidance(Cf.TWO_JOINT_Q_LOW, Cf.TWO_JOINT_Q_HIGH, gamma_p=0.3, gamma_d=1))
+    q = np.array([[3.0, -2.9], [0.1, 3.1]], np.float32)
+    qd = np.array([[0.3, -0.2], [0.0, 0.4]], np.float32)
+    got = core2.evaluate(q, qd).numpy()
+    from riemannian_motion_policies_amd.rmp import _null_table
+    desc = D.build_desc(_null_table(2), [D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, [0.3, 1.0],
+                                                    vec_a=Cf.TWO_JOINT_Q_LOW, vec_b=Cf.TWO_JOINT_Q_HIGH)])
+    want = O.step(desc, q, qd)["qdd64"]
+    assert np.abs(got - want).max() <= ATOL * max(1.0, np.abs(want).max())
+
+
+def test_closed_loop_goal_reaching(hip_lib):
+    """Closed-loop property (06_cluttered_environment.py:120-131): integrating qdd with the reference's
+    10 Hz control / 100 Hz plant brings the grasp target within 2 cm of the goal for a fleet of robots."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2()
+    eng = Engine(desc, 0)
+    R = 256
+    rng = np.random.default_rng(4)
+    q = torch.from_numpy(np.tile(Cf.PANDA_Q_READY.astype(np.float32), (R, 1))).cuda()
+    qd = torch.zeros_like(q)
+    goal = torch.from_numpy(rng.uniform([0.35, -0.3, 0.3], [0.6, 0.3, 0.6], (R, 3)).astype(np.float32)).cuda()
+    dt = 0.01
+    qdd = torch.zeros_like(q)
+    for step in range(6000):
+        if step % 10 == 0:
+            qdd = eng.step(q, qd, goal)
+        qd = qd + dt * qdd
+        q = q + dt * qd
+    x = eng.forward_kinematics(q)[:, 11, :3, 3]
+    dist = (x - goal).norm(dim=1)
+    assert torch.isfinite(q).all()
+    assert (dist < 0.02).float().mean() > 0.95, f"only {(dist < 0.02).float().mean():.2f} reached the goal (median {dist.median():.3f})"
+
+
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_fused_rollout_matches_step_loop(hip_lib, workload):
+    """rmp2_rollout (K control steps + plant ticks inside one launch) against the same loop
+    driven from the host with rmp2_step; same arithmetic (fma plant), so agreement is ~1e-6."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2() if workload == "config2" else Cf.config3()
+    eng = Engine(desc, 0)
+    R, sub, dt = 333, 10, 0.01
+    rng = np.random.default_rng(9)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += 1.5  # spheres above the workspace: mild repulsion, no contact
+    obs = eng.obstacles(spheres=torch.from_numpy(sph)) if workload == "config3" else None
+    goal = torch.from_numpy(s["goal"]).cuda()
+    q0, qd0 = torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda()
+    for K in (3, 40):
+        q, qd = q0.clone(), qd0.clone()           # host-driven reference loop
+        for _ in range(K):
+            qdd = eng.step(q, qd, goal, obstacles=obs)
+            for _ in range(sub):
+                qd = qd + dt * qdd
+                q = q + dt * qd
+        qf, qdf = q0.clone(), qd0.clone()           # fused
+        st = torch.zeros(R, dtype=torch.int32, device="cuda")
+        last = eng.rollout(qf, qdf, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt, status=st)
+        torch.cuda.synchronize()
+        assert last.shape == (R, 9)
+        ok = torch.isfinite(qf).all(dim=1) & torch.isfinite(q).all(dim=1)
+        err = (qf - q).abs().max(dim=1).values
+        if K == 3:
+            assert ok.all() and not (st & 1).any()
+            assert err.max().item() < 1e-5 and (qdf - qd).abs().max().item() < 1e-4
+        else:
+            # Long horizon.  (i) For a few robots (fingers sitting in the joint-limit band) the closed loop is
+            # exponentially sensitive -- 1e-7 of rounding difference grows ~100x per 0.2 s in BOTH
+            # implementations; (ii) the experiment-06 set contains JointVelocityCap, whose metric has a pole at
+            # |qd| = 0.2 and is negative below it (quirk Q4): some robots blow up to Inf in both implementations.
+            # Agreement is therefore asserted for the bulk of the fleet.
+            assert ok.float().mean().item() > 0.8
+            assert err[ok].median().item() < 1e-5 and (err[ok] < 1e-3).float().mean().item() > 0.9
+            assert (qf[ok] - q0[ok]).abs().max().item() > 1e-2  # the fleet actually moved

@@ -1,0 +1,87 @@
+"""Generic robots: random kinematic trees (revolute / prismatic / fixed joints, arbitrary axes and
+origins, up to two simultaneously open branch points) with random RMP sets, HIP vs the CPU oracle.
+Exercises everything the two reference robots do not: non-z axes, multi-axis rpy (quirk Q7 order),
+save/restore slots, unactuated movable joints, leaves on several frames."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def _write_urdf(path, rng, n_links, branch_prob):
+    names, parents = ["base"], {}
+    joints = []
+    for i in range(1, n_links + 1):
+        # parent: mostly the previous link (chain), sometimes an earlier one (branch)
+        p = i - 1 if (i == 1 or rng.random() > branch_prob) else int(rng.integers(max(0, i - 4), i))
+        jt = rng.choice(["revolute", "prismatic", "fixed"], p=[0.6, 0.2, 0.2])
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        if rng.random() < 0.4:
+            axis = np.eye(3)[rng.integers(3)] * rng.choice([-1, 1])
+        rpy = rng.uniform(-1.5, 1.5, 3) * (rng.random(3) < 0.5)
+        xyz = rng.uniform(-0.3, 0.3, 3)
+        joints.append((f"j{i}", jt, f"l{p}" if p else "base", f"l{i}", rpy, xyz, axis))
+    with open(path, "w") as f:
+        f.write('<robot name="rnd">\n<link name="base"/>\n')
+        for i in range(1, n_links + 1):
+            f.write(f'<link name="l{i}"><collision><geometry/></collision></link>\n')
+        for name, jt, par, ch, rpy, xyz, axis in joints:
+            f.write(f'<joint name="{name}" type="{jt}"><parent link="{par}"/><child link="{ch}"/>'
+                    f'<origin rpy="{rpy[0]} {rpy[1]} {rpy[2]}" xyz="{xyz[0]} {xyz[1]} {xyz[2]}"/>'
+                    + (f'<axis xyz="{axis[0]} {axis[1]} {axis[2]}"/>' if jt != "fixed" else "") + '</joint>\n')
+        f.write('</robot>\n')
+    return [j[0] for j in joints if j[1] != "fixed"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_tree_robot(tmp_path, seed, hip_lib):
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import descriptor as D, urdf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(1000 + seed)
+    path = str(tmp_path / "rnd.urdf")
+    for _ in range(50):  # re-draw until the tree fits the engine's limits (<= 9 dof, <= 2 slots)
+        movable = _write_urdf(path, rng, int(rng.integers(3, 13)), branch_prob=0.25)
+        order = [m for m in movable if rng.random() < 0.9][:9]      # some movable joints stay unactuated (q = 0)
+        if not order:
+            continue
+        t = urdf.compile_urdf(path, order)
+        if t.depth_first_schedule()[3] <= 2:
+            break
+    n, F = t.n_dof, t.n_frames
+    frames = rng.choice(F, size=min(F, 3), replace=False)
+    specs = [D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, int(frames[0]),
+                        [0.3, 0.6, 0.075, 0.05, 0.03, 1.0, 0.5, 1.0, 0.02], goal_len=3),
+             D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, [1.0, 0.005, 0.3]),
+             D.LeafSpec(D.LEAF_CSPACE_BIASING, D.TASKMAP_IDENTITY, -1, [0.005, 1.0, 2.0, 0.5, 0.0001],
+                        vec_a=rng.uniform(-0.5, 0.5, n)),
+             D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, int(frames[-1]), [0.1, 0.5, 0.1], goal_len=3)]
+    for fr in frames:
+        specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, int(fr),
+                                [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001]))
+    R = 300
+    q = rng.uniform(-1.0, 1.0, (R, n)).astype(np.float32)
+    qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+    goal = rng.uniform(-0.5, 0.5, (R, 6)).astype(np.float32)
+    sph = np.concatenate([rng.uniform(-1, 1, (5, 3)) + [0, 0, 3.0], rng.uniform(0.05, 0.1, (5, 1))], axis=1).astype(np.float32)
+    for solve in ("auto", "pinv"):
+        desc = D.build_desc(t, specs, solve)
+        eng = Engine(desc, 0)
+        Tg = eng.forward_kinematics(torch.from_numpy(q)).cpu().numpy()
+        assert np.abs(Tg - O.forward_kinematics(desc, q)).max() < 2e-6
+        fr = int(frames[0])
+        got = [x.cpu().numpy() for x in eng.differentiate(torch.from_numpy(q[:32]), torch.from_numpy(qd[:32]), fr)]
+        want = O.differentiate(desc, q[:32], qd[:32], fr)
+        for a, b, nm in zip(got, want, "x xd J c".split()):
+            assert np.abs(a - b).max() < 5e-6, (nm, np.abs(a - b).max())
+        out = eng.step(torch.from_numpy(q), torch.from_numpy(qd), torch.from_numpy(goal),
+                       obstacles=eng.obstacles(spheres=torch.from_numpy(sph)))
+        ref = O.step(desc, q, qd, goal, spheres=sph)
+        err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
+        tol = ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
+        assert (err <= tol).all(), f"seed {seed} {solve}: worst {err.max():.2e}, slots {t.depth_first_schedule()[3]}, n={n}, F={F}"

@@ -1,0 +1,34 @@
+"""Diagnostic: per-phase shader-clock stamps of the quad kernel (build with -DRMP2_STAMPS into
+tools/diag/librmp2_stamps.so, run with RMP2_LIB pointing at it).  Prints median cycles per phase."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RMP2_LIB", os.path.join(ROOT, "tools", "diag", "librmp2_stamps.so"))
+from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+from riemannian_motion_policies_amd.engine import Engine
+from riemannian_motion_policies_amd.urdf import panda_table
+from riemannian_motion_policies_amd.rmp import _null_table
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+t = panda_table()
+damp = D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, Cf.JOINT_DAMPING_PARAMS)
+sets = {"D no-frames damping": D.build_desc(_null_table(9), [damp]), "C walk damping": D.build_desc(t, [damp]),
+        "config2": Cf.config2()[1], "config3": Cf.config3()[1]}
+s = Cf.sample_panda_states(np.random.default_rng(1), R)
+q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng(7))).cuda()
+names = ["prologue", "phase1+walk", "fk leaves", "identity leaves", "LU", "store"]
+for name, desc in sets.items():
+    eng = Engine(desc, 0)
+    obs = eng.obstacles(spheres=sph) if name == "config3" else None
+    g = goal if desc.goal_floats else None
+    f = torch.zeros((R, 9), dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        eng.step(q, qd, g, obstacles=obs, f=f)
+    torch.cuda.synchronize()
+    st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + 15) // 16) * 8].reshape(-1, 8).astype(np.int64)
+    d = np.diff(st[:, :7], axis=1)
+    med = np.median(d, axis=0)
+    tot = np.median(st[:, 6] - st[:, 0])
+    print(f"R={R} {name:22s} total {tot:8.0f} cyc | " + " ".join(f"{n}={m:.0f}" for n, m in zip(names, med)))
