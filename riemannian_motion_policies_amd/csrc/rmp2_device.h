@@ -73,6 +73,14 @@ struct DevProgram {
   int32_t id_leaves[RMP2_MAX_LEAVES];  // identity-task-map leaves, caller's order
   int32_t n_leaf_ops;
   int32_t leaf_ops[kMaxOps];  // schedule positions of the frames that carry leaves
+  // tables of the 16-lanes-per-robot kernel (rmp2_hex.h): the tree as parent pointers instead of a walk order
+  struct Hex {
+    int32_t n_levels;                 // pointer-jumping rounds: smallest L with 2^L >= deepest chain
+    int32_t pad_[3];
+    int32_t jump[5][kMaxOps];         // jump[l][k]: the op 2^l levels above op k, -1 = above the base
+    int32_t dof_op[RMP2_MAX_DOF];     // op whose joint is driven by dof j, -1 = none in this program
+    uint32_t dof_anc[RMP2_MAX_DOF];   // dofs strictly above dof j's joint (they move its origin)
+  } hex;
 };
 
 struct ObsArgs {

@@ -1,0 +1,726 @@
+// rmp2_hex.h -- the latency build of the control step: SIXTEEN LANES PER ROBOT, four robots per wave.
+//
+// Why: at the headline fleet size (4 096 robots) the quad kernel (rmp2_quad.h) puts 256 waves on a chip with
+// 1 024 SIMDs -- three SIMDs in four idle -- and each wave runs one long dependent instruction stream.  With 16
+// lanes per robot the same fleet is 1 024 waves, one per SIMD, and the per-robot work is re-cut so that its
+// critical path shrinks instead of merely being shared:
+//   * kinematics is no longer a serial walk.  All frames build their local transform at once (one frame per
+//     lane), world transforms come from ceil(log2(depth)) rounds of POINTER JUMPING over the parent links
+//     (T[k] <- T[anc_{2^l}(k)] T[k]), and velocities / bias accelerations are closed-form sums over the
+//     ancestor joints evaluated by one lane per joint / per leaf frame:
+//         v_k = sum_m qd_m c_m(p_k),          c_m(p) = z_m x (p - o_m)   (revolute),  z_m (prismatic)
+//         a_k = sum_m qd_m d/dt c_m(p_k)  =  sum_m qd_m [ zd_m x (p_k - o_m) + z_m x (v_k - v_om) ]   (rev.),  zd_m (pris.)
+//     with zd_m = w_m x z_m (w_m: angular velocity above joint m) and v_om the velocity of joint m's origin --
+//     the same J qd and Jdot qd the reference gets from two jacobian_vector_product calls
+//     (kinematics.py:265,267), without the chain dependence of a recursion;
+//   * lane i owns ROW i of the n x n metric: the pull-back, the identity-map leaves and the fp64 resolve touch one
+//     row per lane (the quad kernel: three); the resolve is Gauss-Jordan (no back substitution), one pivot-row
+//     broadcast through LDS per step;
+//   * a distance leaf's pairs are split 16 ways.
+// gfx950's DPP has no row_share / row_xmask: sums over the 16 lanes use quad xor + row_half_mirror + row_mirror
+// (4 full-rate steps); broadcasts go through LDS (all lanes of a robot sit in the same wave, LDS executes a wave's
+// accesses in order).
+//
+// Numerics as in rmp2_quad.h: fp32 kinematics / leaves / pull-back products, fp64 accumulation and resolve,
+// certification + careful fall-through (pivoted LU, then the pseudo-inverse) for (near-)singular robots.
+#pragma once
+#include "rmp2_quad.h"
+
+namespace rmp2 {
+
+constexpr int kHex = 16;
+constexpr int kHexRobots = kWave / kHex;  // 4
+constexpr int kRowMirror = 0x140, kRowHalfMirror = 0x141;
+
+__device__ __forceinline__ float hex_sum(float v) {
+  v += dpp<kXor1>(v);
+  v += dpp<kXor2>(v);
+  v += dpp<kRowHalfMirror>(v);
+  v += dpp<kRowMirror>(v);
+  return v;
+}
+__device__ __forceinline__ double hex_maxd(double v) {
+  v = fmax(v, dppd<kXor1>(v));
+  v = fmax(v, dppd<kXor2>(v));
+  v = fmax(v, dppd<kRowHalfMirror>(v));
+  v = fmax(v, dppd<kRowMirror>(v));
+  return v;
+}
+__device__ __forceinline__ bool hex_any(bool f, int g) {
+  return ((__ballot(f) >> (kHex * g)) & 0xffffull) != 0ull;
+}
+// LDS exchange point between lanes of one robot.  The block IS one wave and the LDS unit executes a wave's
+// accesses in program order, so a value written by one lane is visible to a later read of any other lane without a
+// hardware barrier or a wait: all that is needed is that the COMPILER keeps the accesses in program order.
+__device__ __forceinline__ void hex_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N>
+struct HexLds {
+  static constexpr int kQ = 0;                                          // [4][N]
+  static constexpr int kQd = kHexRobots * N;                            // [4][N]
+  static constexpr int kOut = 2 * kHexRobots * N;                       // [4][N]
+  static constexpr int kDof = (3 * kHexRobots * N + 3) & ~3;            // [4][N][8]: world axis z_j _, joint origin o_j _
+  static constexpr int kCol = kDof + kHexRobots * N * 8;                // [4][16][4]: column of dof s, current frame
+  static constexpr int kXch = kCol + kHexRobots * kHex * 4;             // [4][16][4]: identity-leaf exchange
+  static constexpr int kRowStride = (2 * (N + 1) + 3) & ~3;             // one pivot row [A_k | f_k] as doubles
+  static constexpr int kRow = kXch + kHexRobots * kHex * 4;             // [4][kRowStride]
+  static constexpr int kSysStride = 2 * N * (N + 1);                    // the whole system [N][N+1] as doubles
+  static constexpr int kSys = kRow + kHexRobots * kRowStride;           // [4][kSysStride]
+  static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
+  // dynamic: T0 [4][n_ops][12] | T1 [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
+  //   ops | leaves | fk list | id list | leaf ops | jump[5][32] | dof_op[16] | dof_anc[16] | goal tile [4][16]
+};
+
+// bytes of dynamic LDS a launch needs (host side)
+template <int N>
+inline size_t hex_lds_bytes(int n_ops, int n_leaf_ops, int n_leaves, int n_sphere_floats) {
+  return sizeof(float) * (HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + n_sphere_floats) +
+         sizeof(DevOp) * n_ops + sizeof(DevLeaf) * n_leaves +
+         sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps + 5 * kMaxOps + 2 * RMP2_MAX_DOF) +
+         sizeof(float) * 16 * kHexRobots;
+}
+
+template <int N, bool CAP>
+__global__ void __launch_bounds__(kWave, 1)
+rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
+                     const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
+                     OutArgs out, int R) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef RMP2_STAMPS
+  unsigned long long st_[8];
+  int st_n = 0;
+#endif
+  RMP2_STAMP();
+  const int lane = threadIdx.x;
+  const int s = lane & (kHex - 1);
+  const int g = lane >> 4;
+  const int r0 = blockIdx.x * kHexRobots;
+  const int robot = r0 + g;
+  const bool live = robot < R;
+  const int n_dof = hdr.n_dof, n_ops = hdr.n_ops, n_id = hdr.n_id, n_lo = hdr.n_leaf_ops;
+  const uint32_t rev_mask = hdr.rev_mask;
+  const int n_live = min(kHexRobots, R - r0);
+  const int gi = min(g, n_live - 1);  // groups beyond the fleet's tail re-use the last live robot's inputs
+
+  // ---- LDS carve-up -----------------------------------------------------------------------------------
+  float* const T0 = lds + HexLds<N>::kFloats;
+  float* const T1 = T0 + kHexRobots * n_ops * 12;
+  float* const SCb = T1 + kHexRobots * n_ops * 12;   // [4][n_ops][8] prefix-sum exchange
+  float* const VAb = SCb + kHexRobots * n_ops * 8;   // [4][n_ops][8] (v, a) of every frame origin
+  const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? min(obs.n_spheres, kLdsSpheres) : 0;
+  float* const sph_lds_base = VAb + kHexRobots * n_ops * 8;
+  float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
+  DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
+  DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
+  int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
+  int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
+  int32_t* const s_lo = s_id + RMP2_MAX_LEAVES;
+  int32_t* const s_jump = s_lo + kMaxOps;
+  int32_t* const s_dof_op = s_jump + 5 * kMaxOps;
+  uint32_t* const s_dof_anc = reinterpret_cast<uint32_t*>(s_dof_op + RMP2_MAX_DOF);
+  float* const s_goal = reinterpret_cast<float*>(s_dof_anc + RMP2_MAX_DOF);
+
+  // ---- prologue: one burst of loads brings the state tile, the obstacle table and the program on chip ----
+  {
+    const int tile = n_live * n_dof;
+    const float* gq = q + (size_t)r0 * n_dof;
+    const float* gqd = qd + (size_t)r0 * n_dof;
+    if (n_dof == N) {  // rows are contiguous in HBM and in LDS: no index arithmetic
+      for (int i = lane; i < tile; i += kWave) {
+        lds[HexLds<N>::kQ + i] = gq[i];
+        lds[HexLds<N>::kQd + i] = gqd[i];
+      }
+    } else {
+      for (int i = lane; i < tile; i += kWave) {
+        const int rr = i / n_dof, jj = i - rr * n_dof;
+        lds[HexLds<N>::kQ + rr * N + jj] = gq[i];
+        lds[HexLds<N>::kQd + rr * N + jj] = gqd[i];
+      }
+    }
+    if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
+      const int pad = N - n_dof;
+      for (int i = lane; i < kHexRobots * pad; i += kWave) {
+        const int rr = i / pad, jj = n_dof + (i - rr * pad);
+        lds[HexLds<N>::kQ + rr * N + jj] = 0.f;
+        lds[HexLds<N>::kQd + rr * N + jj] = 0.f;
+      }
+    }
+    {
+      const int nf = (CAP ? 8 : 4) * n_sph_lds;
+      for (int i = lane; i < nf; i += kWave) sph_lds_base[i] = obs.spheres[i];
+    }
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
+      uint4* dst = reinterpret_cast<uint4*>(s_ops);
+      for (int i = lane; i < n_ops * (int)(sizeof(DevOp) / 16); i += kWave) dst[i] = src[i];
+      src = reinterpret_cast<const uint4*>(prog->leaves);
+      dst = reinterpret_cast<uint4*>(s_leaves);
+      for (int i = lane; i < hdr.n_leaves * (int)(sizeof(DevLeaf) / 16); i += kWave) dst[i] = src[i];
+      if (lane < RMP2_MAX_LEAVES) {
+        s_fk[lane] = prog->fk_leaves[lane];
+        s_id[lane] = prog->id_leaves[lane];
+      }
+      if (lane < kMaxOps) s_lo[lane] = prog->leaf_ops[lane];
+      const int32_t* jsrc = &prog->hex.jump[0][0];
+      for (int i = lane; i < 5 * kMaxOps; i += kWave) s_jump[i] = jsrc[i];
+      if (lane < RMP2_MAX_DOF) {
+        s_dof_op[lane] = prog->hex.dof_op[lane];
+        s_dof_anc[lane] = prog->hex.dof_anc[lane];
+      }
+      if (goal) {
+        const int gf = hdr.goal_floats;  // <= 16 (checked on the host)
+        for (int i = lane; i < n_live * gf; i += kWave) {
+          const int rr = i / gf, jj = i - rr * gf;
+          s_goal[rr * 16 + jj] = goal[(size_t)(r0 + rr) * goal_stride + jj];
+        }
+      }
+    }
+    hex_sync();
+  }
+  RMP2_STAMP();  // 1: prologue done
+  const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
+  const float* my_q = &lds[HexLds<N>::kQ + gi * N];
+  const float* my_qd = &lds[HexLds<N>::kQd + gi * N];
+  float* my_out = &lds[HexLds<N>::kOut + g * n_dof];
+  const float* my_goal = goal ? s_goal + gi * 16 : nullptr;
+  float* const DOF = &lds[HexLds<N>::kDof + g * N * 8];
+  float4* const COL = reinterpret_cast<float4*>(&lds[HexLds<N>::kCol + g * kHex * 4]);
+  float4* const XCH = reinterpret_cast<float4*>(&lds[HexLds<N>::kXch + g * kHex * 4]);
+  uint32_t status = 0u;
+
+  // ---- phase 1: local transforms T_constant @ T_variable(q) of all frames, one frame per lane -----------
+  // (kinematics.py:222-240); frames k = s and s + 16
+  float Tm[2][12];  // [R row-major (9) | t (3)]
+#pragma unroll
+  for (int slot = 0; slot < 2; ++slot) {
+    const int k = s + kHex * slot;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) Tm[slot][c] = 0.f;
+    if (k < n_ops) {
+      const DevOp& opg = s_ops[k];
+      const int jt = opg.jtype, qi = opg.qidx;
+      const float qv = qi >= 0 ? my_q[qi] : 0.f;
+      const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
+      float sn = 0.f, cs = 1.f;
+      if (jt == RMP2_JOINT_REVOLUTE) {
+        if (fabsf(qv) <= 8192.0f)
+          sincos1(qv, sn, cs);
+        else
+          sincosf(qv, &sn, &cs);
+      }
+      const float omc = 1.0f - cs;
+      const bool rev = jt == RMP2_JOINT_REVOLUTE;
+      // Rodrigues: cos*I + sin*[u]x + (1-cos)*u u^T (kinematics.py:103-121); identity for non-revolute joints
+      const float ut[9] = {0.f, -ax[2], ax[1], ax[2], 0.f, -ax[0], -ax[1], ax[0], 0.f};
+      float Rv[9], Tc[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) Tc[c] = opg.Tc[c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float e = (r == c) ? 1.f : 0.f;
+          Rv[3 * r + c] = rev ? cs * e + sn * ut[3 * r + c] + omc * (ax[r] * ax[c]) : e;
+        }
+      const float tq = (jt == RMP2_JOINT_PRISMATIC) ? qv : 0.f;
+      const float tv[3] = {tq * ax[0], tq * ax[1], tq * ax[2]};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          Tm[slot][3 * r + c] = Tc[4 * r + 0] * Rv[c] + Tc[4 * r + 1] * Rv[3 + c] + Tc[4 * r + 2] * Rv[6 + c];
+        Tm[slot][9 + r] = Tc[4 * r + 0] * tv[0] + Tc[4 * r + 1] * tv[1] + Tc[4 * r + 2] * tv[2] + Tc[4 * r + 3];
+      }
+      float4* dst = reinterpret_cast<float4*>(T0 + (g * n_ops + k) * 12);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
+    }
+  }
+
+  // ---- phase 2: world transforms by pointer jumping (ordered product of kinematics.py:243-246) -----------
+  // after round l, T[k] is the product of the last min(2^(l+1), depth) local transforms ending at k
+  for (int l = 0; l < hdr.n_levels; ++l) {
+    const float* src = (l & 1) ? T1 : T0;
+    float* dstb = (l & 1) ? T0 : T1;
+    hex_sync();
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int k = s + kHex * slot;
+      if (k < n_ops) {
+        const int j = s_jump[l * kMaxOps + k];
+        if (j >= 0) {
+          const float4* p4 = reinterpret_cast<const float4*>(src + (g * n_ops + j) * 12);
+          const float4 a0 = p4[0], a1 = p4[1], a2 = p4[2];
+          const float Pr[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+          float Tn[12];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              Tn[3 * r + c] = Pr[3 * r] * Tm[slot][c] + Pr[3 * r + 1] * Tm[slot][3 + c] + Pr[3 * r + 2] * Tm[slot][6 + c];
+            Tn[9 + r] = Pr[3 * r] * Tm[slot][9] + Pr[3 * r + 1] * Tm[slot][10] + Pr[3 * r + 2] * Tm[slot][11] + Pr[9 + r];
+          }
+#pragma unroll
+          for (int c = 0; c < 12; ++c) Tm[slot][c] = Tn[c];
+        }
+        float4* dst = reinterpret_cast<float4*>(dstb + (g * n_ops + k) * 12);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
+      }
+    }
+  }
+  hex_sync();
+  const float* const TW = ((hdr.n_levels & 1) ? T1 : T0) + g * n_ops * 12;  // this robot's world transforms
+
+  // ---- phase 3: velocity and bias acceleration of EVERY frame origin from two tree prefix sums -------------
+  // With w_m = qd_m z_m, b_m = -qd_m z_m x o_m (revolute) or w_m = 0, b_m = qd_m z_m (prismatic) and W_k, B_k
+  // their sums over the joints at or above frame k:
+  //     v_k = W_k x p_k + B_k                                     ( = J_k qd,     kinematics.py:265 )
+  // and with zd_m = W_m x z_m, al_m = qd_m zd_m, c_m = -qd_m (zd_m x o_m + z_m x v_m) (revolute) or
+  // al_m = 0, c_m = qd_m zd_m (prismatic) and AL_k, C_k their sums:
+  //     a_k = AL_k x p_k + W_k x v_k + C_k                        ( = Jdot_k qd,  kinematics.py:267 )
+  // Each prefix sum is n_levels rounds of pointer jumping over the same ancestor table as the transforms.
+  {
+    float* const SC = SCb + g * n_ops * 8;
+    float* const VA = VAb + g * n_ops * 8;
+    float pk[2][3], zk[2][3], qdk[2], X[2][6];
+    bool revk[2], prik[2];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int k = s + kHex * slot;
+      revk[slot] = prik[slot] = false;
+      qdk[slot] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pk[slot][c] = zk[slot][c] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) X[slot][c] = 0.f;
+      if (k < n_ops) {
+        const DevOp& opg = s_ops[k];
+        const int jt = opg.jtype, qi = opg.qidx;
+        revk[slot] = jt == RMP2_JOINT_REVOLUTE && qi >= 0;
+        prik[slot] = jt == RMP2_JOINT_PRISMATIC && qi >= 0;
+        qdk[slot] = qi >= 0 ? my_qd[qi] : 0.f;
+        const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          zk[slot][r] = Tm[slot][3 * r] * ax[0] + Tm[slot][3 * r + 1] * ax[1] + Tm[slot][3 * r + 2] * ax[2];
+          pk[slot][r] = Tm[slot][9 + r];
+        }
+        if (qi >= 0 && jt != RMP2_JOINT_FIXED) {  // per-dof table for the Jacobian columns
+          float4* d4 = reinterpret_cast<float4*>(DOF + qi * 8);
+          d4[0] = make_float4(zk[slot][0], zk[slot][1], zk[slot][2], 0.f);
+          d4[1] = make_float4(pk[slot][0], pk[slot][1], pk[slot][2], 0.f);
+        }
+        float zxo[3];
+        cross3(zk[slot], pk[slot], zxo);
+        const float qdm = qdk[slot];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          X[slot][r] = revk[slot] ? qdm * zk[slot][r] : 0.f;
+          X[slot][3 + r] = revk[slot] ? -qdm * zxo[r] : (prik[slot] ? qdm * zk[slot][r] : 0.f);
+        }
+      }
+    }
+    // inclusive prefix sum of X over the ancestors of every op
+    auto tree_prefix = [&](float (&x)[2][6]) {
+      for (int l = 0; l < hdr.n_levels; ++l) {
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+          const int k = s + kHex * slot;
+          if (k < n_ops) {
+            float4* d4 = reinterpret_cast<float4*>(SC + k * 8);
+            d4[0] = make_float4(x[slot][0], x[slot][1], x[slot][2], x[slot][3]);
+            d4[1] = make_float4(x[slot][4], x[slot][5], 0.f, 0.f);
+          }
+        }
+        hex_sync();
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+          const int k = s + kHex * slot;
+          if (k < n_ops) {
+            const int j = s_jump[l * kMaxOps + k];
+            if (j >= 0) {
+              const float4* d4 = reinterpret_cast<const float4*>(SC + j * 8);
+              const float4 u0 = d4[0], u1 = d4[1];
+              x[slot][0] += u0.x, x[slot][1] += u0.y, x[slot][2] += u0.z;
+              x[slot][3] += u0.w, x[slot][4] += u1.x, x[slot][5] += u1.y;
+            }
+          }
+        }
+        hex_sync();
+      }
+    };
+    tree_prefix(X);  // X = (W_k, B_k)
+    float vk[2][3], Y[2][6];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]};
+      float t1[3], zd[3], t2[3], t3[3];
+      cross3(Wk, pk[slot], t1);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) vk[slot][r] = t1[r] + X[slot][3 + r];
+      cross3(Wk, zk[slot], zd);
+      cross3(zd, pk[slot], t2);
+      cross3(zk[slot], vk[slot], t3);
+      const float qdm = qdk[slot];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Y[slot][r] = revk[slot] ? qdm * zd[r] : 0.f;
+        Y[slot][3 + r] = revk[slot] ? -qdm * (t2[r] + t3[r]) : (prik[slot] ? qdm * zd[r] : 0.f);
+      }
+    }
+    tree_prefix(Y);  // Y = (AL_k, C_k)
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int k = s + kHex * slot;
+      if (k < n_ops) {
+        const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]}, ALk[3] = {Y[slot][0], Y[slot][1], Y[slot][2]};
+        float t1[3], t2[3], ak[3];
+        cross3(ALk, pk[slot], t1);
+        cross3(Wk, vk[slot], t2);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ak[r] = t1[r] + t2[r] + Y[slot][3 + r];
+        float4* d4 = reinterpret_cast<float4*>(VA + k * 8);
+        d4[0] = make_float4(vk[slot][0], vk[slot][1], vk[slot][2], ak[0]);
+        d4[1] = make_float4(ak[1], ak[2], 0.f, 0.f);
+      }
+    }
+    hex_sync();
+  }
+  RMP2_STAMP();  // 2: kinematics done
+
+  // ---- the fp64 system, one row per lane: A[j] = M[s][j], fv = f[s] -------------------------------------
+  double A[N];
+  double fv = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) A[j] = 0.0;
+  const bool my_rev = (rev_mask >> (s < N ? s : 0)) & 1u;
+
+  // ---- leaves on FK task maps, frame by frame -----------------------------------------------------------
+  for (int t = 0; t < n_lo; ++t) {
+    const int k = uni<true>(s_lo[t]);
+    OpCtl op = *reinterpret_cast<const OpCtl*>(&s_ops[k]);
+    op.anc_mask = (uint32_t)uni<true>((int)op.anc_mask);
+    op.leaf_begin = uni<true>(op.leaf_begin);
+    op.leaf_count = uni<true>(op.leaf_count);
+    const float4 tp = reinterpret_cast<const float4*>(TW + k * 12)[2];
+    const float4* va4 = reinterpret_cast<const float4*>(VAb + (g * n_ops + k) * 8);
+    const float4 f0 = va4[0], f1 = va4[1];
+    const float P3[3] = {tp.y, tp.z, tp.w}, V3[3] = {f0.x, f0.y, f0.z}, A3[3] = {f0.w, f1.x, f1.y};
+    // Jacobian column of MY dof at this frame's origin; all columns through LDS
+    float mycol[3] = {0.f, 0.f, 0.f};
+    if (s < N && ((op.anc_mask >> s) & 1u)) {
+      const float4* d4 = reinterpret_cast<const float4*>(DOF + s * 8);
+      const float4 z4 = d4[0], o4 = d4[1];
+      const float zj[3] = {z4.x, z4.y, z4.z};
+      const float dd[3] = {P3[0] - o4.x, P3[1] - o4.y, P3[2] - o4.z};
+      float cr[3];
+      cross3(zj, dd, cr);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) mycol[c] = my_rev ? cr[c] : zj[c];
+    }
+    COL[s] = make_float4(mycol[0], mycol[1], mycol[2], 0.f);
+    hex_sync();
+    float col[N][3];  // columns of dofs that do not move the frame were written as zeros: no branches needed
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float4 c4 = COL[j];
+      col[j][0] = c4.x, col[j][1] = c4.y, col[j][2] = c4.z;
+    }
+    for (int li = 0; li < op.leaf_count; ++li) {
+      const DevLeaf& lf = s_leaves[uni<true>(s_fk[op.leaf_begin + li])];
+      LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);
+      lh.kind = uni<true>(lh.kind);
+      lh.taskmap = uni<true>(lh.taskmap);
+      lh.goal_offset = uni<true>(lh.goal_offset);
+      float S[6], h[3];
+      if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+        float gl[3], xdd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
+        if (lh.kind == RMP2_LEAF_TARGET_ATTRACTOR)
+          target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
+        else
+          leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
+        const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
+        h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
+        h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
+        h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+      } else {
+        // distance leaf: this lane takes pairs b = s, s + 16, ...; S and h are summed over the 16 lanes
+#pragma unroll
+        for (int c = 0; c < 6; ++c) S[c] = 0.f;
+        h[0] = h[1] = h[2] = 0.f;
+        const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
+        if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
+          if (spheres_in_lds)
+            pair_loop<kPairsSharedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, s,
+                                                  P3, V3, A3, lh.P, IP, S, h);
+          else
+            pair_loop<kPairsSharedGlobal, CAP, kHex>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres,
+                                                     s, P3, V3, A3, lh.P, IP, S, h);
+        } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+          const int lidx = uni<true>(lf.index);
+          const int pb = obs.pair_begin[lidx];
+          const int count = obs.pair_begin[lidx + 1] - pb;
+          const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
+          pair_loop<kPairsExplicit, false, kHex>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, s, P3,
+                                                 V3, A3, lh.P, IP, S, h);
+        } else {
+          const int b0 = obs.csr_offset[live ? robot : 0];
+          const int count = live ? obs.csr_offset[robot + 1] - b0 : 0;
+          int max_count = count;
+#pragma unroll
+          for (int o = 32; o >= kHex; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+          if (spheres_in_lds)
+            pair_loop<kPairsRaggedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
+                                                  P3, V3, A3, lh.P, IP, S, h);
+          else
+            pair_loop<kPairsRaggedGlobal, CAP, kHex>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
+                                                     P3, V3, A3, lh.P, IP, S, h);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) S[c] = hex_sum(S[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[c] = hex_sum(h[c]);
+      }
+      // pull-back into MY row:  f_s += col_s . h ;  A[s][j] += (S col_s) . col_j   (rmp.py:165-167)
+      const float u[3] = {S[0] * mycol[0] + S[1] * mycol[1] + S[2] * mycol[2],
+                          S[1] * mycol[0] + S[3] * mycol[1] + S[4] * mycol[2],
+                          S[2] * mycol[0] + S[4] * mycol[1] + S[5] * mycol[2]};
+      fv += (double)dot3(mycol, h);
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[j] += (double)dot3(u, col[j]);
+    }
+    hex_sync();  // COL is rewritten for the next frame
+  }
+  RMP2_STAMP();  // 3: FK leaves done
+
+  // ---- identity-task-map leaves: x = q, xd = qd, J = I (taskmap.py:13-20); lane s owns row s -------------
+  {
+    const bool row_ok = s < n_dof;
+    const int ii = (s < N) ? s : 0;
+    const float qi_ = my_q[ii], qdi = (s < N) ? my_qd[ii] : 0.f;
+    for (int li = 0; li < n_id; ++li) {
+      const DevLeaf& lfr = s_leaves[uni<true>(s_id[li])];
+      const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);
+      const int kind = uni<true>(lh.kind), goal_offset = uni<true>(lh.goal_offset);
+      const float* P = lh.P;
+      const float va_i = lfr.va[ii], vb_i = lfr.vb[ii];
+      if (kind == RMP2_LEAF_JOINT_DAMPING || kind == RMP2_LEAF_CSPACE_BIASING || kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {
+        // diagonal metrics m * I:  A_ss += m, f_s += m * xdd_s
+        float mdiag, acc;
+        if (kind == RMP2_LEAF_JOINT_DAMPING) {  // rmp2.py:127-137
+          const float s2 = hex_sum(qdi * qdi);
+          const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+          mdiag = P[1] * nrm + P[2];
+          acc = -(P[0] * nrm) * qdi;
+        } else if (kind == RMP2_LEAF_CSPACE_BIASING) {  // rmp2.py:212-226
+          const float e = (s < N) ? qi_ - va_i : 0.f;
+          const float nrm = sqrtf(hex_sum(e * e));
+          mdiag = P[0] + P[4];
+          const float pos = (nrm < P[3]) ? (-e * P[1]) : (-P[3] * (e / nrm) * P[1]);
+          acc = pos + (-P[2] * qdi);
+        } else {  // rmp.py:330-347
+          mdiag = P[2];
+          acc = P[0] * (va_i - qi_) - P[1] * qdi;
+        }
+        if (s < N) fv += (double)(mdiag * acc);
+        const double dm = (double)mdiag;
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[j] += (s == j) ? dm : 0.0;
+      } else {
+        // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij): every lane forms the
+        // (zeta, xdd, cw) of ITS dof, the triples are exchanged through LDS
+        float zeta_i = 0.f, xdd_i = 0.f, cw_i = 0.f, beta, wsc;
+        if (kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+          // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) on the FULL matrix (quirk Q4)
+          const float cutoff = P[0] - P[1];
+          const float dv = fabsf(qdi) - cutoff;
+          const float sgn = (qdi > 0.f) ? 1.f : (qdi < 0.f ? -1.f : 0.f);
+          const float acc = -fabsf(P[2] * dv) * sgn;
+          xdd_i = (fabsf(qdi) < cutoff) ? 0.f : acc;
+          const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+          zeta_i = P[3] / (1.0f - ratio * ratio);  // diagonal entry
+          cw_i = P[3] / 1.0f;                      // off-diagonal entry
+          beta = 0.f;
+          wsc = 0.f;
+        } else if (kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+          // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
+          const float rr_ = 0.15f;
+          const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
+          const float iqd_max = (float)(60.0 / (20.0 * (2.0 * 3.14159265358979323846)));
+          const float irange = rcp1(vb_i - va_i);
+          const float du = (vb_i - qi_) * irange;
+          const float dl = (qi_ - va_i) * irange;
+          const float d = fminf(du, dl);
+          const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
+          cw_i = row_ok ? (d > rr_ ? 0.f : spline) : 0.f;
+          const float zraw = row_ok ? qdi * iqd_max : 0.f;
+          const float s2 = hex_sum(zraw * zraw);
+          xdd_i = -P[0] * qi_ - P[1] * qdi;
+          const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+          // soft norm h = |v| + (1/c) log(1 + exp(-2 c |v|)), c = 5   (helper/rmp_helper.py:62-65)
+          const float hh = nrm + 0.2f * (0.693147182464599609375f * __builtin_amdgcn_logf(1.0f + exp1(-10.0f * nrm)));
+          zeta_i = zraw * rcp1(hh);
+          beta = 0.9f;
+          wsc = 1.0f;
+        } else {
+          // TargetPolicy on the identity map, rmp.py:241-260 (goal is an n-vector)
+          const float alpha = P[0], beta_d = P[1], c = P[2];
+          const float v_i = row_ok ? my_goal[goal_offset + ii] - qi_ : 0.f;
+          const float vn = sqrtf(hex_sum(v_i * v_i));
+          const float hq = vn + c * logf(1.0f + expf(-2.0f * c * vn));
+          const float inv_h = 1.0f / hq;
+          xdd_i = row_ok ? alpha * (inv_h * v_i) - beta_d * qdi : 0.f;
+          const float fn = sqrtf(hex_sum(xdd_i * xdd_i));
+          const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+          zeta_i = xdd_i / hs;
+          cw_i = 1.0f;
+          beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
+          wsc = expf(-vn / 3.0f);
+        }
+        if (!row_ok) zeta_i = xdd_i = cw_i = 0.f;
+        XCH[s] = make_float4(zeta_i, xdd_i, cw_i, 0.f);
+        hex_sync();
+        const float omb = 1.0f - beta;
+        const bool is_cap = kind == RMP2_LEAF_JOINT_VELOCITY_CAP;
+        const bool is_jla = kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
+        float fi = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // padded dofs hold (0, 0, 0): their columns come out as exact zeros
+          const float4 x4 = XCH[j];
+          const float zj = x4.x, xj = x4.y, cj = x4.z;
+          float a;
+          if (is_cap) {
+            a = (j == s) ? zeta_i : cj;
+          } else {
+            const float Hij = beta * (zeta_i * zj) + omb * (j == s ? 1.f : 0.f);
+            a = is_jla ? cj * Hij : wsc * Hij;
+          }
+          a = row_ok ? a : 0.f;
+          A[j] += (double)a;
+          fi += a * xj;
+        }
+        fv += (double)fi;
+        hex_sync();  // XCH is rewritten by the next dense leaf
+      }
+    }
+  }
+  RMP2_STAMP();  // 4: identity leaves done
+
+  // optional outputs: the combined metric / force before the resolve
+  if (live && s < n_dof) {
+    if (out.M) {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (j < n_dof) out.M[((size_t)robot * n_dof + s) * n_dof + j] = A[j];
+    }
+    if (out.f) out.f[(size_t)robot * n_dof + s] = fv;
+  }
+  // padding dofs of the template: identity rows so that they resolve to qdd = 0
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (s >= n_dof && j == s) A[j] = 1.0;
+  // keep the untouched system for the careful path
+  double* const SYS = reinterpret_cast<double*>(&lds[HexLds<N>::kSys + g * HexLds<N>::kSysStride]);
+  if (s < N) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) SYS[s * (N + 1) + j] = A[j];
+    SYS[s * (N + 1) + N] = fv;
+  }
+
+  // ---- resolve: Gauss-Jordan in fp64 without row exchanges, one row per lane ------------------------------
+  // (certification as lu_solve<N>, rmp2_solve.h: tiny pivot, multiplier growth, non-finite result -> careful path)
+  bool flagged;
+  {
+    double scale = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(A[j]));
+    scale = hex_maxd(scale);
+    const double tiny = 1e-11 * scale;
+    flagged = !(scale > 0.0) || !(scale < 1.7e308);
+    double lmax = 0.0, inv_own = 0.0;
+    double* const ROW = reinterpret_cast<double*>(&lds[HexLds<N>::kRow + g * HexLds<N>::kRowStride]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (s == k) {
+#pragma unroll
+        for (int j = k; j < N; ++j) ROW[j] = A[j];
+        ROW[N] = fv;
+      }
+      hex_sync();
+      double rowk[N];
+#pragma unroll
+      for (int j = k; j < N; ++j) rowk[j] = ROW[j];
+      const double bk = ROW[N];
+      const bool bad = !(fabs(rowk[k]) > tiny);
+      flagged = flagged || bad;
+      const double inv = bad ? 0.0 : rcpd(rowk[k]);
+      inv_own = (s == k) ? inv : inv_own;
+      const double l = (s != k) ? A[k] * inv : 0.0;
+      lmax = fmax(lmax, (s > k) ? fabs(l) : 0.0);
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) A[j] = fma(-l, rowk[j], A[j]);
+      fv = fma(-l, bk, fv);
+      hex_sync();  // the next pivot row overwrites ROW
+    }
+    lmax = hex_maxd(lmax);
+    flagged = flagged || !(lmax <= 1e4);
+    const double x = fv * inv_own;
+    const bool finite = (s >= n_dof) || (fabs(x) < 1.7e308);
+    flagged = flagged || hex_any(!finite, g);
+    if (s < n_dof) my_out[s] = (float)x;
+  }
+  RMP2_STAMP();  // 5: resolve done
+
+  if (__any(flagged && live)) {
+    hex_sync();  // SYS rows of all lanes are in LDS
+    if (flagged) {
+      // ---- rare path: every lane of the robot runs the careful solve on the whole system -----------------
+      double W[N * (N + 1)], T[N * (N + 1)], xp[N];
+      for (int i = 0; i < N * (N + 1); ++i) W[i] = SYS[i];
+      status |= RMP2_STATUS_PINV_PATH;
+      bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does)
+      for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);
+      if (!finite_in) {
+        for (int i = 0; i < N; ++i) xp[i] = __builtin_nan("");
+      } else if (!lu_pivot_compact(W, T, N, xp)) {
+        const int dropped = pinv_solve_compact(W, N, n_dof, xp);
+        if (dropped) status |= RMP2_STATUS_RANK_DROP;
+      }
+      bool finite = true;
+      for (int i = 0; i < n_dof; ++i) {
+        finite = finite && (fabs(xp[i]) < 1.7e308);
+        if (s == 0) my_out[i] = (float)xp[i];
+      }
+      if (!finite) status |= RMP2_STATUS_NONFINITE;
+    }
+  }
+
+  // ---- coalesced store of the qdd tile -----------------------------------------------------------------
+  hex_sync();
+  {
+    const float* tile = &lds[HexLds<N>::kOut];
+    const int count = n_live * n_dof;
+    float* go = out.qdd + (size_t)r0 * n_dof;
+    for (int i = lane; i < count; i += kWave) go[i] = tile[i];
+  }
+  if (out.status && live && s == 0) out.status[robot] = status;
+#ifdef RMP2_STAMPS
+  RMP2_STAMP();  // 6: stored
+  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: f buffer receives the stamps
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
+  }
+#endif
+}
+
+}  // namespace rmp2

@@ -18,6 +18,7 @@
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
 #include "rmp2_quad.h"
+#include "rmp2_hex.h"
 
 using namespace rmp2;
 
@@ -728,7 +729,8 @@ struct rmp2_handle {
   uint32_t rev_mask = 0;
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
   bool likely_singular = false;  // no positive-definite identity leaf in the set
-  int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot (env RMP2_KERNEL=lane|quad, A/B only)
+  int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
+  int hex_levels = 0;
   std::vector<int> distance_leaves;
   DevProgram* d_prog = nullptr;
   int32_t* d_pair_begin = nullptr;
@@ -869,6 +871,37 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     for (int c = 0; c < 3; ++c) op.axis[c] = rb.axis[f][c];
     for (int c = 0; c < 12; ++c) op.Tc[c] = (float)wf[w].Tc[c];
   }
+  {  // tables of the 16-lane kernel: pointer-jumping ancestors, per-dof joint op and strict ancestor dofs
+    std::vector<int> parent_op(F, -1), depth(F, 1);
+    int deepest = F > 0 ? 1 : 0;
+    for (int k = 0; k < F; ++k) {
+      const int p = wf[order[k]].parent;
+      parent_op[k] = p < 0 ? -1 : pos[p];
+      depth[k] = p < 0 ? 1 : depth[pos[p]] + 1;  // depth-first order: the parent's op precedes k
+      deepest = std::max(deepest, depth[k]);
+    }
+    int L = 0;
+    while ((1 << L) < deepest) ++L;
+    P.hex.n_levels = L;
+    for (int l = 0; l < 5; ++l)
+      for (int k = 0; k < kMaxOps; ++k) P.hex.jump[l][k] = -1;
+    for (int k = 0; k < F; ++k) P.hex.jump[0][k] = parent_op[k];
+    for (int l = 1; l < 5; ++l)
+      for (int k = 0; k < F; ++k) {
+        const int j = P.hex.jump[l - 1][k];
+        P.hex.jump[l][k] = j < 0 ? -1 : P.hex.jump[l - 1][j];
+      }
+    for (int j = 0; j < RMP2_MAX_DOF; ++j) {
+      P.hex.dof_op[j] = -1;
+      P.hex.dof_anc[j] = 0u;
+    }
+    for (int k = 0; k < F; ++k) {
+      const int qi = P.ops[k].qidx;
+      if (qi < 0) continue;
+      P.hex.dof_op[qi] = k;
+      P.hex.dof_anc[qi] = P.ops[k].anc_mask & ~(1u << qi);
+    }
+  }
   n_slots = (int)free_at.size();
   P.n_ops = F;
   P.n_dof = n;
@@ -975,7 +1008,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + (o.capsule ? 8 : 4) * n_sph_lds);
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
-  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask};
+  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
+                    h->hex_levels};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
@@ -989,6 +1023,23 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     if (o.capsule) RMP2_QUAD_LAUNCH(2, false, true); else RMP2_QUAD_LAUNCH(2, false, false);
   }
 #undef RMP2_QUAD_LAUNCH
+}
+
+template <int N>
+void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                const OutArgs& out, int R, hipStream_t s) {
+  const int blocks = (R + kHexRobots - 1) / kHexRobots;
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  const size_t bytes = hex_lds_bytes<N>(h->n_ops_step, h->n_leaf_ops, h->n_leaves, (o.capsule ? 8 : 4) * n_sph_lds);
+  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
+                    h->hex_levels};
+  if (o.capsule)
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal, gs,
+                       o, out, R);
+  else
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal,
+                       gs, o, out, R);
 }
 
 template <int N>
@@ -1006,6 +1057,14 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //    splits 4 ways); the only kernel with the fused rollout loop;
   //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
   //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
+  //  * hex (16 lanes per robot): the latency build for fleets that leave SIMDs idle under the quad mapping.
+  const bool hex_ok = !rollout && !h->has_point && h->goal_floats <= 16;
+  // measured (profiles/): hex wins up to 2 waves per SIMD (R <= 8192: 12.0 vs 14.5 us for the 3-leaf set and 23 vs
+  // 43 us for the cluttered set at R = 4096), the quad / lane kernels beyond
+  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 2048 * kHexRobots))) {
+    launch_hex<N>(h, q, qd, goal, gs, o, out, R, s);
+    return RMP2_OK;
+  }
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && R > 16384));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
@@ -1071,10 +1130,13 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
       h->likely_singular = false;
   }
   h->n_leaf_ops = P.n_leaf_ops;
+  h->hex_levels = P.hex.n_levels;
   h->rev_mask = P.rev_mask;
   {
     const char* kenv = std::getenv("RMP2_KERNEL");
-    h->kernel_choice = !kenv ? 0 : (std::strcmp(kenv, "lane") == 0 ? 1 : (std::strcmp(kenv, "quad") == 0 ? 2 : 0));
+    h->kernel_choice = !kenv ? 0
+                       : (std::strcmp(kenv, "lane") == 0 ? 1
+                          : (std::strcmp(kenv, "quad") == 0 ? 2 : (std::strcmp(kenv, "hex") == 0 ? 3 : 0)));
   }
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);

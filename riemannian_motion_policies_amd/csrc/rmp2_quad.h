@@ -162,16 +162,17 @@ __device__ __forceinline__ void target_attractor_fast(const float* P, const floa
 constexpr int kPairsExplicit = 0, kPairsSharedLds = 1, kPairsSharedGlobal = 2, kPairsRaggedLds = 3,
               kPairsRaggedGlobal = 4;
 
-template <int MODE, bool CAP>
+// W = lanes that share one robot's pairs (4: quad kernel, 16: hex kernel); lane `sub` takes pairs sub, sub + W, ...
+template <int MODE, bool CAP, int W = kQuad>
 __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, const float* po, const int32_t* ci,
                                           int count, int max_count, int sub, const float P3[3],
                                           const float V3[3], const float A3[3], const float* P, const float* IP,
                                           float S[6], float h[3]) {
   const float vv = dot3(V3, V3);
-  const int trips = (max_count + kQuad - 1) / kQuad;  // wave-uniform trip count
+  const int trips = (max_count + W - 1) / W;  // wave-uniform trip count
   // the obstacle record of the NEXT trip is fetched while the current one is evaluated
   auto fetch = [&](int t, float4& a, float4& b2) {
-    const int b_raw = kQuad * t + sub;
+    const int b_raw = W * t + sub;
     const int b = b_raw < count ? b_raw : 0;  // masked-off lanes re-read pair 0 (in bounds whenever count > 0)
     if (MODE == kPairsExplicit) {
       if (count > 0) {
@@ -197,7 +198,7 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
 #pragma unroll 2
   for (int t = 0; t < trips; ++t) {
     float nh[3], d;
-    const bool on = kQuad * t + sub < count;
+    const bool on = W * t + sub < count;
     const float4 ca = na, cb = nb;
     fetch(min(t + 1, trips - 1), na, nb);
     if (MODE == kPairsExplicit) {
@@ -279,6 +280,7 @@ struct RolloutArgs {
 struct QuadHdr {
   int32_t n_ops, n_dof, n_id, n_leaves, goal_floats, n_leaf_ops;
   uint32_t rev_mask;
+  int32_t n_levels;  // pointer-jumping rounds (rmp2_hex.h only)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * 16 * n_ops; }

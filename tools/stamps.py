@@ -27,7 +27,8 @@ for name, desc in sets.items():
     for _ in range(5):
         eng.step(q, qd, g, obstacles=obs, f=f)
     torch.cuda.synchronize()
-    st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + 15) // 16) * 8].reshape(-1, 8).astype(np.int64)
+    per_block = 4 if os.environ.get("RMP2_KERNEL") == "hex" else 16
+    st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + per_block - 1) // per_block) * 8].reshape(-1, 8).astype(np.int64)
     d = np.diff(st[:, :7], axis=1)
     med = np.median(d, axis=0)
     tot = np.median(st[:, 6] - st[:, 0])
