@@ -78,10 +78,18 @@ struct DevProgram {
     int32_t n_levels;                 // pointer-jumping rounds: smallest L with 2^L >= deepest chain
     int32_t pad_[3];
     int32_t jump[5][kMaxOps];         // jump[l][k]: the op 2^l levels above op k, -1 = above the base
-    int32_t dof_op[RMP2_MAX_DOF];     // op whose joint is driven by dof j, -1 = none in this program
-    uint32_t dof_anc[RMP2_MAX_DOF];   // dofs strictly above dof j's joint (they move its origin)
+    uint32_t op_anc[kMaxOps];         // bit j: op j is op k itself or one of its ancestors
   } hex;
 };
+
+// Local transform of one frame as an affine function of (cos q, sin q, q), precomputed on the host in fp64:
+//   R_local = A0 + cos(q) A1 + sin(q) A2 ,  t_local = tc + q tu
+// (revolute: A0 = Rc u u^T, A1 = Rc (I - u u^T), A2 = Rc [u]x -- Rodrigues' formula, kinematics.py:103-121,
+//  multiplied through T_constant; prismatic: A0 = Rc, tu = Rc u; fixed: A0 = Rc)
+struct HexOp {
+  float A0[9], A1[9], A2[9], tc[3], tu[3], pad_[3];  // 144 bytes
+};
+static_assert(sizeof(HexOp) % 16 == 0, "staged with dwordx4 copies");
 
 struct ObsArgs {
   int32_t mode, n_spheres, n_pairs;

@@ -77,22 +77,289 @@ struct HexLds {
 
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
-inline size_t hex_lds_bytes(int n_ops, int n_leaf_ops, int n_leaves, int n_sphere_floats) {
+inline size_t hex_lds_bytes(int n_ops, int blob16, int n_sphere_floats) {
   return sizeof(float) * (HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + n_sphere_floats) +
-         sizeof(DevOp) * n_ops + sizeof(DevLeaf) * n_leaves +
-         sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps + 5 * kMaxOps + 2 * RMP2_MAX_DOF) +
-         sizeof(float) * 16 * kHexRobots;
+         16 * (size_t)blob16 + sizeof(float) * 16 * kHexRobots;
+}
+
+// global -> LDS copy with up to four loads per lane in flight before the first LDS write
+template <typename T>
+__device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, int n, int lane) {
+  for (int base = 0; base < n; base += 4 * kWave) {
+    T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * kWave + lane;
+      if (i < n) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * kWave + lane;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
+#ifdef RMP2_STAMPS_KIN  // diagnostic: spend the stamps inside the kinematics phase instead of after the later phases
+#define RMP2_KSTAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (stp) stp[(*stn)++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RMP2_LSTAMP() do {} while (0)
+#else
+#define RMP2_KSTAMP() do {} while (0)
+#define RMP2_LSTAMP() RMP2_STAMP()
+#endif
+
+// ---- kinematics of all frames, SLOTS frames per lane (k = s, s + 16) ---------------------------------------------
+// Written as straight-line code: every LDS read that does not depend on another read's result is issued
+// unconditionally (clamped indices, 0/1 weights instead of branches) so that the reads of one stage are in flight
+// together -- the wave is alone on its SIMD, nothing else hides an LDS round trip.
+//   stage 1  local transforms (kinematics.py:222-240) from the host-folded form R = A0 + cos(q) A1 + sin(q) A2
+//   stage 2  world transforms by pointer jumping (ordered product of kinematics.py:243-246): after round l,
+//            T[k] is the product of the last min(2^(l+1), depth) local transforms ending at k
+//   stage 3  velocity and bias acceleration of every frame origin from two sums over the ancestors.  With
+//            w_m = qd_m z_m, b_m = -qd_m z_m x o_m (revolute) or w_m = 0, b_m = qd_m z_m (prismatic) and W_k, B_k
+//            their sums over the joints at or above frame k:
+//                v_k = W_k x p_k + B_k                                   ( = J_k qd,    kinematics.py:265 )
+//            and with zd_m = W_m x z_m, al_m = qd_m zd_m, c_m = -qd_m (zd_m x o_m + z_m x v_m) (revolute) or
+//            al_m = 0, c_m = qd_m zd_m (prismatic) and AL_k, C_k their sums:
+//                a_k = AL_k x p_k + W_k x v_k + C_k                      ( = Jdot_k qd, kinematics.py:267 )
+// Leaves world transforms in the returned buffer [n_ops][12], (v, a) in VA [n_ops][8], (z_j, o_j) in DOF [N][8].
+template <int N, int SLOTS>
+__device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s, int g, const float* my_q,
+                                                       const float* my_qd, float* T0, float* T1, float* SCb, float* VAb,
+                                                       float* DOF, const DevOp* s_ops, const HexOp* s_hops,
+                                                       const int32_t* s_jump, const uint32_t* s_op_anc,
+                                                       unsigned long long* stp = nullptr, int* stn = nullptr) {
+  const int n_ops = hdr.n_ops;
+  float* const Tb0 = T0 + g * n_ops * 12;
+  float* const Tb1 = T1 + g * n_ops * 12;
+  float4* const SC = reinterpret_cast<float4*>(SCb + g * n_ops * 8);
+  float4* const VA = reinterpret_cast<float4*>(VAb + g * n_ops * 8);
+  bool on[SLOTS], revk[SLOTS], prik[SLOTS];
+  int kk[SLOTS], jmp[SLOTS][5], qi[SLOTS];
+  uint32_t ancm[SLOTS];
+  float Tm[SLOTS][12], ax[SLOTS][3], qv[SLOTS], qdk[SLOTS];
+  // ---- stage 1 ----
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    const int k = s + kHex * slot;
+    on[slot] = k < n_ops;
+    kk[slot] = on[slot] ? k : 0;
+  }
+  float4 hop[SLOTS][9];
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    const int4* c4 = reinterpret_cast<const int4*>(&s_ops[kk[slot]]);
+    const int4 c0 = c4[0], c1 = c4[1];
+    const float4 c2 = reinterpret_cast<const float4*>(c4)[2];
+    const int jt = c0.w;
+    qi[slot] = c1.x;
+    ax[slot][0] = c2.x, ax[slot][1] = c2.y, ax[slot][2] = c2.z;
+    revk[slot] = on[slot] && jt == RMP2_JOINT_REVOLUTE;
+    prik[slot] = on[slot] && jt == RMP2_JOINT_PRISMATIC;
+    const float4* h4 = reinterpret_cast<const float4*>(&s_hops[kk[slot]]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) hop[slot][c] = h4[c];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) jmp[slot][l] = s_jump[l * kMaxOps + kk[slot]];
+    ancm[slot] = on[slot] ? s_op_anc[kk[slot]] : 0u;
+  }
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    const int qc = qi[slot] >= 0 ? qi[slot] : 0;
+    const float a = my_q[qc], b = my_qd[qc];
+    qv[slot] = qi[slot] >= 0 ? a : 0.f;
+    qdk[slot] = (qi[slot] >= 0 && (revk[slot] || prik[slot])) ? b : 0.f;
+  }
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    float sn = 0.f, cs = 1.f;
+    if (revk[slot]) {
+      if (fabsf(qv[slot]) <= 8192.0f)
+        sincos1(qv[slot], sn, cs);
+      else
+        sincosf(qv[slot], &sn, &cs);
+    }
+    const float tq = prik[slot] ? qv[slot] : 0.f;
+    const float* hf = reinterpret_cast<const float*>(hop[slot]);  // A0[9] A1[9] A2[9] tc[3] tu[3]
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Tm[slot][c] = fmaf(sn, hf[18 + c], fmaf(cs, hf[9 + c], hf[c]));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Tm[slot][9 + r] = fmaf(tq, hf[30 + r], hf[27 + r]);
+  }
+  RMP2_KSTAMP();  // K: local transforms done
+  // ---- stage 2 ----
+#pragma unroll
+  for (int l = 0; l < 5; ++l) {
+    if (l < hdr.n_levels) {  // wave-uniform
+      float* const src = (l & 1) ? Tb1 : Tb0;
+#pragma unroll
+      for (int slot = 0; slot < SLOTS; ++slot) {
+        if (on[slot]) {
+          float4* dst = reinterpret_cast<float4*>(src + kk[slot] * 12);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
+        }
+      }
+      hex_sync();
+      float4 pa[SLOTS][3];
+#pragma unroll
+      for (int slot = 0; slot < SLOTS; ++slot) {
+        const int j = jmp[slot][l] >= 0 ? jmp[slot][l] : kk[slot];
+        const float4* p4 = reinterpret_cast<const float4*>(src + j * 12);
+        pa[slot][0] = p4[0], pa[slot][1] = p4[1], pa[slot][2] = p4[2];
+      }
+      hex_sync();
+#pragma unroll
+      for (int slot = 0; slot < SLOTS; ++slot) {
+        if (jmp[slot][l] >= 0 && on[slot]) {
+          const float* Pr = reinterpret_cast<const float*>(pa[slot]);
+          float Tn[12];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              Tn[3 * r + c] = Pr[3 * r] * Tm[slot][c] + Pr[3 * r + 1] * Tm[slot][3 + c] + Pr[3 * r + 2] * Tm[slot][6 + c];
+            Tn[9 + r] = Pr[3 * r] * Tm[slot][9] + Pr[3 * r + 1] * Tm[slot][10] + Pr[3 * r + 2] * Tm[slot][11] + Pr[9 + r];
+          }
+#pragma unroll
+          for (int c = 0; c < 12; ++c) Tm[slot][c] = Tn[c];
+        }
+      }
+    }
+  }
+  float* const TW = (hdr.n_levels & 1) ? Tb1 : Tb0;
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    if (on[slot]) {
+      float4* dst = reinterpret_cast<float4*>(TW + kk[slot] * 12);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
+    }
+  }
+  RMP2_KSTAMP();  // K: world transforms done
+  // ---- stage 3 ----
+  float pk[SLOTS][3], zk[SLOTS][3], X[SLOTS][6];
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      zk[slot][r] = Tm[slot][3 * r] * ax[slot][0] + Tm[slot][3 * r + 1] * ax[slot][1] + Tm[slot][3 * r + 2] * ax[slot][2];
+      pk[slot][r] = Tm[slot][9 + r];
+    }
+    if ((revk[slot] || prik[slot]) && qi[slot] >= 0) {  // per-dof table for the Jacobian columns
+      float4* d4 = reinterpret_cast<float4*>(DOF + qi[slot] * 8);
+      d4[0] = make_float4(zk[slot][0], zk[slot][1], zk[slot][2], 0.f);
+      d4[1] = make_float4(pk[slot][0], pk[slot][1], pk[slot][2], 0.f);
+    }
+    float zxo[3];
+    cross3(zk[slot], pk[slot], zxo);
+    const float qdm = qdk[slot];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      X[slot][r] = revk[slot] ? qdm * zk[slot][r] : 0.f;
+      X[slot][3 + r] = revk[slot] ? -qdm * zxo[r] : (prik[slot] ? qdm * zk[slot][r] : 0.f);
+    }
+  }
+  // inclusive sum of x over op k and its ancestors: every lane adds up the published terms of all ops, weighted
+  // by the 0/1 membership bit of its ancestor mask
+  auto ancestor_sum = [&](float (&x)[SLOTS][6]) {
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+      if (on[slot]) {
+        SC[2 * kk[slot]] = make_float4(x[slot][0], x[slot][1], x[slot][2], x[slot][3]);
+        SC[2 * kk[slot] + 1] = make_float4(x[slot][4], x[slot][5], 0.f, 0.f);
+      }
+    }
+    hex_sync();
+    float acc[SLOTS][6];
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[slot][c] = 0.f;
+    for (int j0 = 0; j0 < n_ops; j0 += 8) {
+      float4 u0[8], u1[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int j = min(j0 + jj, n_ops - 1);  // clamped: the repeated op carries weight 0
+        u0[jj] = SC[2 * j];
+        u1[jj] = SC[2 * j + 1];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+          const float f = (j0 + jj < n_ops && ((ancm[slot] >> (j0 + jj)) & 1u)) ? 1.f : 0.f;
+          acc[slot][0] = fmaf(f, u0[jj].x, acc[slot][0]);
+          acc[slot][1] = fmaf(f, u0[jj].y, acc[slot][1]);
+          acc[slot][2] = fmaf(f, u0[jj].z, acc[slot][2]);
+          acc[slot][3] = fmaf(f, u0[jj].w, acc[slot][3]);
+          acc[slot][4] = fmaf(f, u1[jj].x, acc[slot][4]);
+          acc[slot][5] = fmaf(f, u1[jj].y, acc[slot][5]);
+        }
+      }
+    }
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x[slot][c] = acc[slot][c];
+    hex_sync();
+  };
+  RMP2_KSTAMP();  // K: per-op terms formed
+  ancestor_sum(X);  // X = (W_k, B_k)
+  RMP2_KSTAMP();  // K: first sum done
+  float vk[SLOTS][3], Y[SLOTS][6];
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]};
+    float t1[3], zd[3], t2[3], t3[3];
+    cross3(Wk, pk[slot], t1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) vk[slot][r] = t1[r] + X[slot][3 + r];
+    cross3(Wk, zk[slot], zd);
+    cross3(zd, pk[slot], t2);
+    cross3(zk[slot], vk[slot], t3);
+    const float qdm = qdk[slot];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Y[slot][r] = revk[slot] ? qdm * zd[r] : 0.f;
+      Y[slot][3 + r] = revk[slot] ? -qdm * (t2[r] + t3[r]) : (prik[slot] ? qdm * zd[r] : 0.f);
+    }
+  }
+  RMP2_KSTAMP();  // K: second terms formed
+  ancestor_sum(Y);  // Y = (AL_k, C_k)
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) {
+    if (on[slot]) {
+      const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]}, ALk[3] = {Y[slot][0], Y[slot][1], Y[slot][2]};
+      float t1[3], t2[3], ak[3];
+      cross3(ALk, pk[slot], t1);
+      cross3(Wk, vk[slot], t2);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) ak[r] = t1[r] + t2[r] + Y[slot][3 + r];
+      VA[2 * kk[slot]] = make_float4(vk[slot][0], vk[slot][1], vk[slot][2], ak[0]);
+      VA[2 * kk[slot] + 1] = make_float4(ak[1], ak[2], 0.f, 0.f);
+    }
+  }
+  hex_sync();
+  return TW;
 }
 
 template <int N, bool CAP>
 __global__ void __launch_bounds__(kWave, 1)
-rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
+rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, const float* __restrict__ q,
                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                      OutArgs out, int R) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef RMP2_STAMPS
   unsigned long long st_[8];
   int st_n = 0;
+#endif
+#if defined(RMP2_STAMPS) && defined(RMP2_STAMPS_KIN)
+#define RMP2_KARGS , st_, &st_n
+#else
+#define RMP2_KARGS
 #endif
   RMP2_STAMP();
   const int lane = threadIdx.x;
@@ -115,25 +382,59 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
   float* const sph_lds_base = VAb + kHexRobots * n_ops * 8;
   float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
+  // the staged program: same layout as the host's blob
   DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
-  DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
+  HexOp* const s_hops = reinterpret_cast<HexOp*>(s_ops + n_ops);
+  DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_hops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
   int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
   int32_t* const s_lo = s_id + RMP2_MAX_LEAVES;
   int32_t* const s_jump = s_lo + kMaxOps;
-  int32_t* const s_dof_op = s_jump + 5 * kMaxOps;
-  uint32_t* const s_dof_anc = reinterpret_cast<uint32_t*>(s_dof_op + RMP2_MAX_DOF);
-  float* const s_goal = reinterpret_cast<float*>(s_dof_anc + RMP2_MAX_DOF);
+  uint32_t* const s_op_anc = reinterpret_cast<uint32_t*>(s_jump + 5 * kMaxOps);
+  float* const s_goal = reinterpret_cast<float*>(stage_base) + 4 * blob16;
 
   // ---- prologue: one burst of loads brings the state tile, the obstacle table and the program on chip ----
   {
     const int tile = n_live * n_dof;
     const float* gq = q + (size_t)r0 * n_dof;
     const float* gqd = qd + (size_t)r0 * n_dof;
-    if (n_dof == N) {  // rows are contiguous in HBM and in LDS: no index arithmetic
-      for (int i = lane; i < tile; i += kWave) {
-        lds[HexLds<N>::kQ + i] = gq[i];
-        lds[HexLds<N>::kQd + i] = gqd[i];
+    // state tile: with n_dof == N rows are contiguous in HBM and in LDS and the tile (<= 4 N <= 64 floats) is one
+    // load per lane, issued together with the loads below; other cases take the generic path after them
+    const bool fastq = n_dof == N && tile <= kWave;
+    float qa = 0.f, qb = 0.f;
+    if (fastq && lane < tile) {
+      qa = gq[lane];
+      qb = gqd[lane];
+    }
+    // the program blob, the obstacle table and the goals: loads first, LDS writes after
+    const int nf4 = (CAP ? 2 : 1) * n_sph_lds;
+    const int ng = goal ? n_live * hdr.goal_floats : 0;  // goal_floats <= 16 (checked on the host): ng <= 64
+    uint4 bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = u * kWave + lane;
+      if (i < blob16) bv[u] = blob[i];
+    }
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < nf4) sv = reinterpret_cast<const float4*>(obs.spheres)[lane];
+    float gv = 0.f;
+    int g_rr = 0, g_jj = 0;
+    if (lane < ng) {
+      g_rr = lane / hdr.goal_floats;
+      g_jj = lane - g_rr * hdr.goal_floats;
+      gv = goal[(size_t)(r0 + g_rr) * goal_stride + g_jj];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = u * kWave + lane;
+      if (i < blob16) reinterpret_cast<uint4*>(stage_base)[i] = bv[u];
+    }
+    if (lane < nf4) reinterpret_cast<float4*>(sph_lds_base)[lane] = sv;
+    if (lane < ng) s_goal[g_rr * 16 + g_jj] = gv;
+    if (fastq) {
+      if (lane < tile) {
+        lds[HexLds<N>::kQ + lane] = qa;
+        lds[HexLds<N>::kQd + lane] = qb;
       }
     } else {
       for (int i = lane; i < tile; i += kWave) {
@@ -141,45 +442,21 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
         lds[HexLds<N>::kQ + rr * N + jj] = gq[i];
         lds[HexLds<N>::kQd + rr * N + jj] = gqd[i];
       }
-    }
-    if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
-      const int pad = N - n_dof;
-      for (int i = lane; i < kHexRobots * pad; i += kWave) {
-        const int rr = i / pad, jj = n_dof + (i - rr * pad);
-        lds[HexLds<N>::kQ + rr * N + jj] = 0.f;
-        lds[HexLds<N>::kQd + rr * N + jj] = 0.f;
-      }
-    }
-    {
-      const int nf = (CAP ? 8 : 4) * n_sph_lds;
-      for (int i = lane; i < nf; i += kWave) sph_lds_base[i] = obs.spheres[i];
-    }
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
-      uint4* dst = reinterpret_cast<uint4*>(s_ops);
-      for (int i = lane; i < n_ops * (int)(sizeof(DevOp) / 16); i += kWave) dst[i] = src[i];
-      src = reinterpret_cast<const uint4*>(prog->leaves);
-      dst = reinterpret_cast<uint4*>(s_leaves);
-      for (int i = lane; i < hdr.n_leaves * (int)(sizeof(DevLeaf) / 16); i += kWave) dst[i] = src[i];
-      if (lane < RMP2_MAX_LEAVES) {
-        s_fk[lane] = prog->fk_leaves[lane];
-        s_id[lane] = prog->id_leaves[lane];
-      }
-      if (lane < kMaxOps) s_lo[lane] = prog->leaf_ops[lane];
-      const int32_t* jsrc = &prog->hex.jump[0][0];
-      for (int i = lane; i < 5 * kMaxOps; i += kWave) s_jump[i] = jsrc[i];
-      if (lane < RMP2_MAX_DOF) {
-        s_dof_op[lane] = prog->hex.dof_op[lane];
-        s_dof_anc[lane] = prog->hex.dof_anc[lane];
-      }
-      if (goal) {
-        const int gf = hdr.goal_floats;  // <= 16 (checked on the host)
-        for (int i = lane; i < n_live * gf; i += kWave) {
-          const int rr = i / gf, jj = i - rr * gf;
-          s_goal[rr * 16 + jj] = goal[(size_t)(r0 + rr) * goal_stride + jj];
+      if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
+        const int pad = N - n_dof;
+        for (int i = lane; i < kHexRobots * pad; i += kWave) {
+          const int rr = i / pad, jj = n_dof + (i - rr * pad);
+          lds[HexLds<N>::kQ + rr * N + jj] = 0.f;
+          lds[HexLds<N>::kQd + rr * N + jj] = 0.f;
         }
       }
     }
+    // leftovers of big programs / big obstacle tables
+    if (blob16 > 4 * kWave)
+      stage_copy(reinterpret_cast<uint4*>(stage_base) + 4 * kWave, blob + 4 * kWave, blob16 - 4 * kWave, lane);
+    if (nf4 > kWave)
+      stage_copy(reinterpret_cast<float4*>(sph_lds_base) + kWave, reinterpret_cast<const float4*>(obs.spheres) + kWave,
+                 nf4 - kWave, lane);
     hex_sync();
   }
   RMP2_STAMP();  // 1: prologue done
@@ -193,207 +470,12 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
   float4* const XCH = reinterpret_cast<float4*>(&lds[HexLds<N>::kXch + g * kHex * 4]);
   uint32_t status = 0u;
 
-  // ---- phase 1: local transforms T_constant @ T_variable(q) of all frames, one frame per lane -----------
-  // (kinematics.py:222-240); frames k = s and s + 16
-  float Tm[2][12];  // [R row-major (9) | t (3)]
-#pragma unroll
-  for (int slot = 0; slot < 2; ++slot) {
-    const int k = s + kHex * slot;
-#pragma unroll
-    for (int c = 0; c < 12; ++c) Tm[slot][c] = 0.f;
-    if (k < n_ops) {
-      const DevOp& opg = s_ops[k];
-      const int jt = opg.jtype, qi = opg.qidx;
-      const float qv = qi >= 0 ? my_q[qi] : 0.f;
-      const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
-      float sn = 0.f, cs = 1.f;
-      if (jt == RMP2_JOINT_REVOLUTE) {
-        if (fabsf(qv) <= 8192.0f)
-          sincos1(qv, sn, cs);
-        else
-          sincosf(qv, &sn, &cs);
-      }
-      const float omc = 1.0f - cs;
-      const bool rev = jt == RMP2_JOINT_REVOLUTE;
-      // Rodrigues: cos*I + sin*[u]x + (1-cos)*u u^T (kinematics.py:103-121); identity for non-revolute joints
-      const float ut[9] = {0.f, -ax[2], ax[1], ax[2], 0.f, -ax[0], -ax[1], ax[0], 0.f};
-      float Rv[9], Tc[12];
-#pragma unroll
-      for (int c = 0; c < 12; ++c) Tc[c] = opg.Tc[c];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float e = (r == c) ? 1.f : 0.f;
-          Rv[3 * r + c] = rev ? cs * e + sn * ut[3 * r + c] + omc * (ax[r] * ax[c]) : e;
-        }
-      const float tq = (jt == RMP2_JOINT_PRISMATIC) ? qv : 0.f;
-      const float tv[3] = {tq * ax[0], tq * ax[1], tq * ax[2]};
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          Tm[slot][3 * r + c] = Tc[4 * r + 0] * Rv[c] + Tc[4 * r + 1] * Rv[3 + c] + Tc[4 * r + 2] * Rv[6 + c];
-        Tm[slot][9 + r] = Tc[4 * r + 0] * tv[0] + Tc[4 * r + 1] * tv[1] + Tc[4 * r + 2] * tv[2] + Tc[4 * r + 3];
-      }
-      float4* dst = reinterpret_cast<float4*>(T0 + (g * n_ops + k) * 12);
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
-    }
-  }
-
-  // ---- phase 2: world transforms by pointer jumping (ordered product of kinematics.py:243-246) -----------
-  // after round l, T[k] is the product of the last min(2^(l+1), depth) local transforms ending at k
-  for (int l = 0; l < hdr.n_levels; ++l) {
-    const float* src = (l & 1) ? T1 : T0;
-    float* dstb = (l & 1) ? T0 : T1;
-    hex_sync();
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int k = s + kHex * slot;
-      if (k < n_ops) {
-        const int j = s_jump[l * kMaxOps + k];
-        if (j >= 0) {
-          const float4* p4 = reinterpret_cast<const float4*>(src + (g * n_ops + j) * 12);
-          const float4 a0 = p4[0], a1 = p4[1], a2 = p4[2];
-          const float Pr[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
-          float Tn[12];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              Tn[3 * r + c] = Pr[3 * r] * Tm[slot][c] + Pr[3 * r + 1] * Tm[slot][3 + c] + Pr[3 * r + 2] * Tm[slot][6 + c];
-            Tn[9 + r] = Pr[3 * r] * Tm[slot][9] + Pr[3 * r + 1] * Tm[slot][10] + Pr[3 * r + 2] * Tm[slot][11] + Pr[9 + r];
-          }
-#pragma unroll
-          for (int c = 0; c < 12; ++c) Tm[slot][c] = Tn[c];
-        }
-        float4* dst = reinterpret_cast<float4*>(dstb + (g * n_ops + k) * 12);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          dst[c] = make_float4(Tm[slot][4 * c], Tm[slot][4 * c + 1], Tm[slot][4 * c + 2], Tm[slot][4 * c + 3]);
-      }
-    }
-  }
-  hex_sync();
-  const float* const TW = ((hdr.n_levels & 1) ? T1 : T0) + g * n_ops * 12;  // this robot's world transforms
-
-  // ---- phase 3: velocity and bias acceleration of EVERY frame origin from two tree prefix sums -------------
-  // With w_m = qd_m z_m, b_m = -qd_m z_m x o_m (revolute) or w_m = 0, b_m = qd_m z_m (prismatic) and W_k, B_k
-  // their sums over the joints at or above frame k:
-  //     v_k = W_k x p_k + B_k                                     ( = J_k qd,     kinematics.py:265 )
-  // and with zd_m = W_m x z_m, al_m = qd_m zd_m, c_m = -qd_m (zd_m x o_m + z_m x v_m) (revolute) or
-  // al_m = 0, c_m = qd_m zd_m (prismatic) and AL_k, C_k their sums:
-  //     a_k = AL_k x p_k + W_k x v_k + C_k                        ( = Jdot_k qd,  kinematics.py:267 )
-  // Each prefix sum is n_levels rounds of pointer jumping over the same ancestor table as the transforms.
-  {
-    float* const SC = SCb + g * n_ops * 8;
-    float* const VA = VAb + g * n_ops * 8;
-    float pk[2][3], zk[2][3], qdk[2], X[2][6];
-    bool revk[2], prik[2];
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int k = s + kHex * slot;
-      revk[slot] = prik[slot] = false;
-      qdk[slot] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pk[slot][c] = zk[slot][c] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) X[slot][c] = 0.f;
-      if (k < n_ops) {
-        const DevOp& opg = s_ops[k];
-        const int jt = opg.jtype, qi = opg.qidx;
-        revk[slot] = jt == RMP2_JOINT_REVOLUTE && qi >= 0;
-        prik[slot] = jt == RMP2_JOINT_PRISMATIC && qi >= 0;
-        qdk[slot] = qi >= 0 ? my_qd[qi] : 0.f;
-        const float ax[3] = {opg.axis[0], opg.axis[1], opg.axis[2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          zk[slot][r] = Tm[slot][3 * r] * ax[0] + Tm[slot][3 * r + 1] * ax[1] + Tm[slot][3 * r + 2] * ax[2];
-          pk[slot][r] = Tm[slot][9 + r];
-        }
-        if (qi >= 0 && jt != RMP2_JOINT_FIXED) {  // per-dof table for the Jacobian columns
-          float4* d4 = reinterpret_cast<float4*>(DOF + qi * 8);
-          d4[0] = make_float4(zk[slot][0], zk[slot][1], zk[slot][2], 0.f);
-          d4[1] = make_float4(pk[slot][0], pk[slot][1], pk[slot][2], 0.f);
-        }
-        float zxo[3];
-        cross3(zk[slot], pk[slot], zxo);
-        const float qdm = qdk[slot];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          X[slot][r] = revk[slot] ? qdm * zk[slot][r] : 0.f;
-          X[slot][3 + r] = revk[slot] ? -qdm * zxo[r] : (prik[slot] ? qdm * zk[slot][r] : 0.f);
-        }
-      }
-    }
-    // inclusive prefix sum of X over the ancestors of every op
-    auto tree_prefix = [&](float (&x)[2][6]) {
-      for (int l = 0; l < hdr.n_levels; ++l) {
-#pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {
-          const int k = s + kHex * slot;
-          if (k < n_ops) {
-            float4* d4 = reinterpret_cast<float4*>(SC + k * 8);
-            d4[0] = make_float4(x[slot][0], x[slot][1], x[slot][2], x[slot][3]);
-            d4[1] = make_float4(x[slot][4], x[slot][5], 0.f, 0.f);
-          }
-        }
-        hex_sync();
-#pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {
-          const int k = s + kHex * slot;
-          if (k < n_ops) {
-            const int j = s_jump[l * kMaxOps + k];
-            if (j >= 0) {
-              const float4* d4 = reinterpret_cast<const float4*>(SC + j * 8);
-              const float4 u0 = d4[0], u1 = d4[1];
-              x[slot][0] += u0.x, x[slot][1] += u0.y, x[slot][2] += u0.z;
-              x[slot][3] += u0.w, x[slot][4] += u1.x, x[slot][5] += u1.y;
-            }
-          }
-        }
-        hex_sync();
-      }
-    };
-    tree_prefix(X);  // X = (W_k, B_k)
-    float vk[2][3], Y[2][6];
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]};
-      float t1[3], zd[3], t2[3], t3[3];
-      cross3(Wk, pk[slot], t1);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) vk[slot][r] = t1[r] + X[slot][3 + r];
-      cross3(Wk, zk[slot], zd);
-      cross3(zd, pk[slot], t2);
-      cross3(zk[slot], vk[slot], t3);
-      const float qdm = qdk[slot];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        Y[slot][r] = revk[slot] ? qdm * zd[r] : 0.f;
-        Y[slot][3 + r] = revk[slot] ? -qdm * (t2[r] + t3[r]) : (prik[slot] ? qdm * zd[r] : 0.f);
-      }
-    }
-    tree_prefix(Y);  // Y = (AL_k, C_k)
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int k = s + kHex * slot;
-      if (k < n_ops) {
-        const float Wk[3] = {X[slot][0], X[slot][1], X[slot][2]}, ALk[3] = {Y[slot][0], Y[slot][1], Y[slot][2]};
-        float t1[3], t2[3], ak[3];
-        cross3(ALk, pk[slot], t1);
-        cross3(Wk, vk[slot], t2);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) ak[r] = t1[r] + t2[r] + Y[slot][3 + r];
-        float4* d4 = reinterpret_cast<float4*>(VA + k * 8);
-        d4[0] = make_float4(vk[slot][0], vk[slot][1], vk[slot][2], ak[0]);
-        d4[1] = make_float4(ak[1], ak[2], 0.f, 0.f);
-      }
-    }
-    hex_sync();
-  }
+  // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
+  const float* TW;
+  if (n_ops <= kHex)
+    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ops, s_hops, s_jump, s_op_anc RMP2_KARGS);
+  else
+    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ops, s_hops, s_jump, s_op_anc RMP2_KARGS);
   RMP2_STAMP();  // 2: kinematics done
 
   // ---- the fp64 system, one row per lane: A[j] = M[s][j], fv = f[s] -------------------------------------
@@ -501,7 +583,7 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
     }
     hex_sync();  // COL is rewritten for the next frame
   }
-  RMP2_STAMP();  // 3: FK leaves done
+  RMP2_LSTAMP();  // 3: FK leaves done
 
   // ---- identity-task-map leaves: x = q, xd = qd, J = I (taskmap.py:13-20); lane s owns row s -------------
   {
@@ -614,7 +696,7 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
       }
     }
   }
-  RMP2_STAMP();  // 4: identity leaves done
+  RMP2_LSTAMP();  // 4: identity leaves done
 
   // optional outputs: the combined metric / force before the resolve
   if (live && s < n_dof) {
@@ -679,7 +761,7 @@ rmp2_step_hex_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const flo
     flagged = flagged || hex_any(!finite, g);
     if (s < n_dof) my_out[s] = (float)x;
   }
-  RMP2_STAMP();  // 5: resolve done
+  RMP2_LSTAMP();  // 5: resolve done
 
   if (__any(flagged && live)) {
     hex_sync();  // SYS rows of all lanes are in LDS

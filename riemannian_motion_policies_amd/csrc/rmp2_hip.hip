@@ -731,6 +731,8 @@ struct rmp2_handle {
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
+  void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
+  int hex_blob16 = 0;          // its size in 16-byte units
   std::vector<int> distance_leaves;
   DevProgram* d_prog = nullptr;
   int32_t* d_pair_begin = nullptr;
@@ -764,7 +766,8 @@ int fail(rmp2_handle* h, int code, const std::string& msg) {
 // leaf are dropped (they cannot influence qdd), and FIXED frames without a leaf are folded into their
 // children's constant transform (T_c' = T_fixed @ T_c, formed in fp64; exact up to one fp32 rounding
 // of the folded constant).  prune = false: every frame is visited (forward-kinematics entry points).
-int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string& err, bool prune) {
+int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string& err, bool prune,
+                    std::vector<HexOp>* hops = nullptr) {
   const rmp2_robot& rb = d.robot;
   const int F0 = rb.n_frames, n = rb.n_dof;
   if (F0 < 0 || F0 > RMP2_MAX_FRAMES) return err = "n_frames out of range", RMP2_ERR_INVALID_ARGUMENT;
@@ -891,15 +894,31 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
         const int j = P.hex.jump[l - 1][k];
         P.hex.jump[l][k] = j < 0 ? -1 : P.hex.jump[l - 1][j];
       }
-    for (int j = 0; j < RMP2_MAX_DOF; ++j) {
-      P.hex.dof_op[j] = -1;
-      P.hex.dof_anc[j] = 0u;
-    }
-    for (int k = 0; k < F; ++k) {
-      const int qi = P.ops[k].qidx;
-      if (qi < 0) continue;
-      P.hex.dof_op[qi] = k;
-      P.hex.dof_anc[qi] = P.ops[k].anc_mask & ~(1u << qi);
+    for (int k = 0; k < kMaxOps; ++k) P.hex.op_anc[k] = 0u;
+    for (int k = 0; k < F; ++k) P.hex.op_anc[k] = (1u << k) | (parent_op[k] >= 0 ? P.hex.op_anc[parent_op[k]] : 0u);
+    if (hops) {
+      hops->assign(F, HexOp{});
+      for (int k = 0; k < F; ++k) {
+        const int w = order[k], f = wf[w].orig;
+        const double* Tc = wf[w].Tc;
+        const double u[3] = {rb.axis[f][0], rb.axis[f][1], rb.axis[f][2]};
+        const bool rev = rb.joint_type[f] == RMP2_JOINT_REVOLUTE, pri = rb.joint_type[f] == RMP2_JOINT_PRISMATIC;
+        const double ux[9] = {0.0, -u[2], u[1], u[2], 0.0, -u[0], -u[1], u[0], 0.0};
+        HexOp& ho = (*hops)[k];
+        for (int r = 0; r < 3; ++r) {
+          const double Rc[3] = {Tc[4 * r], Tc[4 * r + 1], Tc[4 * r + 2]};
+          const double Ru = Rc[0] * u[0] + Rc[1] * u[1] + Rc[2] * u[2];
+          for (int c = 0; c < 3; ++c) {
+            const double a0 = Ru * u[c];                                              // (Rc u u^T)_rc
+            const double a2 = Rc[0] * ux[c] + Rc[1] * ux[3 + c] + Rc[2] * ux[6 + c];  // (Rc [u]x)_rc
+            ho.A0[3 * r + c] = (float)(rev ? a0 : Rc[c]);
+            ho.A1[3 * r + c] = (float)(rev ? Rc[c] - a0 : 0.0);
+            ho.A2[3 * r + c] = (float)(rev ? a2 : 0.0);
+          }
+          ho.tc[r] = (float)Tc[4 * r + 3];
+          ho.tu[r] = (float)(pri ? Ru : 0.0);
+        }
+      }
     }
   }
   n_slots = (int)free_at.size();
@@ -1031,15 +1050,16 @@ void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const flo
   const int blocks = (R + kHexRobots - 1) / kHexRobots;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t bytes = hex_lds_bytes<N>(h->n_ops_step, h->n_leaf_ops, h->n_leaves, (o.capsule ? 8 : 4) * n_sph_lds);
+  const size_t bytes = hex_lds_bytes<N>(h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels};
+  const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal, gs,
-                       o, out, R);
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true>), dim3(blocks), dim3(kWave), bytes, s, blob, h->hex_blob16, hdr, q, qd,
+                       goal, gs, o, out, R);
   else
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal,
-                       gs, o, out, R);
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false>), dim3(blocks), dim3(kWave), bytes, s, blob, h->hex_blob16, hdr, q, qd,
+                       goal, gs, o, out, R);
 }
 
 template <int N>
@@ -1100,7 +1120,8 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   DevProgram P, Pfull;
   int n_slots = 0, n_slots_full = 0;
   std::string err;
-  int rc = compile_program(*desc, P, n_slots, err, /*prune=*/true);
+  std::vector<HexOp> hops;
+  int rc = compile_program(*desc, P, n_slots, err, /*prune=*/true, &hops);
   if (rc == RMP2_OK) rc = compile_program(*desc, Pfull, n_slots_full, err, /*prune=*/false);
   if (rc != RMP2_OK) return fail(nullptr, rc, err);
   if (desc->robot.n_dof > 9)
@@ -1148,6 +1169,25 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (e == hipSuccess) e = hipMemcpy(h->d_prog, &P, sizeof(DevProgram), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&h->d_prog_full, sizeof(DevProgram));
   if (e == hipSuccess) e = hipMemcpy(h->d_prog_full, &Pfull, sizeof(DevProgram), hipMemcpyHostToDevice);
+  {
+    // hex kernel: one contiguous blob = [ops | HexOps | leaves | fk list | id list | leaf ops | jump | op_anc]
+    std::vector<unsigned char> blob;
+    auto put = [&blob](const void* p, size_t n) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      blob.insert(blob.end(), b, b + n);
+    };
+    put(P.ops, sizeof(DevOp) * P.n_ops);
+    put(hops.data(), sizeof(HexOp) * hops.size());
+    put(P.leaves, sizeof(DevLeaf) * P.n_leaves);
+    put(P.fk_leaves, sizeof(P.fk_leaves));
+    put(P.id_leaves, sizeof(P.id_leaves));
+    put(P.leaf_ops, sizeof(P.leaf_ops));
+    put(P.hex.jump, sizeof(P.hex.jump));
+    put(P.hex.op_anc, sizeof(P.hex.op_anc));
+    h->hex_blob16 = (int)(blob.size() / 16);
+    if (e == hipSuccess) e = hipMalloc(&h->d_hex_blob, blob.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_hex_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc(&h->d_pair_begin, sizeof(h->h_pair_begin));
   if (e == hipSuccess) e = hipMemset(h->d_pair_begin, 0, sizeof(h->h_pair_begin));
   if (e != hipSuccess) {
@@ -1164,6 +1204,7 @@ int rmp2_destroy(rmp2_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->d_prog) (void)hipFree(h->d_prog);
   if (h->d_prog_full) (void)hipFree(h->d_prog_full);
+  if (h->d_hex_blob) (void)hipFree(h->d_hex_blob);
   if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   delete h;
