@@ -90,6 +90,15 @@ struct HexOp {
   float A0[9], A1[9], A2[9], tc[3], tu[3], pad_[3];  // 144 bytes
 };
 static_assert(sizeof(HexOp) % 16 == 0, "staged with dwordx4 copies");
+// the fields of DevOp the hex kernel reads, packed (the staged program is fetched by every wave of the grid at the
+// same time: every byte of it is L2 hot-spot traffic)
+struct HexCtl {
+  int32_t jtype, qidx;
+  uint32_t anc_mask;
+  int32_t leaf_begin, leaf_count;
+  float axis[3];
+};
+static_assert(sizeof(HexCtl) == 32, "two dwordx4");
 
 struct ObsArgs {
   int32_t mode, n_spheres, n_pairs;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, in
 template <int N, int SLOTS>
 __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s, int g, const float* my_q,
                                                        const float* my_qd, float* T0, float* T1, float* SCb, float* VAb,
-                                                       float* DOF, const DevOp* s_ops, const HexOp* s_hops,
+                                                       float* DOF, const HexCtl* s_ctl, const HexOp* s_hops,
                                                        const int32_t* s_jump, const uint32_t* s_op_anc,
                                                        unsigned long long* stp = nullptr, int* stn = nullptr) {
   const int n_ops = hdr.n_ops;
@@ -148,19 +148,19 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
   float4 hop[SLOTS][9];
 #pragma unroll
   for (int slot = 0; slot < SLOTS; ++slot) {
-    const int4* c4 = reinterpret_cast<const int4*>(&s_ops[kk[slot]]);
-    const int4 c0 = c4[0], c1 = c4[1];
-    const float4 c2 = reinterpret_cast<const float4*>(c4)[2];
-    const int jt = c0.w;
-    qi[slot] = c1.x;
-    ax[slot][0] = c2.x, ax[slot][1] = c2.y, ax[slot][2] = c2.z;
+    const int4* c4 = reinterpret_cast<const int4*>(&s_ctl[kk[slot]]);
+    const int4 c0 = c4[0];                                            // jtype, qidx, anc_mask, leaf_begin
+    const float4 c1 = reinterpret_cast<const float4*>(c4)[1];         // (leaf_count), axis
+    const int jt = c0.x;
+    qi[slot] = c0.y;
+    ax[slot][0] = c1.y, ax[slot][1] = c1.z, ax[slot][2] = c1.w;
     revk[slot] = on[slot] && jt == RMP2_JOINT_REVOLUTE;
     prik[slot] = on[slot] && jt == RMP2_JOINT_PRISMATIC;
     const float4* h4 = reinterpret_cast<const float4*>(&s_hops[kk[slot]]);
 #pragma unroll
     for (int c = 0; c < 9; ++c) hop[slot][c] = h4[c];
 #pragma unroll
-    for (int l = 0; l < 5; ++l) jmp[slot][l] = s_jump[l * kMaxOps + kk[slot]];
+    for (int l = 0; l < 5; ++l) jmp[slot][l] = l < hdr.n_levels ? s_jump[l * n_ops + kk[slot]] : -1;
     ancm[slot] = on[slot] ? s_op_anc[kk[slot]] : 0u;
   }
 #pragma unroll
@@ -383,14 +383,14 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   float* const sph_lds_base = VAb + kHexRobots * n_ops * 8;
   float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
   // the staged program: same layout as the host's blob
-  DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
-  HexOp* const s_hops = reinterpret_cast<HexOp*>(s_ops + n_ops);
+  HexCtl* const s_ctl = reinterpret_cast<HexCtl*>(stage_base);
+  HexOp* const s_hops = reinterpret_cast<HexOp*>(s_ctl + n_ops);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_hops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
-  int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
-  int32_t* const s_lo = s_id + RMP2_MAX_LEAVES;
-  int32_t* const s_jump = s_lo + kMaxOps;
-  uint32_t* const s_op_anc = reinterpret_cast<uint32_t*>(s_jump + 5 * kMaxOps);
+  int32_t* const s_id = s_fk + hdr.n_fk;
+  int32_t* const s_lo = s_id + n_id;
+  int32_t* const s_jump = s_lo + n_lo;
+  uint32_t* const s_op_anc = reinterpret_cast<uint32_t*>(s_jump + hdr.n_levels * n_ops);
   float* const s_goal = reinterpret_cast<float*>(stage_base) + 4 * blob16;
 
   // ---- prologue: one burst of loads brings the state tile, the obstacle table and the program on chip ----
@@ -473,9 +473,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
-    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ops, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
   else
-    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ops, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
   RMP2_STAMP();  // 2: kinematics done
 
   // ---- the fp64 system, one row per lane: A[j] = M[s][j], fv = f[s] -------------------------------------
@@ -488,10 +488,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- leaves on FK task maps, frame by frame -----------------------------------------------------------
   for (int t = 0; t < n_lo; ++t) {
     const int k = uni<true>(s_lo[t]);
-    OpCtl op = *reinterpret_cast<const OpCtl*>(&s_ops[k]);
-    op.anc_mask = (uint32_t)uni<true>((int)op.anc_mask);
-    op.leaf_begin = uni<true>(op.leaf_begin);
-    op.leaf_count = uni<true>(op.leaf_count);
+    struct {
+      uint32_t anc_mask;
+      int leaf_begin, leaf_count;
+    } op = {(uint32_t)uni<true>((int)s_ctl[k].anc_mask), uni<true>(s_ctl[k].leaf_begin), uni<true>(s_ctl[k].leaf_count)};
     const float4 tp = reinterpret_cast<const float4*>(TW + k * 12)[2];
     const float4* va4 = reinterpret_cast<const float4*>(VAb + (g * n_ops + k) * 8);
     const float4 f0 = va4[0], f1 = va4[1];

@@ -731,6 +731,7 @@ struct rmp2_handle {
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
+  int n_fk_leaves = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
   int hex_blob16 = 0;          // its size in 16-byte units
   std::vector<int> distance_leaves;
@@ -1028,7 +1029,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels};
+                    h->hex_levels, h->n_fk_leaves};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
@@ -1052,7 +1053,7 @@ void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const flo
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
   const size_t bytes = hex_lds_bytes<N>(h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels};
+                    h->hex_levels, h->n_fk_leaves};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
     hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true>), dim3(blocks), dim3(kWave), bytes, s, blob, h->hex_blob16, hdr, q, qd,
@@ -1152,6 +1153,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   }
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
+  h->n_fk_leaves = P.n_fk_leaves;
   h->rev_mask = P.rev_mask;
   {
     const char* kenv = std::getenv("RMP2_KERNEL");
@@ -1176,14 +1178,20 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
       const unsigned char* b = static_cast<const unsigned char*>(p);
       blob.insert(blob.end(), b, b + n);
     };
-    put(P.ops, sizeof(DevOp) * P.n_ops);
+    for (int k = 0; k < P.n_ops; ++k) {
+      const DevOp& o = P.ops[k];
+      const HexCtl c{o.jtype, o.qidx, o.anc_mask, o.leaf_begin, o.leaf_count, {o.axis[0], o.axis[1], o.axis[2]}};
+      put(&c, sizeof(c));
+    }
     put(hops.data(), sizeof(HexOp) * hops.size());
     put(P.leaves, sizeof(DevLeaf) * P.n_leaves);
-    put(P.fk_leaves, sizeof(P.fk_leaves));
-    put(P.id_leaves, sizeof(P.id_leaves));
-    put(P.leaf_ops, sizeof(P.leaf_ops));
-    put(P.hex.jump, sizeof(P.hex.jump));
-    put(P.hex.op_anc, sizeof(P.hex.op_anc));
+    // int tables, compact: fk list | id list | leaf ops | jump[n_levels][n_ops] | op_anc[n_ops], padded to 16 bytes
+    put(P.fk_leaves, sizeof(int32_t) * P.n_fk_leaves);
+    put(P.id_leaves, sizeof(int32_t) * P.n_id_leaves);
+    put(P.leaf_ops, sizeof(int32_t) * P.n_leaf_ops);
+    for (int l = 0; l < P.hex.n_levels; ++l) put(P.hex.jump[l], sizeof(int32_t) * P.n_ops);
+    put(P.hex.op_anc, sizeof(uint32_t) * P.n_ops);
+    while (blob.size() % 16) blob.push_back(0);
     h->hex_blob16 = (int)(blob.size() / 16);
     if (e == hipSuccess) e = hipMalloc(&h->d_hex_blob, blob.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_hex_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);

@@ -104,9 +104,11 @@ __device__ __forceinline__ void sincos1(float x, float& sn, float& cs) {
   cs = ((n + 1) & 2) ? -c0 : c0;
 }
 
-__device__ __forceinline__ double rcpd(double x) {  // 1/x in fp64: v_rcp_f64 + two Newton steps (full precision)
+// 1/x in fp64 for the pivots of the resolve: v_rcp_f64 (measured on gfx950: 4.3e-8 relative) + ONE Newton step
+// (1.9e-15 relative, ~49 bits).  The second step would buy the last 3 bits at two more dependent fp64 FMAs on the
+// elimination's critical path, 1e10 below the 1e-5 parity tolerance.
+__device__ __forceinline__ double rcpd(double x) {
   double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
@@ -281,6 +283,7 @@ struct QuadHdr {
   int32_t n_ops, n_dof, n_id, n_leaves, goal_floats, n_leaf_ops;
   uint32_t rev_mask;
   int32_t n_levels;  // pointer-jumping rounds (rmp2_hex.h only)
+  int32_t n_fk;      // leaves on FK task maps (rmp2_hex.h only)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * 16 * n_ops; }
