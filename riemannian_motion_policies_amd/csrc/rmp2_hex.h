@@ -77,24 +77,24 @@ struct HexLds {
 
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
-inline size_t hex_lds_bytes(int n_ops, int blob16, int n_sphere_floats) {
-  return sizeof(float) * (HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + n_sphere_floats) +
-         16 * (size_t)blob16 + sizeof(float) * 16 * kHexRobots;
+inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats) {
+  const size_t per_wave = HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots;
+  return sizeof(float) * (waves * per_wave + n_sphere_floats) + 16 * (size_t)blob16;
 }
 
 // global -> LDS copy with up to four loads per lane in flight before the first LDS write
-template <typename T>
-__device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, int n, int lane) {
-  for (int base = 0; base < n; base += 4 * kWave) {
+template <int THREADS, typename T>
+__device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, int n, int tid) {
+  for (int base = 0; base < n; base += 4 * THREADS) {
     T v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = base + u * kWave + lane;
+      const int i = base + u * THREADS + tid;
       if (i < n) v[u] = src[i];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = base + u * kWave + lane;
+      const int i = base + u * THREADS + tid;
       if (i < n) dst[i] = v[u];
     }
   }
@@ -346,8 +346,10 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
   return TW;
 }
 
-template <int N, bool CAP>
-__global__ void __launch_bounds__(kWave, 1)
+// WAVES = waves per block.  Each wave owns four robots and its own LDS working set; the waves of a block share one
+// staged copy of the program and of the obstacle table (loaded cooperatively, one real barrier after the prologue).
+template <int N, bool CAP, int WAVES>
+__global__ void __launch_bounds__(kWave * WAVES, 1)
 rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, const float* __restrict__ q,
                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                      OutArgs out, int R) {
@@ -362,10 +364,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 #define RMP2_KARGS
 #endif
   RMP2_STAMP();
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6;
+  const int lane = tid & (kWave - 1);
   const int s = lane & (kHex - 1);
   const int g = lane >> 4;
-  const int r0 = blockIdx.x * kHexRobots;
+  const int r0 = (blockIdx.x * WAVES + wv) * kHexRobots;
   const int robot = r0 + g;
   const bool live = robot < R;
   const int n_dof = hdr.n_dof, n_ops = hdr.n_ops, n_id = hdr.n_id, n_lo = hdr.n_leaf_ops;
@@ -374,13 +378,18 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   const int gi = min(g, n_live - 1);  // groups beyond the fleet's tail re-use the last live robot's inputs
 
   // ---- LDS carve-up -----------------------------------------------------------------------------------
-  float* const T0 = lds + HexLds<N>::kFloats;
+  // [per-wave static x WAVES | per-wave T0 T1 SC VA x WAVES | per-wave goal tile x WAVES | sphere table | program]
+  float* const wl = lds + wv * HexLds<N>::kFloats;                       // this wave's static region
+  const int dyn_per_wave = 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8;
+  float* const T0 = lds + WAVES * HexLds<N>::kFloats + wv * dyn_per_wave;
   float* const T1 = T0 + kHexRobots * n_ops * 12;
   float* const SCb = T1 + kHexRobots * n_ops * 12;   // [4][n_ops][8] prefix-sum exchange
   float* const VAb = SCb + kHexRobots * n_ops * 8;   // [4][n_ops][8] (v, a) of every frame origin
   const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
-  float* const sph_lds_base = VAb + kHexRobots * n_ops * 8;
+  float* const goal_base = lds + WAVES * (HexLds<N>::kFloats + dyn_per_wave);
+  float* const s_goal = goal_base + wv * 16 * kHexRobots;
+  float* const sph_lds_base = goal_base + WAVES * 16 * kHexRobots;
   float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
   // the staged program: same layout as the host's blob
   HexCtl* const s_ctl = reinterpret_cast<HexCtl*>(stage_base);
@@ -391,11 +400,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   int32_t* const s_lo = s_id + n_id;
   int32_t* const s_jump = s_lo + n_lo;
   uint32_t* const s_op_anc = reinterpret_cast<uint32_t*>(s_jump + hdr.n_levels * n_ops);
-  float* const s_goal = reinterpret_cast<float*>(stage_base) + 4 * blob16;
 
   // ---- prologue: one burst of loads brings the state tile, the obstacle table and the program on chip ----
   {
-    const int tile = n_live * n_dof;
+    const int tile = max(n_live, 0) * n_dof;
     const float* gq = q + (size_t)r0 * n_dof;
     const float* gqd = qd + (size_t)r0 * n_dof;
     // state tile: with n_dof == N rows are contiguous in HBM and in LDS and the tile (<= 4 N <= 64 floats) is one
@@ -408,15 +416,16 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     }
     // the program blob, the obstacle table and the goals: loads first, LDS writes after
     const int nf4 = (CAP ? 2 : 1) * n_sph_lds;
-    const int ng = goal ? n_live * hdr.goal_floats : 0;  // goal_floats <= 16 (checked on the host): ng <= 64
+    const int ng = goal ? max(n_live, 0) * hdr.goal_floats : 0;  // goal_floats <= 16 (checked on the host): ng <= 64
+    constexpr int kBlk = kWave * WAVES;  // the block's threads share the staging of the program and the table
     uint4 bv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = u * kWave + lane;
+      const int i = u * kBlk + tid;
       if (i < blob16) bv[u] = blob[i];
     }
     float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < nf4) sv = reinterpret_cast<const float4*>(obs.spheres)[lane];
+    if (tid < nf4) sv = reinterpret_cast<const float4*>(obs.spheres)[tid];
     float gv = 0.f;
     int g_rr = 0, g_jj = 0;
     if (lane < ng) {
@@ -426,48 +435,52 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = u * kWave + lane;
+      const int i = u * kBlk + tid;
       if (i < blob16) reinterpret_cast<uint4*>(stage_base)[i] = bv[u];
     }
-    if (lane < nf4) reinterpret_cast<float4*>(sph_lds_base)[lane] = sv;
+    if (tid < nf4) reinterpret_cast<float4*>(sph_lds_base)[tid] = sv;
     if (lane < ng) s_goal[g_rr * 16 + g_jj] = gv;
     if (fastq) {
       if (lane < tile) {
-        lds[HexLds<N>::kQ + lane] = qa;
-        lds[HexLds<N>::kQd + lane] = qb;
+        wl[HexLds<N>::kQ + lane] = qa;
+        wl[HexLds<N>::kQd + lane] = qb;
       }
     } else {
       for (int i = lane; i < tile; i += kWave) {
         const int rr = i / n_dof, jj = i - rr * n_dof;
-        lds[HexLds<N>::kQ + rr * N + jj] = gq[i];
-        lds[HexLds<N>::kQd + rr * N + jj] = gqd[i];
+        wl[HexLds<N>::kQ + rr * N + jj] = gq[i];
+        wl[HexLds<N>::kQd + rr * N + jj] = gqd[i];
       }
       if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
         const int pad = N - n_dof;
         for (int i = lane; i < kHexRobots * pad; i += kWave) {
           const int rr = i / pad, jj = n_dof + (i - rr * pad);
-          lds[HexLds<N>::kQ + rr * N + jj] = 0.f;
-          lds[HexLds<N>::kQd + rr * N + jj] = 0.f;
+          wl[HexLds<N>::kQ + rr * N + jj] = 0.f;
+          wl[HexLds<N>::kQd + rr * N + jj] = 0.f;
         }
       }
     }
     // leftovers of big programs / big obstacle tables
-    if (blob16 > 4 * kWave)
-      stage_copy(reinterpret_cast<uint4*>(stage_base) + 4 * kWave, blob + 4 * kWave, blob16 - 4 * kWave, lane);
-    if (nf4 > kWave)
-      stage_copy(reinterpret_cast<float4*>(sph_lds_base) + kWave, reinterpret_cast<const float4*>(obs.spheres) + kWave,
-                 nf4 - kWave, lane);
-    hex_sync();
+    if (blob16 > 4 * kBlk)
+      stage_copy<kBlk>(reinterpret_cast<uint4*>(stage_base) + 4 * kBlk, blob + 4 * kBlk, blob16 - 4 * kBlk, tid);
+    if (nf4 > kBlk)
+      stage_copy<kBlk>(reinterpret_cast<float4*>(sph_lds_base) + kBlk, reinterpret_cast<const float4*>(obs.spheres) + kBlk,
+                       nf4 - kBlk, tid);
+    if (WAVES > 1)
+      __syncthreads();  // the only cross-wave dependence: the shared staged program / obstacle table
+    else
+      hex_sync();
   }
+  if (n_live <= 0) return;  // a wave past the fleet's tail (it has done its share of the staging)
   RMP2_STAMP();  // 1: prologue done
   const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
-  const float* my_q = &lds[HexLds<N>::kQ + gi * N];
-  const float* my_qd = &lds[HexLds<N>::kQd + gi * N];
-  float* my_out = &lds[HexLds<N>::kOut + g * n_dof];
+  const float* my_q = &wl[HexLds<N>::kQ + gi * N];
+  const float* my_qd = &wl[HexLds<N>::kQd + gi * N];
+  float* my_out = &wl[HexLds<N>::kOut + g * n_dof];
   const float* my_goal = goal ? s_goal + gi * 16 : nullptr;
-  float* const DOF = &lds[HexLds<N>::kDof + g * N * 8];
-  float4* const COL = reinterpret_cast<float4*>(&lds[HexLds<N>::kCol + g * kHex * 4]);
-  float4* const XCH = reinterpret_cast<float4*>(&lds[HexLds<N>::kXch + g * kHex * 4]);
+  float* const DOF = &wl[HexLds<N>::kDof + g * N * 8];
+  float4* const COL = reinterpret_cast<float4*>(&wl[HexLds<N>::kCol + g * kHex * 4]);
+  float4* const XCH = reinterpret_cast<float4*>(&wl[HexLds<N>::kXch + g * kHex * 4]);
   uint32_t status = 0u;
 
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
@@ -712,7 +725,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   for (int j = 0; j < N; ++j)
     if (s >= n_dof && j == s) A[j] = 1.0;
   // keep the untouched system for the careful path
-  double* const SYS = reinterpret_cast<double*>(&lds[HexLds<N>::kSys + g * HexLds<N>::kSysStride]);
+  double* const SYS = reinterpret_cast<double*>(&wl[HexLds<N>::kSys + g * HexLds<N>::kSysStride]);
   if (s < N) {
 #pragma unroll
     for (int j = 0; j < N; ++j) SYS[s * (N + 1) + j] = A[j];
@@ -730,7 +743,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const double tiny = 1e-11 * scale;
     flagged = !(scale > 0.0) || !(scale < 1.7e308);
     double lmax = 0.0, inv_own = 0.0;
-    double* const ROW = reinterpret_cast<double*>(&lds[HexLds<N>::kRow + g * HexLds<N>::kRowStride]);
+    double* const ROW = reinterpret_cast<double*>(&wl[HexLds<N>::kRow + g * HexLds<N>::kRowStride]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       if (s == k) {
@@ -790,7 +803,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- coalesced store of the qdd tile -----------------------------------------------------------------
   hex_sync();
   {
-    const float* tile = &lds[HexLds<N>::kOut];
+    const float* tile = &wl[HexLds<N>::kOut];
     const int count = n_live * n_dof;
     float* go = out.qdd + (size_t)r0 * n_dof;
     for (int i = lane; i < count; i += kWave) go[i] = tile[i];

@@ -731,6 +731,7 @@ struct rmp2_handle {
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
+  int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
   int n_fk_leaves = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
   int hex_blob16 = 0;          // its size in 16-byte units
@@ -1045,22 +1046,32 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
 #undef RMP2_QUAD_LAUNCH
 }
 
-template <int N>
-void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                const OutArgs& out, int R, hipStream_t s) {
-  const int blocks = (R + kHexRobots - 1) / kHexRobots;
+template <int N, int WAVES>
+void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                  const OutArgs& out, int R, hipStream_t s) {
+  const int per_block = kHexRobots * WAVES;
+  const int blocks = (R + per_block - 1) / per_block;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t bytes = hex_lds_bytes<N>(h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
+  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true>), dim3(blocks), dim3(kWave), bytes, s, blob, h->hex_blob16, hdr, q, qd,
-                       goal, gs, o, out, R);
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
+                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, R);
   else
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false>), dim3(blocks), dim3(kWave), bytes, s, blob, h->hex_blob16, hdr, q, qd,
-                       goal, gs, o, out, R);
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
+                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, R);
+}
+
+template <int N>
+void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                const OutArgs& out, int R, hipStream_t s) {
+  if (h->hex_waves == 1)
+    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, R, s);
+  else
+    launch_hex_w<N, 4>(h, q, qd, goal, gs, o, out, R, s);
 }
 
 template <int N>
@@ -1153,6 +1164,10 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   }
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
+  {
+    const char* we = std::getenv("RMP2_HEX_WAVES");
+    h->hex_waves = (we && std::atoi(we) == 1) ? 1 : 4;
+  }
   h->n_fk_leaves = P.n_fk_leaves;
   h->rev_mask = P.rev_mask;
   {
