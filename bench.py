@@ -165,11 +165,16 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    # HIP events bracket every `stride`-th launch of the timed region (on the stream the kernel is
-    # launched on); bracketing every launch would itself add ~8 us of GPU idle time per step
-    stride = max(1, args.steps // 16)
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for i in range(0, args.steps, stride)}
+    # HIP events (on the stream the kernel is launched on) bracket GROUPS of `grp` consecutive launches of the
+    # timed region: an event pair costs ~4 us of GPU time by itself, as much as a third of one launch of the
+    # latency-bound kernel, so it is amortised over the group and its empty-pair reading is calibrated out.
+    # kernel_ms = (elapsed - empty pair) / grp is the steady-state time per launch INCLUDING the idle gap between
+    # two dependent launches (~0.7 us); rocprofv3's kernel-trace average (profiles/) is the kernel alone.
+    grp = 8 if args.steps >= 16 else 1
+    n_groups = min(8, args.steps // grp)
+    starts = {int(round(k * (args.steps - grp) / max(n_groups - 1, 1))) for k in range(n_groups)}
+    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sorted(starts)}
+    ends = {i + grp - 1: i for i in ev}
     stream = torch.cuda.current_stream(dev)
 
     def fence():
@@ -180,29 +185,25 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        e = ev.get(i)
-        if e is None:
-            one_step()
-        else:
-            e[0].record(stream)
-            one_step()
-            e[1].record(stream)
+        if i in ev:
+            ev[i][0].record(stream)
+        one_step()
+        if i in ends:
+            ev[ends[i]][1].record(stream)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    raw_ms = float(np.median([a.elapsed_time(b) for a, b in ev.values()]))  # HIP events on the launch stream
-    # an event pair with nothing in between does not read 0: calibrate that floor out (it is ~15 % of a
-    # 16 us kernel); rocprofv3's kernel-trace duration is the cross-check (profiles/)
+    raw_ms = float(np.median([a.elapsed_time(b) for a, b in ev.values()]))  # one group of `grp` launches
     empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
     for a, b in empty:
         a.record(stream)
         b.record(stream)
     torch.cuda.synchronize(dev)
     floor_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
-    kern_ms = max(raw_ms - floor_ms, 1e-6)
+    kern_ms = max(raw_ms - floor_ms, 1e-6) / grp
 
     total_steps = R * world * args.steps
     value = total_steps / dt
@@ -237,8 +238,8 @@ def main():
                        "parallelism": f"robot-batch split x{world}" + (", RCCL all-gather of the sphere table per step" if exch else "")},
             "roofline": {"bound": "hbm", "achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bw / HBM_PEAK, "traffic": traffic,
-                         "kernel": "rmp2_step_quad_kernel / rmp2_step_kernel (by fleet size)", "kernel_ms": kern_ms,
-                         "event_pair_ms_raw": raw_ms, "event_pair_ms_empty": floor_ms,
+                         "kernel": ("rmp2_step_hex_kernel" if R <= 8192 else ("rmp2_step_quad_kernel" if wl["spheres"] else "rmp2_step_kernel")) + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)", "kernel_ms": kern_ms,
+                         "event_group_launches": grp, "event_group_ms_raw": raw_ms, "event_pair_ms_empty": floor_ms,
                          "algorithmic_bytes_per_robot_step": wl["bytes"],
                          "valu": {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",
                                   "frac": ach_fl / VALU_PEAK, "algorithmic_flops_per_robot_step": wl["flops"]},

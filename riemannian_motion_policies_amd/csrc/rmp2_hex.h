@@ -78,7 +78,8 @@ struct HexLds {
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
 inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats) {
-  const size_t per_wave = HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots;
+  const size_t per_wave = HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots +
+                          kHexRobots * RMP2_MAX_DOF;
   return sizeof(float) * (waves * per_wave + n_sphere_floats) + 16 * (size_t)blob16;
 }
 
@@ -88,10 +89,7 @@ __device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, in
   for (int base = 0; base < n; base += 4 * THREADS) {
     T v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + u * THREADS + tid;
-      if (i < n) v[u] = src[i];
-    }
+    for (int u = 0; u < 4; ++u) v[u] = src[min(base + u * THREADS + tid, n - 1)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = base + u * THREADS + tid;
@@ -389,7 +387,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
   float* const goal_base = lds + WAVES * (HexLds<N>::kFloats + dyn_per_wave);
   float* const s_goal = goal_base + wv * 16 * kHexRobots;
-  float* const sph_lds_base = goal_base + WAVES * 16 * kHexRobots;
+  float* const blk_out = goal_base + WAVES * 16 * kHexRobots;             // [WAVES * 4][n_dof] qdd tile of the block
+  float* const sph_lds_base = blk_out + WAVES * kHexRobots * RMP2_MAX_DOF;
   float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
   // the staged program: same layout as the host's blob
   HexCtl* const s_ctl = reinterpret_cast<HexCtl*>(stage_base);
@@ -420,10 +419,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     constexpr int kBlk = kWave * WAVES;  // the block's threads share the staging of the program and the table
     uint4 bv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = u * kBlk + tid;
-      if (i < blob16) bv[u] = blob[i];
-    }
+    for (int u = 0; u < 4; ++u) bv[u] = blob[min(u * kBlk + tid, blob16 - 1)];  // clamped: no branch around the load
     float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < nf4) sv = reinterpret_cast<const float4*>(obs.spheres)[tid];
     float gv = 0.f;
@@ -476,7 +472,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
   const float* my_q = &wl[HexLds<N>::kQ + gi * N];
   const float* my_qd = &wl[HexLds<N>::kQd + gi * N];
-  float* my_out = &wl[HexLds<N>::kOut + g * n_dof];
+  float* my_out = blk_out + (wv * kHexRobots + g) * n_dof;
   const float* my_goal = goal ? s_goal + gi * 16 : nullptr;
   float* const DOF = &wl[HexLds<N>::kDof + g * N * 8];
   float4* const COL = reinterpret_cast<float4*>(&wl[HexLds<N>::kCol + g * kHex * 4]);
@@ -800,13 +796,17 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     }
   }
 
-  // ---- coalesced store of the qdd tile -----------------------------------------------------------------
-  hex_sync();
+  // ---- coalesced store of the BLOCK's qdd tile (16 robots, contiguous in HBM): whole cache lines instead of one
+  // partial-line write per wave ----------------------------------------------------------------------------
+  if (WAVES > 1)
+    __syncthreads();  // waves that returned past the fleet's tail no longer count
+  else
+    hex_sync();
   {
-    const float* tile = &wl[HexLds<N>::kOut];
-    const int count = n_live * n_dof;
-    float* go = out.qdd + (size_t)r0 * n_dof;
-    for (int i = lane; i < count; i += kWave) go[i] = tile[i];
+    const int rb = blockIdx.x * WAVES * kHexRobots;
+    const int count = min(WAVES * kHexRobots, R - rb) * n_dof;
+    float* go = out.qdd + (size_t)rb * n_dof;
+    for (int i = tid; i < count; i += kWave * WAVES) go[i] = blk_out[i];
   }
   if (out.status && live && s == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS

@@ -27,7 +27,9 @@ for name, desc in sets.items():
     for _ in range(5):
         eng.step(q, qd, g, obstacles=obs, f=f)
     torch.cuda.synchronize()
-    per_block = 4 if os.environ.get("RMP2_KERNEL") == "hex" else 16
+    per_block = 16  # quad: 16 robots per wave-block; hex: 4 waves x 4 robots per block
+    if os.environ.get("RMP2_KERNEL") == "hex" and os.environ.get("RMP2_HEX_WAVES") == "1":
+        per_block = 4
     st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + per_block - 1) // per_block) * 8].reshape(-1, 8).astype(np.int64)
     d = np.diff(st[:, :7], axis=1)
     med = np.median(d, axis=0)
