@@ -92,20 +92,30 @@ def test_config3_all_mappings_and_obstacle_modes(torch_mod, golden_dir, kernel, 
 
 
 @pytest.mark.parametrize("kernel", ["hex", "quad", "lane"])
-def test_two_joint_and_status_paths(torch_mod, golden_dir, kernel):
-    """N = 2 template; robot 0 of the config-1 fixture is the exactly rank-1 start pose: the careful path of every
-    mapping must report the rank drop and return the pseudo-inverse solution."""
+def test_two_joint_template_and_status_paths(torch_mod, golden_dir, kernel):
+    """N = 2 template of every mapping (a TwoJoint set WITH an inertia leaf: sets without one are routed to the
+    strict pseudo-inverse kernel whatever RMP2_KERNEL says), ragged sphere lists, and the non-finite status path."""
     torch = torch_mod
-    from riemannian_motion_policies_amd import configs as Cf
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    from riemannian_motion_policies_amd.urdf import two_joint_table
     g = np.load(os.path.join(golden_dir, "config5.npz"))
-    _, desc = Cf.config5_two_joint()
+    t = two_joint_table()
+    specs = [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("link_23"), Cf.TARGET_POLICY_PARAMS,
+                        goal_len=3, name="target"),
+             D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, Cf.JOINT_DAMPING_PARAMS, name="joint_damping")]
+    for fr in Cf.TWO_JOINT_CONTROL_POINT_FRAMES:
+        specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index(fr),
+                                Cf.OBSTACLE_AVOIDANCE_PARAMS, name=f"collision_avoidance_for_{fr}"))
+    desc = D.build_desc(t, specs)
     eng = _engine(desc, kernel)
-    obs = eng.obstacles(spheres=torch.from_numpy(g["tj_spheres"]), csr_offset=torch.from_numpy(g["tj_csr_offset"]),
-                        csr_index=torch.from_numpy(g["tj_csr_index"]))
+    kw = dict(spheres=g["tj_spheres"], csr_offset=g["tj_csr_offset"], csr_index=g["tj_csr_index"])
+    obs = eng.obstacles(**{k: torch.from_numpy(v) for k, v in kw.items()})
     qdd = eng.step(torch.from_numpy(g["tj_q"]), torch.from_numpy(g["tj_qd"]), torch.from_numpy(g["tj_goal"]), obstacles=obs)
     torch.cuda.synchronize()
-    _check(qdd.cpu().numpy(), g["tj_qdd"], f"config5 two-joint {kernel}")
-    # non-finite input: the mapping's careful path must flag it, not hang
+    ref = O.step(desc, g["tj_q"], g["tj_qd"], g["tj_goal"], **kw)
+    _check(qdd.cpu().numpy(), ref["qdd64"], f"two-joint + damping {kernel}")
+    # non-finite input: the mapping's careful path must flag it, not hang, and leave the other robots alone
     q = g["tj_q"].copy()
     q[0, 0] = np.nan
     st = torch.zeros(q.shape[0], dtype=torch.int32, device="cuda")
@@ -113,4 +123,4 @@ def test_two_joint_and_status_paths(torch_mod, golden_dir, kernel):
                    status=st)
     torch.cuda.synchronize()
     assert st.cpu().numpy()[0] & 1 and not np.isfinite(out.cpu().numpy()[0]).all()
-    assert np.isfinite(out.cpu().numpy()[1:]).all()
+    _check(out.cpu().numpy()[1:], ref["qdd64"][1:], f"two-joint + damping {kernel}, robots next to a NaN one")
