@@ -246,6 +246,15 @@ int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R,
 int rmp2_differentiate(rmp2_handle *h, const float *q, const float *qd, int32_t frame, float *x, float *xd,
                        float *J, float *c, int32_t R, void *stream);
 
+/* Task-map differentiation of the chain [FK(frame), TaskmapFrom4x4ToEuler] (taskmap.py:57-67 with
+ * euler_from_rotation_matrix, kinematics.py:74-96: theta_y = -asin(r20), theta_z = atan2(r10, r00),
+ * theta_x = atan2(r21, r22), i.e. R = Rz Ry Rx), used by the reference's tests/test_taskmaps.py:42-44:
+ *   x[R][3] = (theta_x, theta_y, theta_z), xd[R][3] = J qd, J[R][3][n_dof], c[R][3] = Jdot qd,
+ * analytically: xd = H^-1 w, J = H^-1 J_w, c = H^-1 (alpha - Hdot xd) with w = H(x) xd.  At gimbal lock
+ * (|cos theta_y| < 1e-6, where the reference substitutes 1 for the cosine) the outputs are not finite. */
+int rmp2_differentiate_euler(rmp2_handle *h, const float *q, const float *qd, int32_t frame, float *x, float *xd,
+                             float *J, float *c, int32_t R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

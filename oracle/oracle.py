@@ -150,6 +150,20 @@ def differentiate(desc: D.Desc, q, qd, frame: int, precision="f32"):
     return x, xd, J, c
 
 
+def differentiate_euler(desc: D.Desc, q, qd, frame: int, precision="f32"):
+    """(x, xd, J, c) of the chain [FK(frame), TaskmapFrom4x4ToEuler] (taskmap.py:57-67)."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    qd = np.ascontiguousarray(qd, dtype=np.float32)
+    R, n = q.shape
+    dt, ct = (np.float32, C.c_float) if precision == "f32" else (np.float64, C.c_double)
+    x, xd, c = (np.empty((R, 3), dt) for _ in range(3))
+    J = np.empty((R, 3, n), dt)
+    getattr(lib(), f"orc_differentiate_euler_{precision}")(C.byref(desc), _ptr(q, C.c_float), _ptr(qd, C.c_float),
+                                                            C.c_int(frame), _ptr(x, ct), _ptr(xd, ct), _ptr(J, ct),
+                                                            _ptr(c, ct), C.c_int(R))
+    return x, xd, J, c
+
+
 def pinv_solve(M, f):
     M = np.ascontiguousarray(M, np.float64)
     f = np.ascontiguousarray(f, np.float64)

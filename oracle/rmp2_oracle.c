@@ -751,3 +751,58 @@ int ORC_NAME(orc_differentiate)(const rmp2_desc *desc, const float *q, const flo
 int ORC_NAME(orc_pinv_solve)(int n, const double *M, const double *f, double *x) { return pinv_solve(n, M, f, x); }
 
 size_t ORC_NAME(orc_sizeof_desc)(void) { return sizeof(rmp2_desc); }
+
+/* chain [FK(frame), TaskmapFrom4x4ToEuler]  (taskmap.py:57-67, kinematics.py:74-96): x[R][3] = (theta_x, theta_y,
+ * theta_z) with R = Rz Ry Rx; analytic derivatives through the angular velocity: w = H(e) ed,
+ * H = [Rz Ry ex | Rz ey | ez]  =>  xd = H^-1 w,  J = H^-1 J_w,  c = H^-1 (alpha - Hdot xd).            */
+int ORC_NAME(orc_differentiate_euler)(const rmp2_desc *desc, const float *q, const float *qd, int frame, real *x,
+                                      real *xd, real *J, real *c, int R) {
+  const rmp2_robot *rb = &desc->robot;
+  const int n = rb->n_dof;
+  for (int r = 0; r < R; ++r) {
+    kin_state ks;
+    kinematics_all(rb, q + (size_t)r * n, qd + (size_t)r * n, &ks);
+    const real *T = ks.T[frame];
+    const real r00 = T[0], r10 = T[4], r20 = T[8], r21 = T[9], r22 = T[10];
+#ifdef ORC_DOUBLE
+    const real ty = -asin(r20), cy = cos(ty);
+    const real safe = fabs(cy) < 1e-6 ? 1.0 : cy;
+    const real tz = atan2(r10 / safe, r00 / safe), tx = atan2(r21 / safe, r22 / safe);
+    const real cz = cos(tz), sz = sin(tz);
+#else
+    const real ty = -asinf(r20), cy = cosf(ty);
+    const real safe = fabsf(cy) < 1e-6f ? 1.0f : cy;
+    const real tz = atan2f(r10 / safe, r00 / safe), tx = atan2f(r21 / safe, r22 / safe);
+    const real cz = cosf(tz), sz = sinf(tz);
+#endif
+    const real sy = -r20;
+    real *xo = x + (size_t)r * 3, *xdo = xd + (size_t)r * 3, *co = c + (size_t)r * 3, *Jo = J + (size_t)r * 3 * n;
+    xo[0] = tx, xo[1] = ty, xo[2] = tz;
+#define HINV(u, o)                                   \
+  do {                                               \
+    const real a_ = (cz * (u)[0] + sz * (u)[1]) / cy; \
+    (o)[0] = a_;                                     \
+    (o)[1] = -sz * (u)[0] + cz * (u)[1];             \
+    (o)[2] = (u)[2] + sy * a_;                       \
+  } while (0)
+    real ed[3];
+    HINV(ks.w[frame], ed);
+    for (int i = 0; i < 3; ++i) xdo[i] = ed[i];
+    for (int k = 0; k < 3 * n; ++k) Jo[k] = 0;
+    for (int j = 0; j < rb->n_frames; ++j) {
+      const int d = rb->q_index[j];
+      if (d < 0 || rb->joint_type[j] != RMP2_JOINT_REVOLUTE || !is_ancestor_or_self(rb, j, frame)) continue;
+      real col[3];
+      HINV(ks.z[j], col);
+      for (int i = 0; i < 3; ++i) Jo[i * n + d] = col[i];
+    }
+    const real h0[3] = {-sz * cy * ed[2] - cz * sy * ed[1], cz * cy * ed[2] - sz * sy * ed[1], -cy * ed[1]};
+    const real h1[3] = {-cz * ed[2], -sz * ed[2], 0};
+    real rhs[3], cc[3];
+    for (int i = 0; i < 3; ++i) rhs[i] = ks.al[frame][i] - (h0[i] * ed[0] + h1[i] * ed[1]);
+    HINV(rhs, cc);
+    for (int i = 0; i < 3; ++i) co[i] = cc[i];
+#undef HINV
+  }
+  return 0;
+}

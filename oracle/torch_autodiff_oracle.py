@@ -219,6 +219,24 @@ class TaskmapFrom4x4ToPosition:
         return rmp_differentiate(self.forward)(q, qd)
 
 
+def euler_from_rotation_matrix(Rm):  # kinematics.py:74-96
+    r00, r10, r21, r22, r20 = Rm[:, 0, 0], Rm[:, 1, 0], Rm[:, 2, 1], Rm[:, 2, 2], Rm[:, 2, 0]
+    theta_y = -torch.asin(r20)
+    cos_theta_y = torch.cos(theta_y)
+    safe = torch.where(torch.abs(cos_theta_y) < 1e-6, torch.ones_like(cos_theta_y), cos_theta_y)
+    theta_z = torch.atan2(r10 / safe, r00 / safe)
+    theta_x = torch.atan2(r21 / safe, r22 / safe)
+    return torch.stack((theta_x, theta_y, theta_z), dim=-1)
+
+
+class TaskmapFrom4x4ToEuler:  # taskmap.py:57-67
+    def forward(self, inp):
+        return euler_from_rotation_matrix(inp.reshape(-1, 4, 4)[:, :3, :3])
+
+    def differentiate(self, q, qd):
+        return rmp_differentiate(self.forward)(q, qd)
+
+
 class TaskmapJointFrame4x4ToDistance:
     def __init__(self, pos_on_link, pos_on_obs):
         self.pos_on_link = torch.as_tensor(pos_on_link, dtype=F32)

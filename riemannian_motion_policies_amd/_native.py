@@ -46,6 +46,7 @@ def lib():
                                       C.c_int32, C.c_void_p]
     l.rmp2_differentiate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    l.rmp2_differentiate_euler.argtypes = l.rmp2_differentiate.argtypes
     if l.rmp2_abi_version() != D.ABI_VERSION:
         raise Rmp2Error(f"ABI mismatch: library {l.rmp2_abi_version()} vs bindings {D.ABI_VERSION}")
     if l.rmp2_sizeof_desc() != C.sizeof(D.Desc) or l.rmp2_sizeof_obstacles() != C.sizeof(D.Obstacles):

@@ -632,7 +632,7 @@ template <int SLOTS>
 __global__ void __launch_bounds__(kWave)
 rmp2_diff_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const float* __restrict__ qd,
                  int frame, float* __restrict__ xo, float* __restrict__ xdo, float* __restrict__ Jo,
-                 float* __restrict__ co, float* __restrict__ zo_scratch, int R) {
+                 float* __restrict__ co, float* __restrict__ zo_scratch, int R, int euler) {
   const int robot = blockIdx.x * kWave + threadIdx.x;
   if (robot >= R) return;
   const int n = prog->n_dof;
@@ -663,6 +663,47 @@ rmp2_diff_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
         if (op.save == s) slot[s] = cur;
     }
     if (op.frame != frame) continue;
+    if (euler) {
+      // chain [FK(frame), 4x4 -> Euler xyz] (taskmap.py:57-67, kinematics.py:74-96): R = Rz Ry Rx, angular velocity
+      // w = H(e) ed with H = [Rz Ry ex | Rz ey | ez]; J = H^-1 J_w (J_w: world axes of the revolute ancestors)
+      const float r00 = cur.R[0], r10 = cur.R[3], r20 = cur.R[6], r21 = cur.R[7], r22 = cur.R[8];
+      const float ty = -asinf(r20);
+      const float cy = cosf(ty), sy = -r20;
+      const float safe = fabsf(cy) < 1e-6f ? 1.0f : cy;  // the reference's guard on the VALUE (kinematics.py:88)
+      const float tz = atan2f(r10 / safe, r00 / safe), tx = atan2f(r21 / safe, r22 / safe);
+      const float cz = cosf(tz), sz = sinf(tz);
+      auto hinv = [&](const float u[3], float o[3]) {
+        const float a = (cz * u[0] + sz * u[1]) / cy;
+        o[0] = a;
+        o[1] = -sz * u[0] + cz * u[1];
+        o[2] = u[2] + sy * a;
+      };
+      float* x = xo + (size_t)robot * 3;
+      float* xd = xdo + (size_t)robot * 3;
+      float* c = co + (size_t)robot * 3;
+      float* J = Jo + (size_t)robot * 3 * n;
+      x[0] = tx, x[1] = ty, x[2] = tz;
+      float ed[3];
+      hinv(cur.w, ed);
+      for (int i = 0; i < 3; ++i) xd[i] = ed[i];
+      for (int j = 0; j < n; ++j) {
+        float col[3] = {0.f, 0.f, 0.f};
+        if (((op.anc_mask >> j) & 1u) && ((prog->rev_mask >> j) & 1u)) {
+          const float zj[3] = {zo[j * 6], zo[j * 6 + 1], zo[j * 6 + 2]};
+          hinv(zj, col);
+        }
+        for (int i = 0; i < 3; ++i) J[i * n + j] = col[i];
+      }
+      // Hdot ed: d/dt of the columns (cz cy, sz cy, -sy) and (-sz, cz, 0)
+      const float h0[3] = {-sz * cy * ed[2] - cz * sy * ed[1], cz * cy * ed[2] - sz * sy * ed[1], -cy * ed[1]};
+      const float h1[3] = {-cz * ed[2], -sz * ed[2], 0.f};
+      const float rhs[3] = {cur.al[0] - (h0[0] * ed[0] + h1[0] * ed[1]), cur.al[1] - (h0[1] * ed[0] + h1[1] * ed[1]),
+                            cur.al[2] - (h0[2] * ed[0] + h1[2] * ed[1])};
+      float cc[3];
+      hinv(rhs, cc);
+      for (int i = 0; i < 3; ++i) c[i] = cc[i];
+      return;
+    }
     float* x = xo + (size_t)robot * 16;
     float* xd = xdo + (size_t)robot * 16;
     float* c = co + (size_t)robot * 16;
@@ -1386,8 +1427,8 @@ int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* ta
   return RMP2_OK;
 }
 
-int rmp2_differentiate(rmp2_handle* h, const float* q, const float* qd, int32_t frame, float* x, float* xd, float* J,
-                       float* c, int32_t R, void* stream) {
+static int differentiate_impl(rmp2_handle* h, const float* q, const float* qd, int32_t frame, float* x, float* xd, float* J,
+                              float* c, int32_t R, void* stream, int euler) {
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
   if (!q || !qd || !x || !xd || !J || !c || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
   if (frame < 0 || frame >= h->n_frames) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "frame out of range");
@@ -1405,19 +1446,29 @@ int rmp2_differentiate(rmp2_handle* h, const float* q, const float* qd, int32_t 
   switch (h->n_slots_full) {
     case 0:
       hipLaunchKernelGGL((rmp2_diff_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
-                         h->d_scratch, R);
+                         h->d_scratch, R, euler);
       break;
     case 1:
       hipLaunchKernelGGL((rmp2_diff_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
-                         h->d_scratch, R);
+                         h->d_scratch, R, euler);
       break;
     default:
       hipLaunchKernelGGL((rmp2_diff_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog_full, q, qd, frame, x, xd, J, c,
-                         h->d_scratch, R);
+                         h->d_scratch, R, euler);
       break;
   }
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;
+}
+
+int rmp2_differentiate(rmp2_handle* h, const float* q, const float* qd, int32_t frame, float* x, float* xd, float* J,
+                       float* c, int32_t R, void* stream) {
+  return differentiate_impl(h, q, qd, frame, x, xd, J, c, R, stream, 0);
+}
+
+int rmp2_differentiate_euler(rmp2_handle* h, const float* q, const float* qd, int32_t frame, float* x, float* xd,
+                             float* J, float* c, int32_t R, void* stream) {
+  return differentiate_impl(h, q, qd, frame, x, xd, J, c, R, stream, 1);
 }
 
 }  // extern "C"

@@ -238,3 +238,14 @@ class Engine:
         _native.check(self._lib.rmp2_differentiate(self._h, q.data_ptr(), qd.data_ptr(), int(frame), x.data_ptr(),
                                                    xd.data_ptr(), J.data_ptr(), c.data_ptr(), R, s), self._h)
         return x, xd, J, c
+
+    def differentiate_euler(self, q: torch.Tensor, qd: torch.Tensor, frame: int):
+        """(x, xd, J, c) of the chain [FK(frame), TaskmapFrom4x4ToEuler]: x, xd, c [R,3], J [R,3,n]."""
+        q, qd = _f32(q, self.device), _f32(qd, self.device)
+        R, n = q.shape
+        x, xd, c = (torch.empty((R, 3), dtype=torch.float32, device=self.device) for _ in range(3))
+        J = torch.empty((R, 3, n), dtype=torch.float32, device=self.device)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(self._lib.rmp2_differentiate_euler(self._h, q.data_ptr(), qd.data_ptr(), int(frame), x.data_ptr(),
+                                                         xd.data_ptr(), J.data_ptr(), c.data_ptr(), R, s), self._h)
+        return x, xd, J, c

@@ -44,3 +44,11 @@ class UrdfForwardKinematic:
         qd2 = np.atleast_2d(np.asarray(qd, dtype=np.float32)) if as_np else qd
         out = self._fk_engine().differentiate(q2, qd2, self.table.frame_index(_to_str(frame)))
         return tuple(o.cpu().numpy() for o in out) if as_np else out
+
+    def differentiate_euler(self, q, qd, frame):
+        """-> x[R,3], xd[R,3], J[R,3,n], c[R,3] of the chain [FK(frame), 4x4 -> Euler xyz] (taskmap.py:57-67)."""
+        as_np = not isinstance(q, torch.Tensor)
+        q2 = np.atleast_2d(np.asarray(q, dtype=np.float32)) if as_np else q
+        qd2 = np.atleast_2d(np.asarray(qd, dtype=np.float32)) if as_np else qd
+        out = self._fk_engine().differentiate_euler(q2, qd2, self.table.frame_index(_to_str(frame)))
+        return tuple(o.cpu().numpy() for o in out) if as_np else out

@@ -71,10 +71,20 @@ class TaskmapFrom4x4ToPosition(Taskmap):
 
 
 class TaskmapFrom4x4ToEuler(Taskmap):
-    """taskmap.py:57-67 -- used only by the reference's tests; not on the control path."""
+    """vec(T) -> (theta_x, theta_y, theta_z) with R = Rz Ry Rx (taskmap.py:57-67, euler_from_rotation_matrix
+    kinematics.py:74-96, gimbal guard :88 included).  No leaf of the reference consumes it (its tests do,
+    tests/test_taskmaps.py:42-44); chained behind an FK map, differentiate() runs on the GPU
+    (rmp2_differentiate_euler)."""
 
     def forward(self, input):
-        raise NotImplementedError("Euler task map is outside the accelerated path (SURVEY 8(f)-4)")
+        T = np.asarray(input, dtype=np.float32).reshape(-1, 4, 4)
+        r00, r10, r20, r21, r22 = T[:, 0, 0], T[:, 1, 0], T[:, 2, 0], T[:, 2, 1], T[:, 2, 2]
+        ty = -np.arcsin(r20)
+        cy = np.cos(ty)
+        safe = np.where(np.abs(cy) < 1e-6, np.ones_like(cy), cy)
+        tz = np.arctan2(r10 / safe, r00 / safe)
+        tx = np.arctan2(r21 / safe, r22 / safe)
+        return np.stack((tx, ty, tz), axis=-1).astype(np.float32)
 
 
 class TaskmapFrom4x4ToQuaternions(Taskmap):
@@ -143,12 +153,15 @@ class TaskmapByFunction(Taskmap):
         return out
 
     def differentiate(self, q, qd):
+        st = self.stages()
+        if len(st) == 2 and isinstance(st[0], TaskmapByForwardKinematic) and isinstance(st[1], TaskmapFrom4x4ToEuler):
+            return st[0].fkine.differentiate_euler(q, qd, st[0].frame)
         kind, fk = classify(self)[:2]
         if kind == D.TASKMAP_FK_POSITION:
             x, xd, J, c = fk.differentiate(q, qd)
             rows = list(TaskmapFrom4x4ToPosition.ROWS)
             return x[:, rows], xd[:, rows], J[:, rows, :], c[:, rows]
-        raise NotImplementedError("differentiate() is offered for FK and FK->position chains; "
+        raise NotImplementedError("differentiate() is offered for FK, FK->position and FK->Euler chains; "
                                   "distance chains are differentiated inside RmpCore.evaluate")
 
 

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     declared = set(re.findall(r"\b(rmp2_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"rmp2_handle"}
     assert {"rmp2_create", "rmp2_destroy", "rmp2_step", "rmp2_last_error", "rmp2_forward_kinematics",
-            "rmp2_differentiate", "rmp2_closest_points", "rmp2_rollout", "rmp2_abi_version", "rmp2_sizeof_desc", "rmp2_sizeof_obstacles"} <= declared
+            "rmp2_differentiate", "rmp2_differentiate_euler", "rmp2_closest_points", "rmp2_rollout", "rmp2_abi_version", "rmp2_sizeof_desc", "rmp2_sizeof_obstacles"} <= declared
     lib = C.CDLL(hip_lib)
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/rmp2.h but not exported"

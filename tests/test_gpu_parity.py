@@ -329,3 +329,22 @@ def test_step_is_graph_capturable_and_abi_errors(torch_mod):
     _, d = Cf.config2()
     d.robot.parent[3] = 5                          # not topologically ordered
     assert lib.rmp2_create(C.byref(d), 0, C.byref(hh)) == -1
+
+
+def test_euler_taskmap_golden(torch_mod, golden_dir):
+    """[FK(frame), TaskmapFrom4x4ToEuler].differentiate on the GPU against the autograd vectors,
+    through the class surface (taskmap.chain_taskmaps) and the forward() of the map."""
+    from riemannian_motion_policies_amd import taskmap, urdf
+    from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
+    g = np.load(os.path.join(golden_dir, "euler.npz"))
+    fk = UrdfForwardKinematic(urdf.PANDA_URDF, urdf.PANDA_ORDER)
+    for fr in g["frames"]:
+        name = fk.frame_names[int(fr)]
+        tm = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fk, name), taskmap.TaskmapFrom4x4ToEuler()])
+        x, xd, J, c = tm.differentiate(g["q"], g["qd"])
+        assert x.shape == (16, 3) and J.shape == (16, 3, 9)
+        assert np.abs(x - g[f"f{fr}_x"]).max() < 2e-6
+        assert np.abs(xd - g[f"f{fr}_xd"]).max() < 2e-6
+        assert np.abs(J - g[f"f{fr}_J"]).max() < 5e-6
+        assert np.abs(c - g[f"f{fr}_c"]).max() < 2e-6
+        assert np.abs(tm.forward(g["q"]) - g[f"f{fr}_x"]).max() < 2e-6

@@ -208,3 +208,20 @@ def test_golden_exp05_attached_point_leaves(golden_dir, key):
                dist=g[f"{key}_dist"])
     assert np.abs(r["M"] - g[f"{key}_M"]).max() < 5e-6 and np.abs(r["f"] - g[f"{key}_f"]).max() < 2e-6
     _check(r["qdd64"], g[f"{key}_qdd"], f"exp05 {key}")
+
+
+def test_golden_euler_taskmap(golden_dir):
+    """chain [FK(frame), TaskmapFrom4x4ToEuler]; analytic (H^-1 w, H^-1 J_w, H^-1(alpha - Hdot xd))
+    against the nested-autograd vectors of the reference's expression; plus SciPy's 'xyz' Euler angles."""
+    from scipy.spatial.transform import Rotation
+    g = np.load(os.path.join(golden_dir, "euler.npz"))
+    _, d = Cf.config2()
+    T = O.forward_kinematics(d, g["q"], "f64")
+    for fr in g["frames"]:
+        x, xd, J, c = O.differentiate_euler(d, g["q"], g["qd"], int(fr))
+        assert np.abs(x - g[f"f{fr}_x"]).max() < 2e-6
+        assert np.abs(xd - g[f"f{fr}_xd"]).max() < 2e-6
+        assert np.abs(J - g[f"f{fr}_J"]).max() < 5e-6
+        assert np.abs(c - g[f"f{fr}_c"]).max() < 2e-6
+        ref = Rotation.from_matrix(T[:, int(fr), :3, :3]).as_euler("xyz")      # tests/test_taskmaps.py:46
+        assert np.abs(x - ref).max() < 2e-6
