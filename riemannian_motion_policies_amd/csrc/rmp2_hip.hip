@@ -1106,13 +1106,29 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
                        h->hex_blob16, hdr, q, qd, goal, gs, o, out, R);
 }
 
+constexpr size_t kLdsLimit = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
+
 template <int N>
-void launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
+}
+
+// big programs (many frames / leaves) do not fit four waves' working sets into one block's LDS: one wave per
+// block then; if even that does not fit the caller falls back to the quad kernel
+template <int N>
+bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                 const OutArgs& out, int R, hipStream_t s) {
-  if (h->hex_waves == 1)
-    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, R, s);
-  else
+  if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit) {
     launch_hex_w<N, 4>(h, q, qd, goal, gs, o, out, R, s);
+    return true;
+  }
+  if (hex_bytes<N>(h, o, 1) <= kLdsLimit) {
+    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, R, s);
+    return true;
+  }
+  return false;
 }
 
 template <int N>
@@ -1134,10 +1150,9 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   const bool hex_ok = !rollout && !h->has_point && h->goal_floats <= 16;
   // measured (profiles/): hex wins up to 2 waves per SIMD (R <= 8192: 12.0 vs 14.5 us for the 3-leaf set and 23 vs
   // 43 us for the cluttered set at R = 4096), the quad / lane kernels beyond
-  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 2048 * kHexRobots))) {
-    launch_hex<N>(h, q, qd, goal, gs, o, out, R, s);
+  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 2048 * kHexRobots)) &&
+      launch_hex<N>(h, q, qd, goal, gs, o, out, R, s))
     return RMP2_OK;
-  }
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && R > 16384));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);

@@ -85,3 +85,55 @@ def test_random_tree_robot(tmp_path, seed, hip_lib):
         err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
         tol = ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
         assert (err <= tol).all(), f"seed {seed} {solve}: worst {err.max():.2e}, slots {t.depth_first_schedule()[3]}, n={n}, F={F}"
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad", "lane"])
+def test_deep_chain_more_frames_than_lanes(tmp_path, kernel, hip_lib):
+    """A 30-frame robot (9 actuated joints, the other movable joints held at q = 0, leaves on the deepest frames so that
+    nothing is pruned): more frames than the 16 lanes a robot has in the hex kernel (two frames per lane, five
+    pointer-jumping rounds), deep save/restore-free chain for the walk kernels."""
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import descriptor as D, urdf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    path = str(tmp_path / "deep.urdf")
+    for _ in range(50):
+        movable = _write_urdf(path, rng, 30, branch_prob=0.0)
+        if len(movable) >= 20:      # fixed leaf-less frames are folded away: >= 20 frames survive, > 16 lanes
+            break
+    order = movable[::2][:9]
+    t = urdf.compile_urdf(path, order)
+    n, F = t.n_dof, t.n_frames
+    assert F == 30 and n == 9 and len(movable) >= 20
+    specs = [D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, F - 1,
+                        [0.3, 0.6, 0.075, 0.05, 0.03, 1.0, 0.5, 1.0, 0.02], goal_len=3),
+             D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, [1.0, 0.005, 0.3]),
+             D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, F - 1,
+                        [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001]),
+             D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, F - 9,
+                        [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001])]
+    desc = D.build_desc(t, specs)
+    old = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel
+    try:
+        eng = Engine(desc, 0)
+    finally:
+        if old is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old
+    R = 130
+    q = rng.uniform(-0.6, 0.6, (R, n)).astype(np.float32)
+    qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+    goal = rng.uniform(-0.5, 0.5, (R, 3)).astype(np.float32)
+    sph = np.concatenate([rng.uniform(-1, 1, (6, 3)) + [0, 0, 6.0], rng.uniform(0.05, 0.1, (6, 1))], axis=1).astype(np.float32)
+    M = torch.empty((R, n, n), dtype=torch.float64, device="cuda")
+    out = eng.step(torch.from_numpy(q), torch.from_numpy(qd), torch.from_numpy(goal),
+                   obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), M=M)
+    torch.cuda.synchronize()
+    ref = O.step(desc, q, qd, goal, spheres=sph)
+    scale = np.maximum(1.0, np.abs(ref["M"]).max())
+    assert np.abs(M.cpu().numpy() - ref["M"]).max() < 5e-6 * scale
+    err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
+    assert (err <= 2 * ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))).all(), err.max()
