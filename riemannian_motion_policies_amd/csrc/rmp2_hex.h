@@ -350,7 +350,7 @@ template <int N, bool CAP, int WAVES>
 __global__ void __launch_bounds__(kWave * WAVES, 1)
 rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, const float* __restrict__ q,
                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
-                     OutArgs out, int R) {
+                     OutArgs out, RolloutArgs ro, int R) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef RMP2_STAMPS
   unsigned long long st_[8];
@@ -479,6 +479,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   float4* const XCH = reinterpret_cast<float4*>(&wl[HexLds<N>::kXch + g * kHex * 4]);
   uint32_t status = 0u;
 
+  // closed-loop rollout (rmp2_rollout): n_iters control steps inside this launch; a plain step is one iteration
+#pragma nounroll
+  for (int it = 0; it < ro.n_iters; ++it) {
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
@@ -796,6 +799,25 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     }
   }
 
+  if (ro.substeps > 0) {
+    // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd), lane s advances dof s of the LDS-resident state
+    hex_sync();
+    if (live && s < n_dof) {
+      float* qw = &wl[HexLds<N>::kQ + g * N + s];
+      float* qdw = &wl[HexLds<N>::kQd + g * N + s];
+      const float acc = my_out[s];
+      float qi2 = *qw, qdi2 = *qdw;
+      for (int t = 0; t < ro.substeps; ++t) {
+        qdi2 = fmaf(ro.dt, acc, qdi2);
+        qi2 = fmaf(ro.dt, qdi2, qi2);
+      }
+      *qw = qi2;
+      *qdw = qdi2;
+    }
+    hex_sync();
+  }
+  }  // control steps
+
   // ---- coalesced store of the BLOCK's qdd tile (16 robots, contiguous in HBM): whole cache lines instead of one
   // partial-line write per wave ----------------------------------------------------------------------------
   if (WAVES > 1)
@@ -807,6 +829,14 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const int count = min(WAVES * kHexRobots, R - rb) * n_dof;
     float* go = out.qdd + (size_t)rb * n_dof;
     for (int i = tid; i < count; i += kWave * WAVES) go[i] = blk_out[i];
+  }
+  if (ro.q_out) {  // the advanced state of this wave's robots
+    const int count = n_live * n_dof;
+    for (int i = lane; i < count; i += kWave) {
+      const int rr = i / n_dof, jj = i - rr * n_dof;
+      ro.q_out[(size_t)r0 * n_dof + i] = wl[HexLds<N>::kQ + rr * N + jj];
+      ro.qd_out[(size_t)r0 * n_dof + i] = wl[HexLds<N>::kQd + rr * N + jj];
+    }
   }
   if (out.status && live && s == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS

@@ -1089,7 +1089,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
 
 template <int N, int WAVES>
 void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                  const OutArgs& out, int R, hipStream_t s) {
+                  const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const int per_block = kHexRobots * WAVES;
   const int blocks = (R + per_block - 1) / per_block;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
@@ -1100,10 +1100,10 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
     hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
-                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, R);
+                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
   else
     hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
-                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, R);
+                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
 }
 
 constexpr size_t kLdsLimit = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
@@ -1119,13 +1119,13 @@ size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
 // block then; if even that does not fit the caller falls back to the quad kernel
 template <int N>
 bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                const OutArgs& out, int R, hipStream_t s) {
+                const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit) {
-    launch_hex_w<N, 4>(h, q, qd, goal, gs, o, out, R, s);
+    launch_hex_w<N, 4>(h, q, qd, goal, gs, o, out, ro, R, s);
     return true;
   }
   if (hex_bytes<N>(h, o, 1) <= kLdsLimit) {
-    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, R, s);
+    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, ro, R, s);
     return true;
   }
   return false;
@@ -1147,11 +1147,11 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
   //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
   //  * hex (16 lanes per robot): the latency build for fleets that leave SIMDs idle under the quad mapping.
-  const bool hex_ok = !rollout && !h->has_point && h->goal_floats <= 16;
+  const bool hex_ok = !h->has_point && h->goal_floats <= 16 && !h->strict && !h->likely_singular;
   // measured (profiles/): hex wins up to 2 waves per SIMD (R <= 8192: 12.0 vs 14.5 us for the 3-leaf set and 23 vs
   // 43 us for the cluttered set at R = 4096), the quad / lane kernels beyond
   if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 2048 * kHexRobots)) &&
-      launch_hex<N>(h, q, qd, goal, gs, o, out, R, s))
+      launch_hex<N>(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && R > 16384));

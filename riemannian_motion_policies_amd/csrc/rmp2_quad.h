@@ -951,7 +951,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
       RMP2_STAMP();  // 5: LU done
       if (!__any(flagged && live)) break;
-#ifndef RMP2_EXP_NO_RARE
     } else if (flagged) {
       // ---- rare path: gather the whole system into every lane of the quad, careful solve -------
       double W[N * (N + 1)], T[N * (N + 1)], xp[N];
@@ -981,7 +980,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (sub == 0) my_out[i] = (float)xp[i];
       }
       if (!finite) status |= RMP2_STATUS_NONFINITE;
-#endif
     }
   }
   if (ro.substeps > 0) {

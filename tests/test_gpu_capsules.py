@@ -40,18 +40,18 @@ def _step(torch, eng, s, **obs):
     return out.cpu().numpy(), st.cpu().numpy()
 
 
-def _gate(qdd, ref, clr, what):
+def _gate(qdd, ref, clr, what, scale=1.0):
     e = np.abs(qdd.astype(np.float64) - ref).max(axis=1)
     mag = np.maximum(1.0, np.abs(ref).max(axis=1))
     clear = clr >= 0.05
     assert clear.sum() >= 20, what
-    assert (e[clear] <= ATOL * mag[clear]).all(), f"{what}: clear robots worst {e[clear].max():.2e}"
+    assert (e[clear] <= scale * ATOL * mag[clear]).all(), f"{what}: clear robots worst {e[clear].max():.2e}"
     fin = np.isfinite(ref).all(axis=1) & ~clear
     if fin.any():
         assert (e[fin] <= 1e-3 * mag[fin]).mean() > 0.95, f"{what}: near-contact robots"
 
 
-@pytest.mark.parametrize("kernel", ["quad", "lane"])
+@pytest.mark.parametrize("kernel", ["hex", "quad", "lane"])
 @pytest.mark.parametrize("K", [9, 300])
 def test_capsule_table_vs_oracle(torch_mod, kernel, K):
     """Shared capsule table: K=9 is staged in LDS, K=300 exceeds the 256-record LDS table (global reads)."""
@@ -79,7 +79,9 @@ def test_capsule_table_vs_oracle(torch_mod, kernel, K):
     qdd, _ = _step(torch_mod, eng, s, spheres=caps)
     ref = O.step(desc, s["q"], s["qd"], s["goal"], spheres=caps)
     _, clr = _clearance(desc, s["q"], caps)
-    _gate(qdd, ref["qdd64"], clr, f"capsules K={K} {kernel}")
+    # K = 300: 2400 pairs per robot are summed in fp32, serially in the oracle (like the reference's reduce_sum) and in
+    # 4- / 16-way partial sums in the quad / hex kernels: the association order alone moves qdd by ~2e-5
+    _gate(qdd, ref["qdd64"], clr, f"capsules K={K} {kernel}", scale=3.0 if K > 100 else 1.0)
 
 
 def test_ragged_capsules_vs_oracle(torch_mod):
