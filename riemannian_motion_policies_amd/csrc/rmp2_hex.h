@@ -346,7 +346,8 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
 
 // WAVES = waves per block.  Each wave owns four robots and its own LDS working set; the waves of a block share one
 // staged copy of the program and of the obstacle table (loaded cooperatively, one real barrier after the prologue).
-template <int N, bool CAP, int WAVES>
+// ROLL = build with the fused closed-loop rollout (control-step loop + plant ticks); the plain step carries none of it.
+template <int N, bool CAP, int WAVES, bool ROLL>
 __global__ void __launch_bounds__(kWave * WAVES, 1)
 rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, const float* __restrict__ q,
                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
@@ -480,8 +481,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   uint32_t status = 0u;
 
   // closed-loop rollout (rmp2_rollout): n_iters control steps inside this launch; a plain step is one iteration
+  const int n_iters = ROLL ? ro.n_iters : 1;
 #pragma nounroll
-  for (int it = 0; it < ro.n_iters; ++it) {
+  for (int it = 0; it < n_iters; ++it) {
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
@@ -685,23 +687,36 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         XCH[s] = make_float4(zeta_i, xdd_i, cw_i, 0.f);
         hex_sync();
         const float omb = 1.0f - beta;
-        const bool is_cap = kind == RMP2_LEAF_JOINT_VELOCITY_CAP;
-        const bool is_jla = kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
-        float fi = 0.f;
+        float4 xch[N];  // all triples first (one batch of LDS reads), then one branch-free loop per leaf kind
 #pragma unroll
-        for (int j = 0; j < N; ++j) {  // padded dofs hold (0, 0, 0): their columns come out as exact zeros
-          const float4 x4 = XCH[j];
-          const float zj = x4.x, xj = x4.y, cj = x4.z;
-          float a;
-          if (is_cap) {
-            a = (j == s) ? zeta_i : cj;
-          } else {
-            const float Hij = beta * (zeta_i * zj) + omb * (j == s ? 1.f : 0.f);
-            a = is_jla ? cj * Hij : wsc * Hij;
+        for (int j = 0; j < N; ++j) xch[j] = XCH[j];  // padded dofs hold (0, 0, 0): their columns come out as exact zeros
+        float fi = 0.f;
+        if (kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            float a = (j == s) ? zeta_i : xch[j].z;
+            a = row_ok ? a : 0.f;
+            A[j] += (double)a;
+            fi = fmaf(a, xch[j].y, fi);
           }
-          a = row_ok ? a : 0.f;
-          A[j] += (double)a;
-          fi += a * xj;
+        } else if (kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float Hij = beta * (zeta_i * xch[j].x) + ((j == s) ? omb : 0.f);
+            float a = xch[j].z * Hij;
+            a = row_ok ? a : 0.f;
+            A[j] += (double)a;
+            fi = fmaf(a, xch[j].y, fi);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float Hij = beta * (zeta_i * xch[j].x) + ((j == s) ? omb : 0.f);
+            float a = wsc * Hij;
+            a = row_ok ? a : 0.f;
+            A[j] += (double)a;
+            fi = fmaf(a, xch[j].y, fi);
+          }
         }
         fv += (double)fi;
         hex_sync();  // XCH is rewritten by the next dense leaf
@@ -799,7 +814,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     }
   }
 
-  if (ro.substeps > 0) {
+  if (ROLL && ro.substeps > 0) {
     // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd), lane s advances dof s of the LDS-resident state
     hex_sync();
     if (live && s < n_dof) {
@@ -830,7 +845,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     float* go = out.qdd + (size_t)rb * n_dof;
     for (int i = tid; i < count; i += kWave * WAVES) go[i] = blk_out[i];
   }
-  if (ro.q_out) {  // the advanced state of this wave's robots
+  if (ROLL && ro.q_out) {  // the advanced state of this wave's robots
     const int count = n_live * n_dof;
     for (int i = lane; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;

@@ -1087,7 +1087,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
 #undef RMP2_QUAD_LAUNCH
 }
 
-template <int N, int WAVES>
+template <int N, int WAVES, bool ROLL>
 void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                   const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const int per_block = kHexRobots * WAVES;
@@ -1099,10 +1099,10 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
                     h->hex_levels, h->n_fk_leaves};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
                        h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
   else
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false, WAVES>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
+    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
                        h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
 }
 
@@ -1120,12 +1120,16 @@ size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
 template <int N>
 bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                 const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
   if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit) {
-    launch_hex_w<N, 4>(h, q, qd, goal, gs, o, out, ro, R, s);
+    if (rollout)
+      launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
+    else
+      launch_hex_w<N, 4, false>(h, q, qd, goal, gs, o, out, ro, R, s);
     return true;
   }
-  if (hex_bytes<N>(h, o, 1) <= kLdsLimit) {
-    launch_hex_w<N, 1>(h, q, qd, goal, gs, o, out, ro, R, s);
+  if (!rollout && hex_bytes<N>(h, o, 1) <= kLdsLimit) {  // (the rollout build exists for four-wave blocks only)
+    launch_hex_w<N, 1, false>(h, q, qd, goal, gs, o, out, ro, R, s);
     return true;
   }
   return false;
