@@ -150,7 +150,7 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
     const int4 c0 = c4[0];                                            // jtype, qidx, anc_mask, leaf_begin
     const float4 c1 = reinterpret_cast<const float4*>(c4)[1];         // (leaf_count), axis
     const int jt = c0.x;
-    qi[slot] = c0.y;
+    qi[slot] = on[slot] ? c0.y : -1;  // lanes without a frame read record 0 (or, with no frames at all, whatever follows)
     ax[slot][0] = c1.y, ax[slot][1] = c1.z, ax[slot][2] = c1.w;
     revk[slot] = on[slot] && jt == RMP2_JOINT_REVOLUTE;
     prik[slot] = on[slot] && jt == RMP2_JOINT_PRISMATIC;
@@ -158,7 +158,7 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
 #pragma unroll
     for (int c = 0; c < 9; ++c) hop[slot][c] = h4[c];
 #pragma unroll
-    for (int l = 0; l < 5; ++l) jmp[slot][l] = l < hdr.n_levels ? s_jump[l * n_ops + kk[slot]] : -1;
+    for (int l = 0; l < 5; ++l) jmp[slot][l] = (on[slot] && l < hdr.n_levels) ? s_jump[l * n_ops + kk[slot]] : -1;
     ancm[slot] = on[slot] ? s_op_anc[kk[slot]] : 0u;
   }
 #pragma unroll
