@@ -5,7 +5,7 @@ python bench.py > $O/bench_config2.json 2> $O/bench_config2.err
 python bench.py --workload config3 > $O/bench_config3.json 2> $O/bench_config3.err
 python bench.py --robots 65536 --no-cpu-baseline > $O/bench_config2_64k.json 2>/dev/null
 python bench.py --workload config3 --robots 4096 --no-cpu-baseline > $O/bench_config3_4k.json 2>/dev/null
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline > $O/bench_config2_torchrun1.json 2>$O/torchrun.err
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline > $O/bench_config2_torchrun1.json 2>$O/torchrun.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python3 bench.py --workload config3 --steps 100 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f2 -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
@@ -20,3 +20,8 @@ RMP2_LIB=$GRAFT_REPO_ROOT/tools/diag/librmp2_stamps.so RMP2_KERNEL=hex python to
 RMP2_LIB=$GRAFT_REPO_ROOT/tools/diag/librmp2_stamps.so RMP2_KERNEL=quad python tools/stamps.py 4096 > $O/stamps_quad_R4096.txt 2>/dev/null
 python tools/graph_gap.py config2 4096 200 > $O/graph_gap.txt 2>/dev/null
 find $O -name "*kernel_stats.csv" | head; cat $O/bench_config2.json | cut -c1-300; cat $O/ablation_R4096.txt $O/stamps_hex_R4096.txt
+python tools/rollout_timing.py config2 4096 50 > $O/rollout.txt 2>/dev/null
+RMP2_KERNEL=quad python tools/rollout_timing.py config2 4096 50 >> $O/rollout.txt 2>/dev/null
+python tools/rollout_timing.py config3 4096 50 >> $O/rollout.txt 2>/dev/null
+RMP2_KERNEL=quad python tools/rollout_timing.py config3 4096 50 >> $O/rollout.txt 2>/dev/null
+cat $O/rollout.txt
