@@ -40,7 +40,8 @@ extern "C" {
 /* ---- error codes --------------------------------------------------------------------- */
 #define RMP2_OK 0
 #define RMP2_ERR_INVALID_ARGUMENT (-1)
-#define RMP2_ERR_UNSUPPORTED (-2) /* e.g. more dof / tree branching than a kernel exists for */
+#define RMP2_ERR_UNSUPPORTED (-2) /* no kernel for this combination (e.g. > 2 open branch points; solve = PINV,
+                                     sets without an inertia leaf or attached-point leaves beyond 9 dofs) */
 #define RMP2_ERR_NO_DEVICE (-3)
 #define RMP2_ERR_HIP (-4)         /* a HIP runtime call failed; see rmp2_last_error()      */
 #define RMP2_ERR_ABI_MISMATCH (-5)

@@ -1196,8 +1196,16 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   int rc = compile_program(*desc, P, n_slots, err, /*prune=*/true, &hops);
   if (rc == RMP2_OK) rc = compile_program(*desc, Pfull, n_slots_full, err, /*prune=*/false);
   if (rc != RMP2_OK) return fail(nullptr, rc, err);
-  if (desc->robot.n_dof > 9)
-    return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kernels are instantiated for n_dof <= 9");
+  if (desc->robot.n_dof > 9) {
+    // 10 .. 16 dofs: the hex kernel (one metric row per lane, 16 lanes per robot) is the only mapping instantiated
+    if (desc->solve_mode == RMP2_SOLVE_PINV)
+      return fail(nullptr, RMP2_ERR_UNSUPPORTED, "solve = PINV is instantiated for n_dof <= 9");
+    if (desc->goal_floats > 16)
+      return fail(nullptr, RMP2_ERR_UNSUPPORTED, "more than 16 goal floats per robot with n_dof > 9");
+    for (int l = 0; l < desc->n_leaves; ++l)
+      if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_POINT)
+        return fail(nullptr, RMP2_ERR_UNSUPPORTED, "attached-point leaves are instantiated for n_dof <= 9");
+  }
   if (n_slots > 2 || n_slots_full > 2)
     return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kinematic tree needs more than 2 saved branch states");
   rmp2_handle* h = new (std::nothrow) rmp2_handle();
@@ -1210,7 +1218,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->n_ops_step = P.n_ops;
   h->n_leaves = desc->n_leaves;
   h->goal_floats = desc->goal_floats;
-  h->n_template = h->n_dof <= 2 ? 2 : 9;
+  h->n_template = h->n_dof <= 2 ? 2 : (h->n_dof <= 9 ? 9 : 16);
   h->strict = desc->solve_mode == RMP2_SOLVE_PINV;
   h->n_id_leaves = P.n_id_leaves;
   h->likely_singular = true;
@@ -1221,6 +1229,11 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
         (lf.kind == RMP2_LEAF_CSPACE_BIASING && lf.params[0] + lf.params[4] > 0.f) ||
         (lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING && lf.params[2] > 0.f))
       h->likely_singular = false;
+  }
+  if (h->likely_singular && h->n_template == 16) {
+    delete h;
+    return fail(nullptr, RMP2_ERR_UNSUPPORTED,
+                "a set without an inertia leaf resolves by the pseudo-inverse kernel, instantiated for n_dof <= 9");
   }
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
@@ -1361,8 +1374,10 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   int rc;
   if (h->n_template == 2)
     rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
-  else
+  else if (h->n_template == 9)
     rc = dispatch_solve<9>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
+  else  // 10 .. 16 dofs: hex mapping at every fleet size
+    rc = launch_hex<16>(h, q, qd, goal, goal_stride, o, oa, ro, R, s) ? RMP2_OK : RMP2_ERR_UNSUPPORTED;
   if (rc != RMP2_OK) return fail(h, rc, "no kernel instantiation for this robot");
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;

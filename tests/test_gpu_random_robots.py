@@ -137,3 +137,53 @@ def test_deep_chain_more_frames_than_lanes(tmp_path, kernel, hip_lib):
     assert np.abs(M.cpu().numpy() - ref["M"]).max() < 5e-6 * scale
     err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
     assert (err <= 2 * ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))).all(), err.max()
+
+
+def test_twelve_dof_robot(tmp_path, hip_lib):
+    """10 .. 16 actuated dofs (the ABI's RMP2_MAX_DOF) run on the hex mapping's N = 16 template at every fleet size;
+    what has no N = 16 instantiation is refused at rmp2_create."""
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import _native, descriptor as D, urdf
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(1234)
+    path = str(tmp_path / "twelve.urdf")
+    for _ in range(100):
+        movable = _write_urdf(path, rng, 18, branch_prob=0.1)
+        if len(movable) >= 12:
+            t = urdf.compile_urdf(path, movable[:12])
+            if t.depth_first_schedule()[3] <= 2:
+                break
+    n, F = t.n_dof, t.n_frames
+    assert n == 12
+    specs = [D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, F - 1,
+                        [0.3, 0.6, 0.075, 0.05, 0.03, 1.0, 0.5, 1.0, 0.02], goal_len=3),
+             D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, [1.0, 0.005, 0.3]),
+             D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, [0.3, 1.0], vec_a=np.full(n, -2.0), vec_b=np.full(n, 2.0)),
+             D.LeafSpec(D.LEAF_JOINT_VELOCITY_CAP, D.TASKMAP_IDENTITY, -1, [0.5, 0.15, 5.0, 0.05]),
+             D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, F - 1,
+                        [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001]),
+             D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, F // 2,
+                        [0.0, 50.0, 0.04, 0.01, 0.01, 800.0, 0.01, 0.5, 1.0, 0.02, 0.001])]
+    desc = D.build_desc(t, specs)
+    eng = Engine(desc, 0)
+    sph = np.concatenate([rng.uniform(-1, 1, (6, 3)) + [0, 0, 6.0], rng.uniform(0.05, 0.1, (6, 1))], axis=1).astype(np.float32)
+    for R in (5, 9000):          # one block / beyond the hex mapping's usual fleet range
+        q = rng.uniform(-1.2, 1.2, (R, n)).astype(np.float32)
+        q[: min(R, 3), 0] = 1.95                                   # inside a joint-limit band
+        qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+        goal = rng.uniform(-0.5, 0.5, (R, 3)).astype(np.float32)
+        M = torch.empty((R, n, n), dtype=torch.float64, device="cuda")
+        out = eng.step(torch.from_numpy(q), torch.from_numpy(qd), torch.from_numpy(goal),
+                       obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), M=M)
+        torch.cuda.synchronize()
+        sub = slice(0, min(R, 400))
+        ref = O.step(desc, q[sub], qd[sub], goal[sub], spheres=sph)
+        assert np.abs(M.cpu().numpy()[sub] - ref["M"]).max() < 5e-6 * max(1.0, np.abs(ref["M"]).max())
+        err = np.abs(out.cpu().numpy()[sub] - ref["qdd64"]).max(axis=1)
+        assert (err <= ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))).all(), err.max()
+    # refused combinations name their reason
+    for bad, word in ((D.build_desc(t, specs, "pinv"), b"PINV"), (D.build_desc(t, specs[:1]), b"inertia")):
+        with pytest.raises(_native.Rmp2Error) as e:
+            Engine(bad, 0)
+        assert word in str(e.value).encode()
