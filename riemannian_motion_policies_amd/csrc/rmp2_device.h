@@ -1,12 +1,10 @@
 // rmp2_device.h -- device-side building blocks of the RMP2 control step (gfx950).
 //
-// Execution model: ONE LANE OWNS ONE ROBOT.  A wave walks the kinematic tree once
-// (depth-first schedule compiled on the host), keeps the running frame state in VGPRs,
-// the per-dof joint axes/origins and the q/qd tile in LDS (lane-private columns, bank
-// conflict free), evaluates every leaf attached to a frame while the walk passes it, and
-// accumulates the pulled-back metric in fp64 registers.  Everything that is identical for
-// all robots of the fleet (the program, leaf parameters, the shared obstacle table) is
-// wave-uniform and is fetched through the scalar cache (s_load) -- no VGPR, no LDS.
+// Shared by the three mappings of robots to lanes (rmp2_hex.h: 16 lanes per robot; rmp2_quad.h: 4; the
+// lane-per-robot kernels in rmp2_hip.hip): the compiled program records, the kernel argument blocks, the
+// lane-per-robot frame visit and the accurate (libm) leaf functions.  Everything that is identical for all robots
+// of the fleet (the program, leaf parameters, the shared obstacle table) is wave-uniform: the lane / quad kernels
+// fetch it through the scalar cache (s_load), the hex kernel stages a packed copy in LDS.
 //
 // Reference restated (file:line) -- see also include/rmp2.h:
 //   local/world transforms   kinematics.py:214-247 (T_constant @ T_variable, ordered product)

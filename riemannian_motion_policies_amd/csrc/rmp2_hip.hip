@@ -1,9 +1,11 @@
-// rmp2_hip.hip -- kernels + C ABI of the MI355X RMP2 engine (see include/rmp2.h).
+// rmp2_hip.hip -- the C ABI of the MI355X RMP2 engine (include/rmp2.h), the program compiler, the kernel
+// dispatch and the lane-per-robot kernels.
 //
-// One control step = ONE kernel launch: FK walk -> per-frame Jacobian columns and J-dot-qd ->
+// One control step = ONE kernel launch: forward kinematics -> per-frame Jacobian columns and J-dot-qd ->
 // leaf (xdd, A) evaluation -> pull-back J^T A J / J^T A (xdd - c) -> sum over leaves (fp64) ->
-// resolve (fp64 LU, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
-// and step: q, qd in, qdd out (+ goal): 120 B for the Panda.
+// resolve (fp64 elimination, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
+// and step: q, qd in, qdd out (+ goal): 120 B for the Panda.  Which kernel runs a step is decided
+// by fleet size in dispatch_solve(): rmp2_hex.h (<= 8192 robots), rmp2_quad.h, or rmp2_step_kernel below.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
