@@ -74,7 +74,8 @@ struct DevProgram {
   // tables of the 16-lanes-per-robot kernel (rmp2_hex.h): the tree as parent pointers instead of a walk order
   struct Hex {
     int32_t n_levels;                 // pointer-jumping rounds: smallest L with 2^L >= deepest chain
-    int32_t pad_[3];
+    int32_t is_chain;                 // 1: op k's parent is op k - 1 for every k (a serial chain in program order)
+    int32_t pad_[2];
     int32_t jump[5][kMaxOps];         // jump[l][k]: the op 2^l levels above op k, -1 = above the base
     uint32_t op_anc[kMaxOps];         // bit j: op j is op k itself or one of its ancestors
   } hex;

@@ -39,6 +39,12 @@ __device__ __forceinline__ float hex_sum(float v) {
   v += dpp<kRowMirror>(v);
   return v;
 }
+// lane i of a 16-lane row reads lane i - SH of the same row, 0 below the row's first lane (DPP row_shr)
+template <int SH>
+__device__ __forceinline__ float row_shr(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x110 + SH, 0xF, 0xF, true));
+}
 __device__ __forceinline__ double hex_maxd(double v) {
   v = fmax(v, dppd<kXor1>(v));
   v = fmax(v, dppd<kXor2>(v));
@@ -304,8 +310,25 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
       for (int c = 0; c < 6; ++c) x[slot][c] = acc[slot][c];
     hex_sync();
   };
+  // serial chains in program order (frame k in lane k, parent in lane k - 1, at most 16 frames): the ancestor sum is
+  // an inclusive prefix sum along the lanes of the row -- four DPP row_shr steps per component, no LDS round trip
+  const bool dpp_chain = SLOTS == 1 && hdr.is_chain;  // wave-uniform
+  auto chain_prefix = [&](float (&x)[SLOTS][6]) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      float v = x[0][c];
+      v += row_shr<1>(v);
+      v += row_shr<2>(v);
+      v += row_shr<4>(v);
+      v += row_shr<8>(v);
+      x[0][c] = v;
+    }
+  };
   RMP2_KSTAMP();  // K: per-op terms formed
-  ancestor_sum(X);  // X = (W_k, B_k)
+  if (dpp_chain)
+    chain_prefix(X);
+  else
+    ancestor_sum(X);  // X = (W_k, B_k)
   RMP2_KSTAMP();  // K: first sum done
   float vk[SLOTS][3], Y[SLOTS][6];
 #pragma unroll
@@ -326,7 +349,10 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
     }
   }
   RMP2_KSTAMP();  // K: second terms formed
-  ancestor_sum(Y);  // Y = (AL_k, C_k)
+  if (dpp_chain)
+    chain_prefix(Y);
+  else
+    ancestor_sum(Y);  // Y = (AL_k, C_k)
 #pragma unroll
   for (int slot = 0; slot < SLOTS; ++slot) {
     if (on[slot]) {

@@ -776,6 +776,7 @@ struct rmp2_handle {
   int hex_levels = 0;
   int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
   int n_fk_leaves = 0;
+  int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
   int hex_blob16 = 0;          // its size in 16-byte units
   std::vector<int> distance_leaves;
@@ -931,6 +932,9 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     int L = 0;
     while ((1 << L) < deepest) ++L;
     P.hex.n_levels = L;
+    P.hex.is_chain = 1;
+    for (int k = 0; k < F; ++k)
+      if (parent_op[k] != k - 1) P.hex.is_chain = 0;
     for (int l = 0; l < 5; ++l)
       for (int k = 0; k < kMaxOps; ++k) P.hex.jump[l][k] = -1;
     for (int k = 0; k < F; ++k) P.hex.jump[0][k] = parent_op[k];
@@ -1073,7 +1077,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
@@ -1098,7 +1102,7 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
   const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   if (o.capsule)
     hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
@@ -1244,6 +1248,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
     h->hex_waves = (we && std::atoi(we) == 1) ? 1 : 4;
   }
   h->n_fk_leaves = P.n_fk_leaves;
+  h->hex_is_chain = P.hex.is_chain;
   h->rev_mask = P.rev_mask;
   {
     const char* kenv = std::getenv("RMP2_KERNEL");

@@ -284,6 +284,7 @@ struct QuadHdr {
   uint32_t rev_mask;
   int32_t n_levels;  // pointer-jumping rounds (rmp2_hex.h only)
   int32_t n_fk;      // leaves on FK task maps (rmp2_hex.h only)
+  int32_t is_chain;  // every frame's parent is the previous frame of the program (rmp2_hex.h only)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * 16 * n_ops; }
