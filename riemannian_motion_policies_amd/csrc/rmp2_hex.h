@@ -45,6 +45,12 @@ __device__ __forceinline__ float row_shr(float v) {
   const int i = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x110 + SH, 0xF, 0xF, true));
 }
+// as row_shr, but lanes without a source lane receive `fill`
+template <int SH>
+__device__ __forceinline__ float row_shr_or(float v, float fill) {
+  const int i = __builtin_bit_cast(int, v), f = __builtin_bit_cast(int, fill);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(f, i, 0x110 + SH, 0xF, 0xF, false));
+}
 __device__ __forceinline__ double hex_maxd(double v) {
   v = fmax(v, dppd<kXor1>(v));
   v = fmax(v, dppd<kXor2>(v));
@@ -192,9 +198,37 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
   }
   RMP2_KSTAMP();  // K: local transforms done
   // ---- stage 2 ----
+  // serial chains in program order (frame k in lane k, parent in lane k - 1, at most 16 frames): the ancestor 2^l
+  // levels up sits 2^l lanes down the row -- its transform arrives through DPP row_shr operands (lanes without
+  // such an ancestor receive the identity), no LDS round trip
+  const bool dpp_chain = SLOTS == 1 && hdr.is_chain;  // wave-uniform
+  if (dpp_chain) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < hdr.n_levels) {
+        float Pr[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+          Pr[c] = (l == 0)   ? row_shr_or<1>(Tm[0][c], (c == 0 || c == 4 || c == 8) ? 1.f : 0.f)
+                  : (l == 1) ? row_shr_or<2>(Tm[0][c], (c == 0 || c == 4 || c == 8) ? 1.f : 0.f)
+                  : (l == 2) ? row_shr_or<4>(Tm[0][c], (c == 0 || c == 4 || c == 8) ? 1.f : 0.f)
+                             : row_shr_or<8>(Tm[0][c], (c == 0 || c == 4 || c == 8) ? 1.f : 0.f);
+        float Tn[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            Tn[3 * r + c] = Pr[3 * r] * Tm[0][c] + Pr[3 * r + 1] * Tm[0][3 + c] + Pr[3 * r + 2] * Tm[0][6 + c];
+          Tn[9 + r] = Pr[3 * r] * Tm[0][9] + Pr[3 * r + 1] * Tm[0][10] + Pr[3 * r + 2] * Tm[0][11] + Pr[9 + r];
+        }
+#pragma unroll
+        for (int c = 0; c < 12; ++c) Tm[0][c] = Tn[c];
+      }
+    }
+  }
 #pragma unroll
   for (int l = 0; l < 5; ++l) {
-    if (l < hdr.n_levels) {  // wave-uniform
+    if (!dpp_chain && l < hdr.n_levels) {  // wave-uniform
       float* const src = (l & 1) ? Tb1 : Tb0;
 #pragma unroll
       for (int slot = 0; slot < SLOTS; ++slot) {
@@ -312,7 +346,6 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
   };
   // serial chains in program order (frame k in lane k, parent in lane k - 1, at most 16 frames): the ancestor sum is
   // an inclusive prefix sum along the lanes of the row -- four DPP row_shr steps per component, no LDS round trip
-  const bool dpp_chain = SLOTS == 1 && hdr.is_chain;  // wave-uniform
   auto chain_prefix = [&](float (&x)[SLOTS][6]) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
