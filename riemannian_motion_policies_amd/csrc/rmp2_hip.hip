@@ -5,7 +5,7 @@
 // leaf (xdd, A) evaluation -> pull-back J^T A J / J^T A (xdd - c) -> sum over leaves (fp64) ->
 // resolve (fp64 elimination, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
 // and step: q, qd in, qdd out (+ goal): 120 B for the Panda.  Which kernel runs a step is decided
-// by fleet size in dispatch_solve(): rmp2_hex.h (<= 8192 robots), rmp2_quad.h, or rmp2_step_kernel below.
+// by fleet size in dispatch_solve(): rmp2_hex.h (<= 12288 robots), rmp2_quad.h, or rmp2_step_kernel below.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1158,9 +1158,10 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
   //  * hex (16 lanes per robot): the latency build for fleets that leave SIMDs idle under the quad mapping.
   const bool hex_ok = !h->has_point && h->goal_floats <= 16 && !h->strict && !h->likely_singular;
-  // measured (profiles/): hex wins up to 2 waves per SIMD (R <= 8192: 12.0 vs 14.5 us for the 3-leaf set and 23 vs
-  // 43 us for the cluttered set at R = 4096), the quad / lane kernels beyond
-  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 2048 * kHexRobots)) &&
+  // measured (profiles/): hex wins up to 3 waves per SIMD (R <= 12288: 13.0 vs 14.5 us for the 3-leaf set and 41.6 vs
+  // 42.6 us for the cluttered set at R = 12288; 8.9 vs 14.1 and 20.7 vs 40.0 us at R = 4096), the quad / lane kernels
+  // beyond (R = 16384: 16.4 vs 14.5 and 46.8 vs 42.5 us)
+  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 3072 * kHexRobots)) &&
       launch_hex<N>(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
