@@ -125,15 +125,24 @@ def test_closed_loop_goal_reaching(hip_lib):
     assert (dist < 0.02).float().mean() > 0.95, f"only {(dist < 0.02).float().mean():.2f} reached the goal (median {dist.median():.3f})"
 
 
+@pytest.mark.parametrize("kernel", ["hex", "quad"])
 @pytest.mark.parametrize("workload", ["config2", "config3"])
-def test_fused_rollout_matches_step_loop(hip_lib, workload):
+def test_fused_rollout_matches_step_loop(hip_lib, workload, kernel):
     """rmp2_rollout (K control steps + plant ticks inside one launch) against the same loop
     driven from the host with rmp2_step; same arithmetic (fma plant), so agreement is ~1e-6."""
     import torch
     from riemannian_motion_policies_amd import configs as Cf
     from riemannian_motion_policies_amd.engine import Engine
     _, desc = Cf.config2() if workload == "config2" else Cf.config3()
-    eng = Engine(desc, 0)
+    old_env = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel            # both mappings carry the rollout loop (read at rmp2_create)
+    try:
+        eng = Engine(desc, 0)
+    finally:
+        if old_env is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old_env
     R, sub, dt = 333, 10, 0.01
     rng = np.random.default_rng(9)
     s = Cf.sample_panda_states(rng, R)
