@@ -84,7 +84,7 @@ struct HexLds {
   static constexpr int kSys = kRow + kHexRobots * kRowStride;           // [4][kSysStride]
   static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
   // dynamic: T0 [4][n_ops][12] | T1 [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
-  //   ops | leaves | fk list | id list | leaf ops | jump[5][32] | dof_op[16] | dof_anc[16] | goal tile [4][16]
+  //   HexCtl | HexOp | leaves (execution order) | leaf-frame records | jump | op_anc
 };
 
 // bytes of dynamic LDS a launch needs (host side)
@@ -454,10 +454,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   HexCtl* const s_ctl = reinterpret_cast<HexCtl*>(stage_base);
   HexOp* const s_hops = reinterpret_cast<HexOp*>(s_ctl + n_ops);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_hops + n_ops);
-  int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
-  int32_t* const s_id = s_fk + hdr.n_fk;
-  int32_t* const s_lo = s_id + n_id;
-  int32_t* const s_jump = s_lo + n_lo;
+  const int4* const s_lo = reinterpret_cast<const int4*>(s_leaves + hdr.n_leaves);  // (op, anc dofs, first leaf, count)
+  int32_t* const s_jump = reinterpret_cast<int32_t*>(const_cast<int4*>(s_lo) + n_lo);
   uint32_t* const s_op_anc = reinterpret_cast<uint32_t*>(s_jump + hdr.n_levels * n_ops);
 
   // ---- prologue: one burst of loads brings the state tile, the obstacle table and the program on chip ----
@@ -560,11 +558,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 
   // ---- leaves on FK task maps, frame by frame -----------------------------------------------------------
   for (int t = 0; t < n_lo; ++t) {
-    const int k = uni<true>(s_lo[t]);
+    const int4 lo = s_lo[t];
+    const int k = uni<true>(lo.x);
     struct {
       uint32_t anc_mask;
       int leaf_begin, leaf_count;
-    } op = {(uint32_t)uni<true>((int)s_ctl[k].anc_mask), uni<true>(s_ctl[k].leaf_begin), uni<true>(s_ctl[k].leaf_count)};
+    } op = {(uint32_t)uni<true>(lo.y), uni<true>(lo.z), uni<true>(lo.w)};
     const float4 tp = reinterpret_cast<const float4*>(TW + k * 12)[2];
     const float4* va4 = reinterpret_cast<const float4*>(VAb + (g * n_ops + k) * 8);
     const float4 f0 = va4[0], f1 = va4[1];
@@ -590,7 +589,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       col[j][0] = c4.x, col[j][1] = c4.y, col[j][2] = c4.z;
     }
     for (int li = 0; li < op.leaf_count; ++li) {
-      const DevLeaf& lf = s_leaves[uni<true>(s_fk[op.leaf_begin + li])];
+      const DevLeaf& lf = s_leaves[op.leaf_begin + li];  // staged in execution order
       LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);
       lh.kind = uni<true>(lh.kind);
       lh.taskmap = uni<true>(lh.taskmap);
@@ -664,7 +663,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const int ii = (s < N) ? s : 0;
     const float qi_ = my_q[ii], qdi = (s < N) ? my_qd[ii] : 0.f;
     for (int li = 0; li < n_id; ++li) {
-      const DevLeaf& lfr = s_leaves[uni<true>(s_id[li])];
+      const DevLeaf& lfr = s_leaves[hdr.n_fk + li];  // identity-map leaves follow the FK leaves
       const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);
       const int kind = uni<true>(lh.kind), goal_offset = uni<true>(lh.goal_offset);
       const float* P = lh.P;

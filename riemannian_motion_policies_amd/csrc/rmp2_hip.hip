@@ -1268,7 +1268,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->d_prog_full, sizeof(DevProgram));
   if (e == hipSuccess) e = hipMemcpy(h->d_prog_full, &Pfull, sizeof(DevProgram), hipMemcpyHostToDevice);
   {
-    // hex kernel: one contiguous blob = [ops | HexOps | leaves | fk list | id list | leaf ops | jump | op_anc]
+    // hex kernel: one contiguous blob = [HexCtl | HexOp | leaves in execution order | leaf-frame records | jump | op_anc]
     std::vector<unsigned char> blob;
     auto put = [&blob](const void* p, size_t n) {
       const unsigned char* b = static_cast<const unsigned char*>(p);
@@ -1280,11 +1280,17 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
       put(&c, sizeof(c));
     }
     put(hops.data(), sizeof(HexOp) * hops.size());
-    put(P.leaves, sizeof(DevLeaf) * P.n_leaves);
-    // int tables, compact: fk list | id list | leaf ops | jump[n_levels][n_ops] | op_anc[n_ops], padded to 16 bytes
-    put(P.fk_leaves, sizeof(int32_t) * P.n_fk_leaves);
-    put(P.id_leaves, sizeof(int32_t) * P.n_id_leaves);
-    put(P.leaf_ops, sizeof(int32_t) * P.n_leaf_ops);
+    // leaf records in EXECUTION order (FK leaves grouped by frame, then the identity-map leaves): the kernel
+    // indexes them directly -- every indirection through a list is one more dependent LDS round trip per leaf
+    for (int i = 0; i < P.n_fk_leaves; ++i) put(&P.leaves[P.fk_leaves[i]], sizeof(DevLeaf));
+    for (int i = 0; i < P.n_id_leaves; ++i) put(&P.leaves[P.id_leaves[i]], sizeof(DevLeaf));
+    // one 16-byte record per leaf-bearing frame: (op, ancestor dofs, first leaf, leaf count)
+    for (int t = 0; t < P.n_leaf_ops; ++t) {
+      const DevOp& o = P.ops[P.leaf_ops[t]];
+      const int32_t rec[4] = {P.leaf_ops[t], (int32_t)o.anc_mask, o.leaf_begin, o.leaf_count};
+      put(rec, sizeof(rec));
+    }
+    // int tables: jump[n_levels][n_ops] | op_anc[n_ops], padded to 16 bytes
     for (int l = 0; l < P.hex.n_levels; ++l) put(P.hex.jump[l], sizeof(int32_t) * P.n_ops);
     put(P.hex.op_anc, sizeof(uint32_t) * P.n_ops);
     while (blob.size() % 16) blob.push_back(0);
