@@ -17,6 +17,8 @@
  *   - every call returns 0 on success or a negative RMP2_ERR_* code; the message is
  *     available from rmp2_last_error().
  *   - a handle is bound to one device; calls on one handle must not race (thread-compatible).
+ *     rmp2_create and the launching calls make that device the calling thread's current HIP device
+ *     (as hipSetDevice would) and leave it so; rmp2_destroy restores the caller's.
  *   - there is NO host/CPU execution path in this library.  If no HIP device is usable,
  *     rmp2_create() fails with RMP2_ERR_NO_DEVICE.
  */

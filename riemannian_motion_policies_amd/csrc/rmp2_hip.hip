@@ -1311,12 +1311,15 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
 
 int rmp2_destroy(rmp2_handle* h) {
   if (!h) return RMP2_OK;
+  int prev = -1;  // the caller's current device is left as it was
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
   (void)hipSetDevice(h->device);
   if (h->d_prog) (void)hipFree(h->d_prog);
   if (h->d_prog_full) (void)hipFree(h->d_prog_full);
   if (h->d_hex_blob) (void)hipFree(h->d_hex_blob);
   if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
   delete h;
   return RMP2_OK;
 }
