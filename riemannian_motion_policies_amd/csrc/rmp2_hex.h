@@ -77,20 +77,20 @@ struct HexLds {
   static constexpr int kOut = 2 * kHexRobots * N;                       // [4][N]
   static constexpr int kDof = (3 * kHexRobots * N + 3) & ~3;            // [4][N][8]: world axis z_j _, joint origin o_j _
   static constexpr int kCol = kDof + kHexRobots * N * 8;                // [4][16][4]: column of dof s, current frame
-  static constexpr int kXch = kCol + kHexRobots * kHex * 4;             // [4][16][4]: identity-leaf exchange
+  static constexpr int kXch = kCol;                                     // [4][16][4]: identity-leaf exchange (the FK-leaf phase is over)
   static constexpr int kRowStride = (2 * (N + 1) + 3) & ~3;             // one pivot row [A_k | f_k] as doubles
   static constexpr int kRow = kXch + kHexRobots * kHex * 4;             // [4][kRowStride]
   static constexpr int kSysStride = 2 * N * (N + 1);                    // the whole system [N][N+1] as doubles
   static constexpr int kSys = kRow + kHexRobots * kRowStride;           // [4][kSysStride]
   static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
-  // dynamic: T0 [4][n_ops][12] | T1 [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
+  // dynamic: T [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
   //   HexCtl | HexOp | leaves (execution order) | leaf-frame records | jump | op_anc
 };
 
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
 inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats) {
-  const size_t per_wave = HexLds<N>::kFloats + 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots +
+  const size_t per_wave = HexLds<N>::kFloats + kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots +
                           kHexRobots * RMP2_MAX_DOF;
   return sizeof(float) * (waves * per_wave + n_sphere_floats) + 16 * (size_t)blob16;
 }
@@ -135,13 +135,12 @@ __device__ __forceinline__ void stage_copy(T* dst, const T* __restrict__ src, in
 // Leaves world transforms in the returned buffer [n_ops][12], (v, a) in VA [n_ops][8], (z_j, o_j) in DOF [N][8].
 template <int N, int SLOTS>
 __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s, int g, const float* my_q,
-                                                       const float* my_qd, float* T0, float* T1, float* SCb, float* VAb,
+                                                       const float* my_qd, float* T0, float* SCb, float* VAb,
                                                        float* DOF, const HexCtl* s_ctl, const HexOp* s_hops,
                                                        const int32_t* s_jump, const uint32_t* s_op_anc,
                                                        unsigned long long* stp = nullptr, int* stn = nullptr) {
   const int n_ops = hdr.n_ops;
   float* const Tb0 = T0 + g * n_ops * 12;
-  float* const Tb1 = T1 + g * n_ops * 12;
   float4* const SC = reinterpret_cast<float4*>(SCb + g * n_ops * 8);
   float4* const VA = reinterpret_cast<float4*>(VAb + g * n_ops * 8);
   bool on[SLOTS], revk[SLOTS], prik[SLOTS];
@@ -229,7 +228,7 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
 #pragma unroll
   for (int l = 0; l < 5; ++l) {
     if (!dpp_chain && l < hdr.n_levels) {  // wave-uniform
-      float* const src = (l & 1) ? Tb1 : Tb0;
+      float* const src = Tb0;  // one buffer: a round's reads are issued before the next round's writes (same wave)
 #pragma unroll
       for (int slot = 0; slot < SLOTS; ++slot) {
         if (on[slot]) {
@@ -266,7 +265,7 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
       }
     }
   }
-  float* const TW = (hdr.n_levels & 1) ? Tb1 : Tb0;
+  float* const TW = Tb0;
 #pragma unroll
   for (int slot = 0; slot < SLOTS; ++slot) {
     if (on[slot]) {
@@ -436,12 +435,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   const int gi = min(g, n_live - 1);  // groups beyond the fleet's tail re-use the last live robot's inputs
 
   // ---- LDS carve-up -----------------------------------------------------------------------------------
-  // [per-wave static x WAVES | per-wave T0 T1 SC VA x WAVES | per-wave goal tile x WAVES | sphere table | program]
+  // [per-wave static x WAVES | per-wave T SC VA x WAVES | per-wave goal tile x WAVES | block qdd tile | sphere table | program]
   float* const wl = lds + wv * HexLds<N>::kFloats;                       // this wave's static region
-  const int dyn_per_wave = 2 * kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8;
+  const int dyn_per_wave = kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8;
   float* const T0 = lds + WAVES * HexLds<N>::kFloats + wv * dyn_per_wave;
-  float* const T1 = T0 + kHexRobots * n_ops * 12;
-  float* const SCb = T1 + kHexRobots * n_ops * 12;   // [4][n_ops][8] prefix-sum exchange
+  float* const SCb = T0 + kHexRobots * n_ops * 12;   // [4][n_ops][8] prefix-sum exchange
   float* const VAb = SCb + kHexRobots * n_ops * 8;   // [4][n_ops][8] (v, a) of every frame origin
   const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
@@ -544,9 +542,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
-    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
   else
-    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, T1, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
   RMP2_STAMP();  // 2: kinematics done
 
   // ---- the fp64 system, one row per lane: A[j] = M[s][j], fv = f[s] -------------------------------------
