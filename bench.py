@@ -240,7 +240,7 @@ def main():
                        "parallelism": f"robot-batch split x{world}" + (", RCCL all-gather of the sphere table per step" if exch else "")},
             "roofline": {"bound": "hbm", "achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach_bw / HBM_PEAK, "traffic": traffic,
-                         "kernel": ("rmp2_step_hex_kernel" if R <= 12288 else ("rmp2_step_quad_kernel" if wl["spheres"] else "rmp2_step_kernel")) + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)", "kernel_ms": kern_ms,
+                         "kernel": ("rmp2_step_hex_kernel" if R <= 20480 else ("rmp2_step_quad_kernel" if wl["spheres"] else "rmp2_step_kernel")) + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)", "kernel_ms": kern_ms,
                          "event_group_launches": grp, "event_group_ms_raw": raw_ms, "event_pair_ms_empty": floor_ms,
                          "algorithmic_bytes_per_robot_step": wl["bytes"],
                          "valu": {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",

@@ -5,7 +5,7 @@
 // leaf (xdd, A) evaluation -> pull-back J^T A J / J^T A (xdd - c) -> sum over leaves (fp64) ->
 // resolve (fp64 elimination, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
 // and step: q, qd in, qdd out (+ goal): 120 B for the Panda.  Which kernel runs a step is decided
-// by fleet size in dispatch_solve(): rmp2_hex.h (<= 12288 robots), rmp2_quad.h, or rmp2_step_kernel below.
+// by fleet size in dispatch_solve(): rmp2_hex.h (<= 20480 robots), rmp2_quad.h, or rmp2_step_kernel below.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1158,10 +1158,11 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
   //  * hex (16 lanes per robot): the latency build for fleets that leave SIMDs idle under the quad mapping.
   const bool hex_ok = !h->has_point && h->goal_floats <= 16 && !h->strict && !h->likely_singular;
-  // measured (profiles/): hex wins up to 3 waves per SIMD (R <= 12288: 13.0 vs 14.5 us for the 3-leaf set and 41.6 vs
-  // 42.6 us for the cluttered set at R = 12288; 8.9 vs 14.1 and 20.7 vs 40.0 us at R = 4096), the quad / lane kernels
-  // beyond (R = 16384: 16.4 vs 14.5 and 46.8 vs 42.5 us)
-  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 3072 * kHexRobots)) &&
+  // measured (rocprofv3 kernel times, 3-leaf set / cluttered set, hex vs the kernel chosen otherwise):
+  //   R =  4096:  8.7 / 19.7 us  vs  13.4 / 40.0        R = 20480: 16.9 / 47.2 us  vs  19.4 / 54.3
+  //   R = 12288: 12.2 / 30.4 us  vs  14.5 / 42.6        R = 24576: 19.6 / 54.7 us  vs  19.7 / 54.9
+  //   R = 16384: 14.9 / 41.6 us  vs  14.5 / 42.9        R = 32768: 25.8 / 71.8 us  vs  19.9 / 56.3
+  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 20480)) &&
       launch_hex<N>(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
