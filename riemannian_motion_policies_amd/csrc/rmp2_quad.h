@@ -581,26 +581,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const float4* fr4 = reinterpret_cast<const float4*>(loc + 16 * k);
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
       const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
-      // Jacobian columns of the frame origin (all dofs; wave-uniform activity mask)
-      float col[N][3];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if ((op.anc_mask >> j) & 1u) {
-          const float zj[3] = {zo[(j * 6 + 0) * kRobotsPerWave], zo[(j * 6 + 1) * kRobotsPerWave],
-                               zo[(j * 6 + 2) * kRobotsPerWave]};
-          if ((rev_mask >> j) & 1u) {
-            const float d[3] = {P3[0] - zo[(j * 6 + 3) * kRobotsPerWave], P3[1] - zo[(j * 6 + 4) * kRobotsPerWave],
-                                P3[2] - zo[(j * 6 + 5) * kRobotsPerWave]};
-            cross3(zj, d, col[j]);
-          } else {
-            col[j][0] = zj[0];
-            col[j][1] = zj[1];
-            col[j][2] = zj[2];
-          }
-        } else {
-          col[j][0] = col[j][1] = col[j][2] = 0.f;
-        }
-      }
       // the columns of MY rows (lane-dependent dof index -> dynamic LDS address)
       float mycol[ROWS][3];
 #pragma unroll
@@ -617,6 +597,18 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         const bool rev = (rev_mask >> ii) & 1u;
 #pragma unroll
         for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rev ? cr[c] : zj[c]) : 0.f;
+      }
+
+      // all columns in every lane: column j lives in lane (j & 3) as its local row j >> 2 -- three quad broadcasts per
+      // column instead of recomputing nine cross products per lane
+      float col[N][3];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const float v = mycol[j >> 2][cc];
+          col[j][cc] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
+        }
       }
 
       for (int li = 0; li < op.leaf_count; ++li) {
