@@ -84,8 +84,8 @@ def cpu_baseline(desc, s, spheres, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)  # ~17 ms of GPU time at the headline size: above timer noise
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--robots", type=int, default=0, help="robots per GPU (default: the workload's)")
     ap.add_argument("--solve", default="auto", choices=["auto", "pinv"])
