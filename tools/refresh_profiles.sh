@@ -1,3 +1,10 @@
+#!/bin/bash
+# Regenerates gpurun_out/r01c/* (bench lines, rocprofv3 kernel stats, PMC traffic, ablations, stamps, rollout and
+# launch-gap timings) in one go on a GPU box; the files judged are then copied into profiles/ (see profiles/README.md).
+# Needs the diagnostic build next to the product library (built here, it travels with the snapshot):
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -shared -Iinclude -DRMP2_STAMPS \
+#         riemannian_motion_policies_amd/csrc/rmp2_hip.hip -o tools/diag/librmp2_stamps.so
+# PMC passes are separate rocprofv3 runs (--pmc never combined with tracing), the program after "--" is python3 itself.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01c; mkdir -p $O
