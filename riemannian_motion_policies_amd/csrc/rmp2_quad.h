@@ -742,21 +742,35 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       } else {
         // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij)
         float zeta[N], xdd[N], cw[N], beta, wsc;
+        // each lane forms the terms of ITS dofs (i = sub + 4 m) once; the quad then broadcasts them (three DPP moves per
+        // dof and array) instead of every lane recomputing all n of them -- the divisions below are IEEE sequences
+        auto expand = [&](const float (&own)[ROWS], float (&full)[N]) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float v = own[j >> 2];
+            full[j] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
+          }
+        };
         if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
           // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) on the FULL matrix (quirk Q4):
           // off-diagonal = w, diagonal = w / (1 - ratio_i^2)
           const float cutoff = P[0] - P[1];
+          float xdd_o[ROWS], zeta_o[ROWS];
 #pragma unroll
-          for (int j = 0; j < N; ++j) {
-            const float qdj = my_qd[j];
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const float qdj = my_qd[i < N ? i : 0];
             const float dv = fabsf(qdj) - cutoff;
             const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
             const float acc = -fabsf(P[2] * dv) * sgn;
-            xdd[j] = (fabsf(qdj) < cutoff) ? 0.f : acc;
+            xdd_o[m] = (fabsf(qdj) < cutoff) ? 0.f : acc;
             const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
-            zeta[j] = P[3] / (1.0f - ratio * ratio);  // diagonal entry
-            cw[j] = P[3] / 1.0f;                      // off-diagonal entry
+            zeta_o[m] = P[3] / (1.0f - ratio * ratio);  // diagonal entry
           }
+          expand(xdd_o, xdd);
+          expand(zeta_o, zeta);
+#pragma unroll
+          for (int j = 0; j < N; ++j) cw[j] = P[3] / 1.0f;  // off-diagonal entry
           beta = 0.f;
           wsc = 0.f;
         } else if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
@@ -764,26 +778,32 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const float rr_ = 0.15f;
           const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
           const float iqd_max = (float)(60.0 / (20.0 * (2.0 * 3.14159265358979323846)));
-          float s2 = 0.f;
+          float cw_o[ROWS], zeta_o[ROWS], xdd_o[ROWS], s2 = 0.f;
 #pragma unroll
-          for (int j = 0; j < N; ++j) {
-            const float qj = my_q[j], qdj = my_qd[j];
-            const float irange = rcp1(lf.vb[j] - lf.va[j]);
-            const float du = (lf.vb[j] - qj) * irange;
-            const float dl = (qj - lf.va[j]) * irange;
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const int ii = i < N ? i : 0;
+            const float qj = my_q[ii], qdj = my_qd[ii];
+            const float irange = rcp1(lf.vb[ii] - lf.va[ii]);
+            const float du = (lf.vb[ii] - qj) * irange;
+            const float dl = (qj - lf.va[ii]) * irange;
             const float d = fminf(du, dl);
             const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
-            cw[j] = (j < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
-            zeta[j] = qdj * iqd_max;
-            s2 += zeta[j] * zeta[j];
-            xdd[j] = -P[0] * qj - P[1] * qdj;
+            cw_o[m] = (i < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
+            zeta_o[m] = (i < N) ? qdj * iqd_max : 0.f;
+            s2 += zeta_o[m] * zeta_o[m];
+            xdd_o[m] = -P[0] * qj - P[1] * qdj;
           }
+          s2 = quad_sum(s2);
           const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
           // soft norm h = |v| + (1/c) log(1 + exp(-2 c |v|)), c = 5   (helper/rmp_helper.py:62-65)
           const float hh = nrm + 0.2f * (0.693147182464599609375f * __builtin_amdgcn_logf(1.0f + exp1(-10.0f * nrm)));
           const float ihh = rcp1(hh);
 #pragma unroll
-          for (int j = 0; j < N; ++j) zeta[j] = zeta[j] * ihh;
+          for (int m = 0; m < ROWS; ++m) zeta_o[m] *= ihh;
+          expand(cw_o, cw);
+          expand(zeta_o, zeta);
+          expand(xdd_o, xdd);
           beta = 0.9f;
           wsc = 1.0f;
         } else {
