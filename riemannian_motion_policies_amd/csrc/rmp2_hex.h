@@ -79,9 +79,9 @@ struct HexLds {
   static constexpr int kCol = kDof + kHexRobots * N * 8;                // [4][16][4]: column of dof s, current frame
   static constexpr int kXch = kCol;                                     // [4][16][4]: identity-leaf exchange (the FK-leaf phase is over)
   static constexpr int kRowStride = (2 * (N + 1) + 3) & ~3;             // one pivot row [A_k | f_k] as doubles
-  static constexpr int kRow = kXch + kHexRobots * kHex * 4;             // [4][kRowStride]
+  static constexpr int kRow = kXch + kHexRobots * kHex * 4;             // [4][2][kRowStride]: two pivot rows per exchange
   static constexpr int kSysStride = 2 * N * (N + 1);                    // the whole system [N][N+1] as doubles
-  static constexpr int kSys = kRow + kHexRobots * kRowStride;           // [4][kSysStride]
+  static constexpr int kSys = kRow + kHexRobots * 2 * kRowStride;       // [4][kSysStride]
   static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
   // dynamic: T [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
   //   HexCtl | HexOp | leaves (execution order) | leaf-frame records | jump | op_anc
@@ -813,29 +813,69 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const double tiny = 1e-11 * scale;
     flagged = !(scale > 0.0) || !(scale < 1.7e308);
     double lmax = 0.0, inv_own = 0.0;
-    double* const ROW = reinterpret_cast<double*>(&wl[HexLds<N>::kRow + g * HexLds<N>::kRowStride]);
+    // Pivots are taken TWO per LDS exchange: lanes k and k + 1 publish their rows together, every lane applies step k
+    // to the copy of row k + 1 itself (n - k fp64 FMAs, redundantly) and then eliminates both columns from its own row
+    // -- half the dependent LDS round trips of one pivot per exchange.
+    double* const ROW0 = reinterpret_cast<double*>(&wl[HexLds<N>::kRow + g * 2 * HexLds<N>::kRowStride]);
+    double* const ROW1 = ROW0 + HexLds<N>::kRowStride / 2;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k + 1 < N; k += 2) {
+      const int k1 = k + 1;
       if (s == k) {
 #pragma unroll
-        for (int j = k; j < N; ++j) ROW[j] = A[j];
-        ROW[N] = fv;
+        for (int j = k; j < N; ++j) ROW0[j] = A[j];
+        ROW0[N] = fv;
+      }
+      if (s == k1) {
+#pragma unroll
+        for (int j = k; j < N; ++j) ROW1[j] = A[j];
+        ROW1[N] = fv;
       }
       hex_sync();
-      double rowk[N];
+      double r0[N], r1[N];
 #pragma unroll
-      for (int j = k; j < N; ++j) rowk[j] = ROW[j];
-      const double bk = ROW[N];
-      const bool bad = !(fabs(rowk[k]) > tiny);
+      for (int j = k; j < N; ++j) {
+        r0[j] = ROW0[j];
+        r1[j] = ROW1[j];
+      }
+      const double b0 = ROW0[N];
+      double b1 = ROW1[N];
+      const bool bad0 = !(fabs(r0[k]) > tiny);
+      const double inv0 = bad0 ? 0.0 : rcpd(r0[k]);
+      const double m10 = r1[k] * inv0;  // step k applied to the published copy of row k + 1
+#pragma unroll
+      for (int j = k1; j < N; ++j) r1[j] = fma(-m10, r0[j], r1[j]);
+      b1 = fma(-m10, b0, b1);
+      const bool bad1 = !(fabs(r1[k1]) > tiny);
+      const double inv1 = bad1 ? 0.0 : rcpd(r1[k1]);
+      flagged = flagged || bad0 || bad1;
+      inv_own = (s == k) ? inv0 : ((s == k1) ? inv1 : inv_own);
+      const double l0 = (s != k) ? A[k] * inv0 : 0.0;
+#pragma unroll
+      for (int j = k1; j < N; ++j) A[j] = fma(-l0, r0[j], A[j]);
+      fv = fma(-l0, b0, fv);
+      const double l1 = (s != k1) ? A[k1] * inv1 : 0.0;
+#pragma unroll
+      for (int j = k1 + 1; j < N; ++j) A[j] = fma(-l1, r1[j], A[j]);
+      fv = fma(-l1, b1, fv);
+      lmax = fmax(lmax, fmax((s > k) ? fabs(l0) : 0.0, (s > k1) ? fabs(l1) : 0.0));
+      hex_sync();  // the next pair of pivot rows overwrites ROW0 / ROW1
+    }
+    if (N & 1) {  // the last pivot of an odd system on its own
+      constexpr int k = N - 1;
+      if (s == k) {
+        ROW0[k] = A[k];
+        ROW0[N] = fv;
+      }
+      hex_sync();
+      const double pk = ROW0[k], bk = ROW0[N];
+      const bool bad = !(fabs(pk) > tiny);
       flagged = flagged || bad;
-      const double inv = bad ? 0.0 : rcpd(rowk[k]);
+      const double inv = bad ? 0.0 : rcpd(pk);
       inv_own = (s == k) ? inv : inv_own;
       const double l = (s != k) ? A[k] * inv : 0.0;
-      lmax = fmax(lmax, (s > k) ? fabs(l) : 0.0);
-#pragma unroll
-      for (int j = k + 1; j < N; ++j) A[j] = fma(-l, rowk[j], A[j]);
       fv = fma(-l, bk, fv);
-      hex_sync();  // the next pivot row overwrites ROW
+      hex_sync();
     }
     lmax = hex_maxd(lmax);
     flagged = flagged || !(lmax <= 1e4);
