@@ -70,6 +70,11 @@ __device__ __forceinline__ void hex_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Per-robot LDS regions are padded to a stride of 8 (mod 32) floats: the four robots of a wave touch the same element
+// of their own region in the same instruction, and with strides that are multiples of 32 floats (T: 12 n_ops, SC / VA:
+// 8 n_ops, COL: 64) those four 16-byte accesses would queue on the same banks.
+__host__ __device__ constexpr int hex_pad(int floats) { return floats + ((8 - floats % 32) + 32) % 32; }
+
 template <int N>
 struct HexLds {
   static constexpr int kQ = 0;                                          // [4][N]
@@ -79,7 +84,8 @@ struct HexLds {
   static constexpr int kCol = kDof + kHexRobots * N * 8;                // [4][16][4]: column of dof s, current frame
   static constexpr int kXch = kCol;                                     // [4][16][4]: identity-leaf exchange (the FK-leaf phase is over)
   static constexpr int kRowStride = (2 * (N + 1) + 3) & ~3;             // one pivot row [A_k | f_k] as doubles
-  static constexpr int kRow = kXch + kHexRobots * kHex * 4;             // [4][2][kRowStride]: two pivot rows per exchange
+  static constexpr int kColStride = hex_pad(kHex * 4);                  // per-robot stride of COL / XCH
+  static constexpr int kRow = kXch + kHexRobots * kColStride;           // [4][2][kRowStride]: two pivot rows per exchange
   static constexpr int kSysStride = 2 * N * (N + 1);                    // the whole system [N][N+1] as doubles
   static constexpr int kSys = kRow + kHexRobots * 2 * kRowStride;       // [4][kSysStride]
   static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
@@ -90,7 +96,8 @@ struct HexLds {
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
 inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats) {
-  const size_t per_wave = HexLds<N>::kFloats + kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8 + 16 * kHexRobots +
+  const size_t per_wave = HexLds<N>::kFloats + kHexRobots * hex_pad(n_ops * 12) + 2 * kHexRobots * hex_pad(n_ops * 8) +
+                          16 * kHexRobots +
                           kHexRobots * RMP2_MAX_DOF;
   return sizeof(float) * (waves * per_wave + n_sphere_floats) + 16 * (size_t)blob16;
 }
@@ -140,9 +147,9 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
                                                        const int32_t* s_jump, const uint32_t* s_op_anc,
                                                        unsigned long long* stp = nullptr, int* stn = nullptr) {
   const int n_ops = hdr.n_ops;
-  float* const Tb0 = T0 + g * n_ops * 12;
-  float4* const SC = reinterpret_cast<float4*>(SCb + g * n_ops * 8);
-  float4* const VA = reinterpret_cast<float4*>(VAb + g * n_ops * 8);
+  float* const Tb0 = T0 + g * hex_pad(n_ops * 12);
+  float4* const SC = reinterpret_cast<float4*>(SCb + g * hex_pad(n_ops * 8));
+  float4* const VA = reinterpret_cast<float4*>(VAb + g * hex_pad(n_ops * 8));
   bool on[SLOTS], revk[SLOTS], prik[SLOTS];
   int kk[SLOTS], jmp[SLOTS][5], qi[SLOTS];
   uint32_t ancm[SLOTS];
@@ -437,10 +444,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- LDS carve-up -----------------------------------------------------------------------------------
   // [per-wave static x WAVES | per-wave T SC VA x WAVES | per-wave goal tile x WAVES | block qdd tile | sphere table | program]
   float* const wl = lds + wv * HexLds<N>::kFloats;                       // this wave's static region
-  const int dyn_per_wave = kHexRobots * n_ops * 12 + 2 * kHexRobots * n_ops * 8;
+  const int dyn_per_wave = kHexRobots * hex_pad(n_ops * 12) + 2 * kHexRobots * hex_pad(n_ops * 8);
   float* const T0 = lds + WAVES * HexLds<N>::kFloats + wv * dyn_per_wave;
-  float* const SCb = T0 + kHexRobots * n_ops * 12;   // [4][n_ops][8] prefix-sum exchange
-  float* const VAb = SCb + kHexRobots * n_ops * 8;   // [4][n_ops][8] (v, a) of every frame origin
+  float* const SCb = T0 + kHexRobots * hex_pad(n_ops * 12);   // [4][n_ops][8] prefix-sum exchange
+  float* const VAb = SCb + kHexRobots * hex_pad(n_ops * 8);   // [4][n_ops][8] (v, a) of every frame origin
   const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
   float* const goal_base = lds + WAVES * (HexLds<N>::kFloats + dyn_per_wave);
@@ -531,8 +538,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   float* my_out = blk_out + (wv * kHexRobots + g) * n_dof;
   const float* my_goal = goal ? s_goal + gi * 16 : nullptr;
   float* const DOF = &wl[HexLds<N>::kDof + g * N * 8];
-  float4* const COL = reinterpret_cast<float4*>(&wl[HexLds<N>::kCol + g * kHex * 4]);
-  float4* const XCH = reinterpret_cast<float4*>(&wl[HexLds<N>::kXch + g * kHex * 4]);
+  float4* const COL = reinterpret_cast<float4*>(&wl[HexLds<N>::kCol + g * HexLds<N>::kColStride]);
+  float4* const XCH = reinterpret_cast<float4*>(&wl[HexLds<N>::kXch + g * HexLds<N>::kColStride]);
   uint32_t status = 0u;
 
   // closed-loop rollout (rmp2_rollout): n_iters control steps inside this launch; a plain step is one iteration
@@ -563,7 +570,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       int leaf_begin, leaf_count;
     } op = {(uint32_t)uni<true>(lo.y), uni<true>(lo.z), uni<true>(lo.w)};
     const float4 tp = reinterpret_cast<const float4*>(TW + k * 12)[2];
-    const float4* va4 = reinterpret_cast<const float4*>(VAb + (g * n_ops + k) * 8);
+    const float4* va4 = reinterpret_cast<const float4*>(VAb + g * hex_pad(n_ops * 8) + k * 8);
     const float4 f0 = va4[0], f1 = va4[1];
     const float P3[3] = {tp.y, tp.z, tp.w}, V3[3] = {f0.x, f0.y, f0.z}, A3[3] = {f0.w, f1.x, f1.y};
     // Jacobian column of MY dof at this frame's origin; all columns through LDS
