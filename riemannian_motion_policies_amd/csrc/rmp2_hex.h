@@ -51,6 +51,13 @@ __device__ __forceinline__ float row_shr_or(float v, float fill) {
   const int i = __builtin_bit_cast(int, v), f = __builtin_bit_cast(int, fill);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(f, i, 0x110 + SH, 0xF, 0xF, false));
 }
+__device__ __forceinline__ int hex_maxi(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kXor1, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kXor2, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kRowHalfMirror, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kRowMirror, 0xF, 0xF, false));
+  return v;
+}
 __device__ __forceinline__ double hex_maxd(double v) {
   v = fmax(v, dppd<kXor1>(v));
   v = fmax(v, dppd<kXor2>(v));
@@ -813,13 +820,17 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // (certification as lu_solve<N>, rmp2_solve.h: tiny pivot, multiplier growth, non-finite result -> careful path)
   bool flagged;
   {
-    double scale = 0.0;
+    // magnitudes are compared on the HIGH WORD of the doubles (monotone for non-negative values, NaN / Inf on top):
+    // integer max at fp32 rate instead of dependent fp64 max chains.  scale = max |M_ij| rounded down to its high word.
+    int scale_hi = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(A[j]));
-    scale = hex_maxd(scale);
+    for (int j = 0; j < N; ++j) scale_hi = max(scale_hi, __double2hiint(A[j]) & 0x7fffffff);
+    scale_hi = hex_maxi(scale_hi);
+    const double scale = __hiloint2double(scale_hi, 0);
     const double tiny = 1e-11 * scale;
     flagged = !(scale > 0.0) || !(scale < 1.7e308);
-    double lmax = 0.0, inv_own = 0.0;
+    int lmax_hi = 0;
+    double inv_own = 0.0;
     // Pivots are taken TWO per LDS exchange: lanes k and k + 1 publish their rows together, every lane applies step k
     // to the copy of row k + 1 itself (n - k fp64 FMAs, redundantly) and then eliminates both columns from its own row
     // -- half the dependent LDS round trips of one pivot per exchange.
@@ -865,7 +876,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 #pragma unroll
       for (int j = k1 + 1; j < N; ++j) A[j] = fma(-l1, r1[j], A[j]);
       fv = fma(-l1, b1, fv);
-      lmax = fmax(lmax, fmax((s > k) ? fabs(l0) : 0.0, (s > k1) ? fabs(l1) : 0.0));
+      lmax_hi = max(lmax_hi, max((s > k) ? (__double2hiint(l0) & 0x7fffffff) : 0, (s > k1) ? (__double2hiint(l1) & 0x7fffffff) : 0));
       hex_sync();  // the next pair of pivot rows overwrites ROW0 / ROW1
     }
     if (N & 1) {  // the last pivot of an odd system on its own
@@ -884,8 +895,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       fv = fma(-l, bk, fv);
       hex_sync();
     }
-    lmax = hex_maxd(lmax);
-    flagged = flagged || !(lmax <= 1e4);
+    lmax_hi = hex_maxi(lmax_hi);
+    flagged = flagged || !(lmax_hi <= __double2hiint(1e4));  // multiplier growth > 1e4 (NaN / Inf compare above it)
     const double x = fv * inv_own;
     const bool finite = (s >= n_dof) || (fabs(x) < 1.7e308);
     flagged = flagged || hex_any(!finite, g);
