@@ -158,10 +158,17 @@ def main():
         def one_step():
             launch()
     else:
+        # obstacle all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered
+        # (into the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
+        local_ready = torch.cuda.Event()
+        local_ready.record(torch.cuda.current_stream(dev))
+        exch.start(local, produced=local_ready)
+
         def one_step():
-            # obstacle all-gather on a side stream, joined by an event right before the kernel
-            exch.start(local)
-            eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=exch.finish()), out=out)
+            table = exch.finish()
+            eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=table), out=out)
+            exch.consumed()
+            exch.start(local, produced=local_ready)
 
     for _ in range(args.warmup):
         one_step()

@@ -34,35 +34,68 @@ def balanced_bounds(weights, world: int):
 
 
 class ObstacleExchange:
-    """All-gather of the per-rank slices of the shared sphere table [K, 4]."""
+    """All-gather of the per-rank slices of the shared sphere table [K, 4] (RCCL, side stream).
+
+    Two table buffers: the gather for step k + 1 can be in flight while the kernel of step k reads the other buffer
+    (`start` right after launching the step; `finish` at the top of the next one).  Ordering is by events only:
+    the gather waits for the producer of `local` and for the last kernel that read the buffer it overwrites; the
+    consuming step waits for the gather."""
 
     def __init__(self, spheres_per_rank: int, device, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device)
-        self.table = torch.zeros((self.world * spheres_per_rank, 4), dtype=torch.float32, device=self.device)
-        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
-        self.ready = torch.cuda.Event() if self.device.type == "cuda" else None
+        cuda = self.device.type == "cuda"
+        self.tables = [torch.zeros((self.world * spheres_per_rank, 4), dtype=torch.float32, device=self.device)
+                       for _ in range(2)]
+        self.side = torch.cuda.Stream(self.device) if cuda else None
+        self.ready = [torch.cuda.Event() for _ in range(2)] if cuda else None
+        self.reader_done = [None, None]   # event after the last kernel that read buffer b
+        self._reader_events = [torch.cuda.Event() for _ in range(2)] if cuda else None
+        self._next, self._pending, self._last = 0, [], None
 
-    def start(self, local: torch.Tensor) -> None:
-        """Issue the all-gather of `local` [K/world, 4] (asynchronously on the side stream)."""
+    @property
+    def table(self) -> torch.Tensor:
+        """The most recently finished table."""
+        return self.tables[self._last if self._last is not None else 0]
+
+    def start(self, local: torch.Tensor, produced=None) -> None:
+        """Issue the all-gather of `local` [K/world, 4] into the free buffer.  `produced`: event after which `local`
+        is valid (default: everything issued so far on the current stream)."""
+        b = self._next
+        self._next ^= 1
+        self._pending.append(b)
         if self.world == 1:
-            self.table.copy_(local)
+            self.tables[b].copy_(local)
             return
         if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.device))  # `local` was produced on the main stream
+            if produced is not None:
+                self.side.wait_event(produced)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+            if self.reader_done[b] is not None:
+                self.side.wait_event(self.reader_done[b])
             with torch.cuda.stream(self.side):
-                dist.all_gather_into_tensor(self.table, local.contiguous(), group=self.group)
-                self.ready.record(self.side)
+                dist.all_gather_into_tensor(self.tables[b], local.contiguous(), group=self.group)
+                self.ready[b].record(self.side)
         else:
-            dist.all_gather_into_tensor(self.table, local.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(self.tables[b], local.contiguous(), group=self.group)
 
     def finish(self) -> torch.Tensor:
-        """Make the main stream wait for the gathered table; returns it."""
+        """Make the current stream wait for the oldest outstanding gather; returns its table."""
+        b = self._pending.pop(0)
+        self._last = b
         if self.world > 1 and self.side is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.ready)
-        return self.table
+            torch.cuda.current_stream(self.device).wait_event(self.ready[b])
+        return self.tables[b]
+
+    def consumed(self) -> None:
+        """Call after launching the kernel that reads the table returned by the last finish()."""
+        if self.world > 1 and self.side is not None and self._last is not None:
+            ev = self._reader_events[self._last]
+            ev.record(torch.cuda.current_stream(self.device))
+            self.reader_done[self._last] = ev
 
 
 class Fleet:
@@ -78,7 +111,10 @@ class Fleet:
         if self.exchange is not None:
             self.exchange.start(local_spheres)
             obstacles = self.engine.obstacles(spheres=self.exchange.finish())
-        return self.engine.step(q, qd, goal, obstacles=obstacles, out=out)
+        res = self.engine.step(q, qd, goal, obstacles=obstacles, out=out)
+        if self.exchange is not None:
+            self.exchange.consumed()
+        return res
 
 
 class MixedFleet:

@@ -31,6 +31,13 @@ def _worker(rank, world, port, tmp):
     ex.start(torch.from_numpy(spheres[rank * (K // world):(rank + 1) * (K // world)]))
     table = ex.finish().numpy()
     assert np.array_equal(table, spheres), "all-gathered sphere table differs from the global table"
+    # pipelined use: two gathers in flight (double buffering), consumed in issue order
+    per = K // world
+    for shift in (1.0, 2.0):
+        ex.start(torch.from_numpy(spheres[rank * per:(rank + 1) * per] + np.float32(shift)))
+    for shift in (1.0, 2.0):
+        assert np.array_equal(ex.finish().numpy(), spheres + np.float32(shift))
+        ex.consumed()
     sl = slice(start, start + count)
     r = O.step(desc, s["q"][sl], s["qd"][sl], s["goal"][sl], spheres=table)
     np.save(os.path.join(tmp, f"qdd_{rank}.npy"), r["qdd"])
