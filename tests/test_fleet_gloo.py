@@ -29,7 +29,7 @@ def _worker(rank, world, port, tmp):
     start, count = shard_bounds(R, world, rank)
     ex = ObstacleExchange(K // world, "cpu")
     ex.start(torch.from_numpy(spheres[rank * (K // world):(rank + 1) * (K // world)]))
-    table = ex.finish().numpy()
+    table = ex.finish().numpy().copy()           # (a view of buffer 0, which the pipelined gathers below reuse)
     assert np.array_equal(table, spheres), "all-gathered sphere table differs from the global table"
     # pipelined use: two gathers in flight (double buffering), consumed in issue order
     per = K // world
