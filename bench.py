@@ -2,46 +2,56 @@
 """bench.py -- RMP2 control steps/s (batched robots) on N MI355X of one node.
 
 A "step" is one pass of the hot path (rmp2_step: FK -> J, Jdot qd -> leaves -> pull-back ->
-sum -> resolve) over this rank's robot batch, inputs and outputs resident in HBM.  Default
-workload = BASELINE.json configs[1]: Franka Panda, TargetAttractor + JointLimitAvoidance +
-JointDamping, 4096 robots per GPU, fp32 I/O (weak scaling: every rank steps its own 4096).
-`--workload config3` runs the cluttered set (8 control points x 32 spheres, 65536 robots per
-GPU) whose sphere table is produced distributed and all-gathered over RCCL every step.
+sum -> resolve) over this rank's robot batch, inputs and outputs resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W --workload config2|config3 --robots R]
+    python bench.py [--gpus N --steps K --warmup W --workload auto|config2|config3|config4|config5 --robots R]
 
-Rank 0 prints ONE JSON line (contract in the task description): whole-job steps/s, the HBM
-and VALU roofline fractions of the control-step kernel computed from the ALGORITHMIC bytes /
-flops of BASELINE.md section 3, and a CPU baseline (the oracle, OpenMP over robots, timed on
-this box's host cores on a bounded sample).
+Workloads (BASELINE.json configs[1..4]; weak scaling: the per-GPU fleet is fixed):
+  config3  (default at N = 1) Franka Panda cluttered set, 8 control points x 32 shared spheres, 65536 robots per
+           GPU -- the largest single-GPU configuration.  The latency figure of configs[1] (config 2, 4096 robots)
+           rides along as the nested "secondary" object of the same JSON line (same process, second engine).
+  config4  (default at N > 1) config 3 per GPU, the sphere table produced distributed (K / N spheres per rank) and
+           all-gathered over RCCL every step on a side stream, one step ahead of the kernel that consumes it.
+  config5  mixed fleet: 50/50 TwoJoint + Panda, ragged per-robot obstacle lists (CSR), 32768 robots per GPU;
+           the type-sorted fleet is cut across ranks so that the estimated work (sum of pairs) is balanced.
+  config2  Franka Panda, target + joint-limit + damping, 4096 robots per GPU.
+
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (fresh child processes, before
+anything in this process touches a GPU) and fails loudly when the node has fewer devices; under
+`torch.distributed.run` the ranks are taken from the environment.
+
+Rank 0 prints ONE JSON line (contract in the task description): whole-job steps/s, the roofline fractions of the
+control-step kernel from the ALGORITHMIC bytes / flops of BASELINE.md section 3, and (N = 1) a CPU baseline
+timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from riemannian_motion_policies_amd import configs as Cf  # noqa: E402
-from riemannian_motion_policies_amd import descriptor as D  # noqa: E402
-
 HBM_PEAK = 8.0e12        # B/s   MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK = 157.3e12     # flop/s fp32 vector (non-MFMA)
+PAIR_FLOPS = 240.0       # SURVEY 8(d): per distance pair
 # BASELINE.md section 3 / SURVEY 8(d): algorithmic bytes and flops per robot-step
 WORKLOADS = {
-    "config2": dict(builder=Cf.config2, robots=4096, bytes=120, flops=3.0e3, spheres=0,
+    "config2": dict(robots=4096, bytes=120, flops=3.0e3,
                     name="Franka Panda, target + joint-limit + damping, 4096 robots/GPU (BASELINE configs[1])"),
-    "config3": dict(builder=Cf.config3, robots=65536, bytes=120, flops=66.0e3, spheres=Cf.N_SPHERES,
+    "config3": dict(robots=65536, bytes=120, flops=66.0e3,
                     name="Franka Panda cluttered: 8 control points x 32 shared spheres, 65536 robots/GPU (BASELINE configs[2])"),
+    "config4": dict(robots=65536, bytes=120, flops=66.0e3,
+                    name="Franka Panda cluttered, 65536 robots/GPU, sphere table sharded over the ranks and "
+                         "all-gathered over RCCL every step (BASELINE configs[3])"),
+    "config5": dict(robots=32768, bytes=None, flops=None,
+                    name="mixed fleet 50/50 TwoJoint + Franka Panda, ragged per-robot obstacle lists k_r ~ U{0..32}, "
+                         "32768 robots/GPU, work-balanced cut (BASELINE configs[4])"),
 }
 
 
@@ -60,54 +70,225 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(desc, s, spheres, budget_s=10.0):
-    """Oracle (plain-C restatement, `port`) on the host cores, OpenMP over robots, bounded sample."""
+def lscpu_summary() -> str:
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        keep = {}
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
+                keep[k.strip()] = v.strip()
+        return "; ".join(f"{k}={v}" for k, v in keep.items())
+    except Exception:
+        return "lscpu unavailable"
+
+
+def cpu_baseline(workload: str, desc, table, s, spheres):
+    """The oracle on this box's host cores, on bounded samples of the same workload:
+       value / cores   plain-C restatement (`port`), OpenMP over robots, every core this process may use
+       threads_1       the same with one thread
+       reference_style_proxy   the torch-autograd restatement run the way the reference runs (one robot per
+                               call, FK re-differentiated per RMP) -- proxy, not TensorFlow"""
+    import ctypes
+    import numpy as np
     cores = host_cores()
-    os.environ["OMP_NUM_THREADS"] = str(cores)   # must be set before libgomp is loaded
+    os.environ["OMP_NUM_THREADS"] = str(cores)   # before libgomp is loaded
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     R = min(len(s["q"]), 4096)
     q, qd, goal = s["q"][:R], s["qd"][:R], s["goal"][:R]
     kw = dict(spheres=spheres) if spheres is not None else {}
-    O.step(desc, q[:64], qd[:64], goal[:64], **kw)  # warm-up / page-in
-    iters, t0 = 0, time.perf_counter()
-    while True:
-        O.step(desc, q, qd, goal, **kw)
-        iters += 1
+    O.step(desc, q[:64], qd[:64], goal[:64], **kw)  # warm-up / page-in (loads libgomp)
+    gomp = ctypes.CDLL("libgomp.so.1")
+
+    def timed(threads, robots, budget_s):
+        gomp.omp_set_num_threads(int(threads))
+        iters, t0 = 0, time.perf_counter()
+        while True:
+            O.step(desc, q[:robots], qd[:robots], goal[:robots], **kw)
+            iters += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or iters >= 5000:
+                return robots * iters / dt, iters, dt
+
+    v1, it1, dt1 = timed(1, min(R, 512), 4.0)
+    vN, itN, dtN = timed(cores, R, 8.0)
+    out = {"value": vN, "unit": "robot control steps/s", "cores": cores, "kind": "port",
+           "sample": f"{itN} steps of {R} robots, oracle/rmp2_oracle.c (gcc -O3 -march=native, OpenMP {cores} threads), {dtN:.1f} s",
+           "threads_1": {"value": v1, "cores": 1,
+                         "sample": f"{it1} steps of {min(R, 512)} robots, same C restatement, 1 thread, {dt1:.1f} s"},
+           "host": lscpu_summary() + f"; usable by this process: {cores}"}
+    try:
+        import torch_autodiff_oracle as TA
+        from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "kinematic_tables.json")))
+        fk = TA.UrdfForwardKinematicTorch(gold["panda"])
+        leaves = TA.leaves_from_desc(desc, table.frame_names)
+        pairs_of = None
+        if spheres is not None:
+            T = O.forward_kinematics(desc, q[:16], precision="f64")
+            frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+            origins = T[:, frames][:, :, :3, 3].astype(np.float32)
+            pl, po = Cf.pairs_from_spheres(origins, spheres)
+            dl, K = D.distance_leaf_indices(desc), spheres.shape[0]
+
+            def pairs_of(r):
+                return {li: (pl[r, k * K:(k + 1) * K], po[r, k * K:(k + 1) * K]) for k, li in enumerate(dl)}
+        n, t0 = 0, time.perf_counter()
+        while True:
+            r = n % 16
+            TA.evaluate_one(fk, leaves, q[r], qd[r], goal[r], pairs_of(r) if pairs_of else None)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt >= 10.0 and n >= 10) or n >= 100:
+                break
+        out["reference_style_proxy"] = {
+            "value": n / dt, "cores": 1, "kind": "proxy, not TensorFlow",
+            "sample": f"{n} control steps at R = 1 (one robot per call, FK re-differentiated per RMP, nested torch.autograd "
+                      f"as the reference nests GradientTapes), oracle/torch_autodiff_oracle.py, 1 thread, {dt:.1f} s"}
+    except Exception as e:  # the proxy is a reported extra, never a reason to lose the bench line
+        out["reference_style_proxy"] = {"value": None, "error": repr(e)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: start N fresh ranks (this process has not touched a GPU and never will)."""
+    import torch  # device_count() does not initialise the GPU runtime
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} HIP device(s); "
+              f"not silently running on fewer", file=sys.stderr)
+        return 2
+    import __graft_entry__ as ge
+    ge.build_hip()   # once, here (hipcc, no GPU), instead of N racing builds
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+class Timed:
+    """Warm-up, then EXACTLY `steps` steps between two fences (barrier + synchronize), MAX over ranks; HIP events on the
+    launch stream bracket groups of consecutive launches inside the timed region (an event pair costs about as much
+    GPU time as a third of a latency-bound launch, so it is amortised over a group and never subtracted)."""
+
+    def __init__(self, dev, use_dist):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.dev, self.use_dist = torch, dist, dev, use_dist
+
+    def fence(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    SETTLE_S = 0.05   # untimed set-up launches before the W warm-up steps: code objects resident, clocks ramped
+
+    def run(self, one_step, steps, warmup):
+        import numpy as np
+        torch = self.torch
+        t_settle, self.settle_launches = time.perf_counter(), 0
+        while time.perf_counter() - t_settle < self.SETTLE_S:
+            one_step()
+            self.settle_launches += 1
+            if self.settle_launches % 64 == 0:
+                torch.cuda.synchronize(self.dev)
+        for _ in range(warmup):
+            one_step()
+        grp = 8 if steps >= 16 else 1
+        n_groups = min(8, steps // grp)
+        starts = {int(round(k * (steps - grp) / max(n_groups - 1, 1))) for k in range(n_groups)}
+        ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sorted(starts)}
+        ends = {i + grp - 1: i for i in ev}
+        stream = torch.cuda.current_stream(self.dev)
+        self.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i in ev:
+                ev[i][0].record(stream)
+            one_step()
+            if i in ends:
+                ev[ends[i]][1].record(stream)
+        self.fence()
         dt = time.perf_counter() - t0
-        if dt >= budget_s or iters >= 5000:
-            break
-    return {"value": R * iters / dt, "unit": "robot control steps/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} steps of {R} robots, oracle/rmp2_oracle.c (gcc -O3 -march=native, OpenMP {cores} threads), {dt:.1f} s"}
+        if self.use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        raw_ms = float(np.median([a.elapsed_time(b) for a, b in ev.values()]))
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
+        for a, b in empty:
+            a.record(stream)
+            b.record(stream)
+        torch.cuda.synchronize(self.dev)
+        floor_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
+        kern_ms = raw_ms / grp if grp > 1 else max(raw_ms - floor_ms, 1e-6)
+        return dict(dt=dt, kernel_ms=kern_ms, grp=grp, raw_ms=raw_ms, floor_ms=floor_ms, settle=self.settle_launches)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)  # ~17 ms of GPU time at the headline size: above timer noise
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--robots", type=int, default=0, help="robots per GPU (default: the workload's)")
-    ap.add_argument("--solve", default="auto", choices=["auto", "pinv"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs, traffic):
+    ach_bw = per_launch_bytes / (kern["kernel_ms"] * 1e-3)
+    ach_fl = per_launch_flops / (kern["kernel_ms"] * 1e-3)
+    return {"bound": "hbm", "achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": ach_bw / HBM_PEAK, "traffic": traffic,
+            "kernel": kernel, "kernel_ms": kern["kernel_ms"],
+            "event_group_launches": kern["grp"], "event_group_ms_raw": kern["raw_ms"], "event_pair_ms_empty": kern["floor_ms"],
+            "setup_launches_before_warmup": kern.get("settle", 0),
+            "algorithmic_bytes_per_robot_step": bytes_rs,
+            "valu": {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": ach_fl / VALU_PEAK, "algorithmic_flops_per_robot_step": flops_rs},
+            "binding": "fp32 VALU issue (see DESIGN.md: 120 B per robot-step cannot load HBM; `valu` is the binding roof)"}
+
+
+def traffic_of(workload, R):
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        tj = json.load(open(tpath))
+        return tj.get("hbm_bytes_per_launch") if tj.get("robots") == R else None
+    except Exception:
+        return None
+
+
+def worker(args) -> int:
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from riemannian_motion_policies_amd import configs as Cf
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the RMP2 engine has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no HIP device {local_rank} on this node")
+    workload = args.workload
+    if workload == "auto":
+        workload = "config3" if world == 1 else "config4"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # under torchrun (RANK/WORLD_SIZE set) the process group is created even for one rank, so that the
-    # N > 1 code path (RCCL init, barriers, MAX-reduce of the time, obstacle all-gather) is the one
-    # exercised on a single-GPU box as well
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    # the process group exists whenever a launcher set RANK (even for one rank: RCCL init, barriers and the MAX-reduce
+    # are then exercised on a one-GPU box too) and for config4, whose defining element is the RCCL exchange
+    use_dist = "RANK" in os.environ or workload == "config4"
     if use_dist:
-        # keep stdout to the ONE JSON line: RCCL prints its version banner (and warnings) on fd 1 while the
-        # communicator is created, so fd 1 points at stderr until the first collective has completed
+        if "RANK" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+        # keep stdout to the ONE JSON line: RCCL prints its banner on fd 1 while the communicator is created
         sys.stdout.flush()
         saved_fd1 = os.dup(1)
         os.dup2(2, 1)
@@ -126,110 +307,81 @@ def main():
     if use_dist:
         dist.barrier()
     from riemannian_motion_policies_amd.engine import Engine
-    from riemannian_motion_policies_amd.fleet import ObstacleExchange
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard, ObstacleExchange
 
-    wl = WORKLOADS[args.workload]
+    timer = Timed(dev, use_dist)
+    wl = WORKLOADS[workload]
     R = args.robots or wl["robots"]
-    _, desc = wl["builder"](args.solve)
-    eng = Engine(desc, local_rank)
-
-    # synthetic inputs, SURVEY 8(d): seed 1 -> performance inputs (rank-offset so shards differ)
-    rng = np.random.default_rng(1 + 1000 * rank)
-    s = Cf.sample_panda_states(rng, R)
-    q, qd, goal = (torch.from_numpy(s[k]).to(dev) for k in ("q", "qd", "goal"))
-    out = torch.empty_like(q)
+    line_extra = {}
     spheres_np = None
-    exch = None
-    obstacles = None
-    if wl["spheres"]:
-        K = wl["spheres"]
-        spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
-        if use_dist:
-            if K % world:
-                raise SystemExit("sphere count must divide by the world size")
-            exch = ObstacleExchange(K // world, dev)
-            local = torch.from_numpy(spheres_np[rank * (K // world):(rank + 1) * (K // world)]).to(dev)
+    desc = table = s = None
+
+    if workload in ("config2", "config3", "config4"):
+        table, desc = (Cf.config2 if workload == "config2" else Cf.config3)(args.solve)
+        eng = Engine(desc, local_rank)
+        # synthetic inputs, SURVEY 8(d): seed 1 -> performance inputs (rank-offset so shards differ)
+        s = Cf.sample_panda_states(np.random.default_rng(1 + 1000 * rank), R)
+        q, qd, goal = (torch.from_numpy(s[k]).to(dev) for k in ("q", "qd", "goal"))
+        out = torch.empty_like(q)
+        if workload == "config2":
+            launch, _ = eng.bind(q, qd, goal, out=out)   # bare C-ABI call on fixed buffers
+            one_step = launch
         else:
-            obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
+            K = Cf.N_SPHERES
+            spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
+            if workload == "config3":
+                obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
+                launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
+                one_step = launch
+            else:
+                if K % world:
+                    raise SystemExit("sphere count must divide by the world size")
+                exch = ObstacleExchange(K // world, dev)
+                local = torch.from_numpy(spheres_np[rank * (K // world):(rank + 1) * (K // world)]).to(dev)
+                # all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered (into
+                # the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
+                local_ready = torch.cuda.Event()
+                local_ready.record(torch.cuda.current_stream(dev))
+                exch.start(local, produced=local_ready)
 
-    if exch is None:
-        launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)   # bare C-ABI call on fixed buffers
-
-        def one_step():
-            launch()
+                def one_step():
+                    tbl = exch.finish()
+                    eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tbl), out=out)
+                    exch.consumed()
+                    exch.start(local, produced=local_ready)
+        kern = timer.run(one_step, args.steps, args.warmup)
+        bytes_rs, flops_rs = wl["bytes"], wl["flops"]
+        per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
+        kernel_name = eng.last_kernel() + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)"
+        total_robots = R * world
+        parallelism = f"robot-batch split x{world}" + (
+            ", RCCL all-gather of the sphere table per step (side stream, double-buffered)" if workload == "config4" else "")
     else:
-        # obstacle all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered
-        # (into the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
-        local_ready = torch.cuda.Event()
-        local_ready.record(torch.cuda.current_stream(dev))
-        exch.start(local, produced=local_ready)
-
-        def one_step():
-            table = exch.finish()
-            eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=table), out=out)
-            exch.consumed()
-            exch.start(local, produced=local_ready)
-
-    for _ in range(args.warmup):
-        one_step()
-    # HIP events (on the stream the kernel is launched on) bracket GROUPS of `grp` consecutive launches of the
-    # timed region: an event pair costs ~4 us of GPU time by itself, as much as a third of one launch of the
-    # latency-bound kernel, so it is amortised over the group and its empty-pair reading is calibrated out.
-    # kernel_ms = elapsed / grp is the steady-state time per launch INCLUDING the idle gap between two dependent
-    # launches (~0.7 us) and 1/grp of an event pair; rocprofv3's kernel-trace average (profiles/) is the kernel alone.
-    grp = 8 if args.steps >= 16 else 1
-    n_groups = min(8, args.steps // grp)
-    starts = {int(round(k * (args.steps - grp) / max(n_groups - 1, 1))) for k in range(n_groups)}
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sorted(starts)}
-    ends = {i + grp - 1: i for i in ev}
-    stream = torch.cuda.current_stream(dev)
-
-    def fence():
+        # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, work-balanced cut across the ranks ----
+        shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve)
+        one_step = shard.step
+        kern = timer.run(one_step, args.steps, args.warmup)
+        # the dominant kernel (the Panda engine's) timed on its own right after the timed region, same buffers
+        kk = Timed(dev, False).run(shard.step_dominant, min(args.steps, 200), 10)
+        kern.update(kernel_ms=kk["kernel_ms"], grp=kk["grp"], raw_ms=kk["raw_ms"], floor_ms=kk["floor_ms"])
+        per_launch_bytes, per_launch_flops = shard.dominant_bytes, shard.dominant_flops
+        bytes_rs = per_launch_bytes / max(shard.dominant_robots, 1)
+        flops_rs = per_launch_flops / max(shard.dominant_robots, 1)
+        kernel_name = shard.dominant_kernel() + " (Panda engine of this rank's shard; timed on its own after the timed region)"
+        total_robots = R * world
+        parallelism = (f"type-sorted fleet cut x{world} by estimated work (fleet.balanced_bounds); "
+                       "one engine per robot type per rank; no data-path collective")
+        counts = torch.tensor([float(shard.n_two_joint), float(shard.n_panda), float(shard.work)], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            allc = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(allc, counts)
+        else:
+            allc = [counts]
+        line_extra["shards"] = [{"two_joint": int(c[0]), "panda": int(c[1]), "est_work_Mflop": float(c[2]) / 1e6} for c in allc]
 
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i in ev:
-            ev[i][0].record(stream)
-        one_step()
-        if i in ends:
-            ev[ends[i]][1].record(stream)
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    raw_ms = float(np.median([a.elapsed_time(b) for a, b in ev.values()]))  # one group of `grp` launches
-    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
-    for a, b in empty:
-        a.record(stream)
-        b.record(stream)
-    torch.cuda.synchronize(dev)
-    floor_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
-    # conservative: the event pair's own cost (floor_ms, reported) is NOT subtracted when it is amortised over a
-    # group -- the per-launch figure then sits between the steady-state step time and rocprofv3's kernel average
-    kern_ms = raw_ms / grp if grp > 1 else max(raw_ms - floor_ms, 1e-6)
-
-    total_steps = R * world * args.steps
-    value = total_steps / dt
+    value = total_robots * args.steps / kern["dt"]
+    rc = 0
     if rank == 0:
-        per_launch_bytes = wl["bytes"] * R
-        per_launch_flops = wl["flops"] * R
-        ach_bw = per_launch_bytes / (kern_ms * 1e-3)
-        ach_fl = per_launch_flops / (kern_ms * 1e-3)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("robots") == R:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
             "metric": "RMP2 control steps/sec (batched robots)",
             "value": value,
@@ -237,29 +389,59 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": kern["dt"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (leaves, Jacobians, pull-back) + f64 (sum over leaves, resolve)",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "robots_per_gpu": R, "solve": args.solve,
-                       "parallelism": f"robot-batch split x{world}" + (", RCCL all-gather of the sphere table per step" if exch else "")},
-            "roofline": {"bound": "hbm", "achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach_bw / HBM_PEAK, "traffic": traffic,
-                         "kernel": ("rmp2_step_hex_kernel" if R <= 20480 else ("rmp2_step_quad_kernel" if wl["spheres"] else "rmp2_step_kernel")) + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)", "kernel_ms": kern_ms,
-                         "event_group_launches": grp, "event_group_ms_raw": raw_ms, "event_pair_ms_empty": floor_ms,
-                         "algorithmic_bytes_per_robot_step": wl["bytes"],
-                         "valu": {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",
-                                  "frac": ach_fl / VALU_PEAK, "algorithmic_flops_per_robot_step": wl["flops"]},
-                         "binding": "fp32 VALU / launch latency (see DESIGN.md: 120 B per robot-step cannot load HBM)"},
+            "config": {"workload": wl["name"], "workload_key": workload, "robots_per_gpu": R, "solve": args.solve,
+                       "parallelism": parallelism},
+            "roofline": roofline_obj(kernel_name, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs,
+                                     traffic_of("config3" if workload == "config4" else workload, R)),
         }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(desc, s, spheres_np)
+        line.update(line_extra)
+        if workload in ("config3", "config4") and not args.no_secondary:
+            # BASELINE configs[1] in the same process: the latency-bound fleet (4096 robots: one wave per SIMD)
+            t2, d2 = Cf.config2(args.solve)
+            eng2 = Engine(d2, local_rank)
+            s2 = Cf.sample_panda_states(np.random.default_rng(1), 4096)
+            q2, qd2, g2 = (torch.from_numpy(s2[k]).to(dev) for k in ("q", "qd", "goal"))
+            o2 = torch.empty_like(q2)
+            launch2, _ = eng2.bind(q2, qd2, g2, out=o2)
+            k2 = Timed(dev, False).run(launch2, 2000, 200)
+            w2 = WORKLOADS["config2"]
+            line["secondary"] = {
+                "workload": w2["name"], "robots": 4096, "value": 4096 * 2000 / k2["dt"], "unit": "robot control steps/s",
+                "steps": 2000, "warmup": 200, "ms_per_step": k2["dt"] / 2000 * 1e3, "n_gpus": 1,
+                "roofline": roofline_obj(eng2.last_kernel(), k2, w2["bytes"] * 4096, w2["flops"] * 4096, w2["bytes"], w2["flops"],
+                                         traffic_of("config2", 4096)),
+                "note": "latency regime: 1024 waves on 1024 SIMDs, ~3 us of the launch is dispatch floor (DESIGN.md section 5)"}
+        if not args.no_cpu_baseline and world == 1 and desc is not None:
+            line["cpu_baseline"] = cpu_baseline(workload, desc, table, s, spheres_np)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
+    ap.add_argument("--robots", type=int, default=0, help="robots per GPU (default: the workload's)")
+    ap.add_argument("--solve", default="auto", choices=["auto", "pinv"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ extern "C" {
 #define RMP2_ABI_VERSION 1
 
 #define RMP2_MAX_FRAMES 32  /* frames (= URDF joints) per robot type                    */
-#define RMP2_MAX_DOF 16     /* actuated joints per robot type (kernels exist for <= 9)   */
+#define RMP2_MAX_DOF 16     /* actuated joints per robot type                            */
 #define RMP2_MAX_LEAVES 48  /* leaf RMPs per set                                          */
 #define RMP2_MAX_PARAMS 12  /* scalar parameters per leaf                                 */
 
@@ -200,6 +200,11 @@ int rmp2_destroy(rmp2_handle *h);
 
 /* Last error message of `h` (or of the last failed rmp2_create when h == NULL). */
 const char *rmp2_last_error(const rmp2_handle *h);
+
+/* Name of the kernel (mapping of robots to lanes) the last rmp2_step / rmp2_rollout on `h` launched: which of the
+ * three mappings runs is decided per call from the fleet size and the RMP set.  Diagnostic:
+ * benchmarks and profiles name the kernel they measured from this instead of restating the dispatch rule. */
+const char *rmp2_last_kernel(const rmp2_handle *h);
 
 /* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
  *   q, qd       device [R][n_dof] fp32

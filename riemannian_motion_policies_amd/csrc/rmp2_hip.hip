@@ -786,6 +786,7 @@ struct rmp2_handle {
   bool pair_begin_valid = false;
   float* d_scratch = nullptr;  // rmp2_differentiate scratch
   size_t scratch_robots = 0;
+  mutable const char* last_kernel = "none";  // mapping the last control step / rollout was launched with (rmp2_last_kernel)
   std::string error;
 };
 
@@ -805,6 +806,15 @@ int fail(rmp2_handle* h, int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                      \
       return fail(h, RMP2_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
   } while (0)
+
+// Every launching entry point makes the handle's device the calling thread's current device first (include/rmp2.h,
+// "Rules of the boundary"): a process that drives two engines on two devices must not launch on whichever device the
+// last rmp2_create left current.
+int use_device(rmp2_handle* h) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
+  return RMP2_OK;
+}
 
 // Compile the descriptor into the device program: depth-first schedule with save/restore slots
 // (same algorithm as urdf.py:depth_first_schedule).
@@ -1048,6 +1058,8 @@ template <int N, int SLOTS, bool STRICT>
 void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                  const OutArgs& out, int R, hipStream_t s) {
   const int blocks = (R + kWave - 1) / kWave;
+  h->last_kernel = STRICT ? "rmp2_step_kernel<STRICT> (one lane per robot, Jacobi pseudo-inverse)"
+                          : "rmp2_step_kernel (one lane per robot)";
   if (h->has_point || o.capsule)
     hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT, true>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
                        o, out, R);
@@ -1082,6 +1094,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
+  h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP)                                                                              \
   hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, \
                      hdr, q, qd, goal, gs, o, out, ro, R)
@@ -1104,6 +1117,7 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
+  h->last_kernel = "rmp2_step_hex_kernel (16 lanes per robot)";
   if (o.capsule)
     hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
                        h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
@@ -1188,6 +1202,8 @@ size_t rmp2_sizeof_desc(void) { return sizeof(rmp2_desc); }
 size_t rmp2_sizeof_obstacles(void) { return sizeof(rmp2_obstacles); }
 
 const char* rmp2_last_error(const rmp2_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+const char* rmp2_last_kernel(const rmp2_handle* h) { return h ? h->last_kernel : "none"; }
 
 int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (!desc || !out) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
@@ -1337,10 +1353,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "goal_stride must be 0 (shared) or >= goal_floats");
   }
   hipStream_t s = (hipStream_t)stream;
-  {
-    int cur = -1;  // the launch goes to the calling thread's current device: make sure it is the handle's
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
-  }
+  if (int rc = use_device(h)) return rc;
   ObsArgs o;
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;
@@ -1423,6 +1436,7 @@ int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R,
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
   if (!q || !T || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
   if (R == 0 || h->n_frames == 0) return RMP2_OK;
+  if (int rc = use_device(h)) return rc;
   const int blocks = (R + kWave - 1) / kWave;
   hipStream_t s = (hipStream_t)stream;
   switch (h->n_slots_full) {
@@ -1444,10 +1458,7 @@ int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* ta
     return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
   if (R == 0 || !h->has_distance || table->n_spheres == 0) return RMP2_OK;
   hipStream_t s = (hipStream_t)stream;
-  {
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) HIP_TRY(h, hipSetDevice(h->device));
-  }
+  if (int rc = use_device(h)) return rc;
   // pair layout of the arrays written here: the i-th distance leaf owns pairs [i*K, (i+1)*K)
   int32_t pb[RMP2_MAX_LEAVES + 1];
   int acc = 0;
@@ -1485,9 +1496,11 @@ static int differentiate_impl(rmp2_handle* h, const float* q, const float* qd, i
   if (!q || !qd || !x || !xd || !J || !c || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
   if (frame < 0 || frame >= h->n_frames) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "frame out of range");
   if (R == 0) return RMP2_OK;
+  if (int rc = use_device(h)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((size_t)R > h->scratch_robots) {  // setup-time style allocation, grows monotonically (not on the hot path)
-    HIP_TRY(h, hipSetDevice(h->device));
+  // The per-robot scratch belongs to the handle: the differentiate entry points are single-stream per handle
+  // (include/rmp2.h).  It grows monotonically; hipFree synchronises the device, so no launch still reads the old one.
+  if ((size_t)R > h->scratch_robots) {
     if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
     h->d_scratch = nullptr;
     h->scratch_robots = 0;

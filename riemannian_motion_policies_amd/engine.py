@@ -21,11 +21,26 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _is_resident(t, device) -> bool:
+    """A contiguous fp32 tensor on `device`: usable by the library as it is (no staging copy)."""
+    return (isinstance(t, torch.Tensor) and t.device == device and t.dtype == torch.float32 and t.is_contiguous())
+
+
+def _require_resident(device, **tensors) -> None:
+    for name, t in tensors.items():
+        if t is not None and not _is_resident(t, device):
+            raise ValueError(f"{name} must be a contiguous fp32 tensor on {device}: a staging copy would be made on "
+                             "torch's current stream (not ordered against an explicit launch stream) and, for a bound "
+                             "launch, later in-place writes to the original would never be seen")
+
+
 class Engine:
     def __init__(self, desc: D.Desc, device: int | torch.device = 0):
         if not torch.cuda.is_available():
             raise _native.Rmp2Error("no HIP device visible; the RMP2 engine has no CPU fallback")
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.desc = desc
         self.n_dof = desc.robot.n_dof
         self.n_frames = desc.robot.n_frames
@@ -44,6 +59,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def last_kernel(self) -> str:
+        """Kernel (mapping of robots to lanes) the last step / rollout of this engine launched."""
+        return self._lib.rmp2_last_kernel(self._h).decode()
 
     # ------------------------------------------------------------------------------
     def obstacles(self, *, spheres=None, p_link=None, p_obs=None, pair_counts: Optional[Sequence[int]] = None,
@@ -101,7 +120,11 @@ class Engine:
              out: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
              M: Optional[torch.Tensor] = None, f: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
         """One control step for the R robots in q/qd ([R, n_dof] fp32 device tensors).
-        Asynchronous on `stream` (default: torch's current stream)."""
+        Asynchronous on `stream` (default: torch's current stream).  With an explicit raw `stream` every tensor must
+        already be a contiguous fp32 tensor on the engine's device (conversion copies would run on torch's current
+        stream, unordered against `stream`)."""
+        if stream is not None:
+            _require_resident(self.device, q=q, qd=qd, goal=goal)
         q, qd = _f32(q, self.device), _f32(qd, self.device)
         if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
             raise ValueError(f"q and qd must be [R, {self.n_dof}], got {tuple(q.shape)} / {tuple(qd.shape)}")
@@ -147,14 +170,15 @@ class Engine:
              out: Optional[torch.Tensor] = None, stream=None):
         """Pre-validate and pre-marshal one step on FIXED device buffers (the usual control loop:
         the simulator writes q/qd in place, the engine writes qdd in place).  Returns
-        (launch, out): `launch()` is a bare C-ABI call (~2 us of host time)."""
+        (launch, out): `launch()` is a bare C-ABI call (~2 us of host time).  The launch reads the caller's buffers
+        themselves, so q, qd and goal must be contiguous fp32 tensors on the engine's device (anything else would be
+        copied once and the copy, not the caller's buffer, would be read forever after)."""
+        _require_resident(self.device, q=q, qd=qd, goal=goal if self.desc.goal_floats else None, out=out)
         out = self.step(q, qd, goal, obstacles=obstacles, out=out, stream=stream)  # validates + warms up
-        q, qd = _f32(q, self.device), _f32(qd, self.device)
         R = q.shape[0]
         goal_ptr, goal_stride = None, 0
         keep = [q, qd, out, obstacles]
         if self.desc.goal_floats:
-            goal = _f32(goal, self.device)
             goal_stride = 0 if goal.dim() == 1 else self.desc.goal_floats
             goal_ptr = goal.data_ptr()
             keep.append(goal)
@@ -195,9 +219,14 @@ class Engine:
             raise ValueError("this RMP set has distance leaves: pass obstacles=engine.obstacles(...)")
         if out is None:
             out = torch.empty((R, self.n_dof), dtype=torch.float32, device=self.device)
+        elif not _is_resident(out, self.device) or tuple(out.shape) != (R, self.n_dof):
+            raise ValueError("out must be a contiguous fp32 [R, n_dof] tensor on the engine's device")
         o = D.Outputs()
         o.qdd = out.data_ptr()
         if status is not None:
+            if not (isinstance(status, torch.Tensor) and status.device == self.device and status.is_contiguous()
+                    and status.dtype in (torch.int32, torch.uint32) and status.numel() == R):
+                raise ValueError("status must be a contiguous int32 / uint32 tensor of R elements on the engine's device")
             o.status = status.data_ptr()
         cfg = D.RolloutCfg(int(n_control_steps), int(substeps), float(dt))
         s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream

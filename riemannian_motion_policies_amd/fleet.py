@@ -43,8 +43,9 @@ class ObstacleExchange:
 
     def __init__(self, spheres_per_rank: int, device, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.collective else 1
+        self.rank = dist.get_rank(group) if self.collective else 0
         self.device = torch.device(device)
         cuda = self.device.type == "cuda"
         self.tables = [torch.zeros((self.world * spheres_per_rank, 4), dtype=torch.float32, device=self.device)
@@ -62,11 +63,13 @@ class ObstacleExchange:
 
     def start(self, local: torch.Tensor, produced=None) -> None:
         """Issue the all-gather of `local` [K/world, 4] into the free buffer.  `produced`: event after which `local`
-        is valid (default: everything issued so far on the current stream)."""
+        is valid (default: everything issued so far on the current stream).  With a process group the collective
+        is issued even for one rank (the RCCL path is then the one exercised on a one-GPU box); without one the
+        slice is the table."""
         b = self._next
         self._next ^= 1
         self._pending.append(b)
-        if self.world == 1:
+        if not self.collective:
             self.tables[b].copy_(local)
             return
         if self.side is not None:
@@ -86,13 +89,13 @@ class ObstacleExchange:
         """Make the current stream wait for the oldest outstanding gather; returns its table."""
         b = self._pending.pop(0)
         self._last = b
-        if self.world > 1 and self.side is not None:
+        if self.collective and self.side is not None:
             torch.cuda.current_stream(self.device).wait_event(self.ready[b])
         return self.tables[b]
 
     def consumed(self) -> None:
         """Call after launching the kernel that reads the table returned by the last finish()."""
-        if self.world > 1 and self.side is not None and self._last is not None:
+        if self.collective and self.side is not None and self._last is not None:
             ev = self._reader_events[self._last]
             ev.record(torch.cuda.current_stream(self.device))
             self.reader_done[self._last] = ev
@@ -146,3 +149,96 @@ class MixedFleet:
             obstacles = eng.obstacles(**okw) if okw else None
             out[key] = eng.step(q, qd, goal, obstacles=obstacles)
         return out
+
+
+class MixedFleetShard:
+    """One rank's shard of BASELINE config 5 across `world` GPUs: the fleet is stably partitioned by robot
+    TYPE (wavefronts stay type-homogeneous), then cut into `world` contiguous shards so that the estimated WORK -- the
+    per-robot flops of SURVEY 8(d): a base term per type plus 240 flops per (control point, obstacle) pair -- is
+    balanced, not the robot count.  A shard therefore holds robots of one type or, where a cut falls inside a type's
+    range, of two; it drives one engine per type present.  Robots are independent: no data-path collective."""
+
+    BASE_FLOPS = {"two_joint": 0.5e3, "panda": 4.0e3}      # BASELINE.md section 3, config 5
+    CONTROL_POINTS = {"two_joint": 3, "panda": 8}
+    BYTES = {"two_joint": 36, "panda": 120}
+
+    @staticmethod
+    def plan(total: int, world: int, counts):
+        """counts[r] = obstacles robot r sees, in TYPE-SORTED order (first total // 2 robots: TwoJoint, rest: Panda).
+        Returns (cuts, ranges): cuts = world + 1 indices into the sorted fleet; ranges[rank] = {type: (lo, hi)} in
+        per-type robot numbering."""
+        import numpy as np
+        counts = np.asarray(counts)
+        n_tj = total // 2
+        is_tj = np.arange(total) < n_tj
+        work = np.where(is_tj, MixedFleetShard.BASE_FLOPS["two_joint"], MixedFleetShard.BASE_FLOPS["panda"]) + \
+            240.0 * np.where(is_tj, 3, 8) * counts
+        cuts = balanced_bounds(work, world)
+        ranges = []
+        for r in range(world):
+            lo, hi = cuts[r], cuts[r + 1]
+            ranges.append({"two_joint": (min(lo, n_tj), min(hi, n_tj)),
+                           "panda": (max(lo, n_tj) - n_tj, max(hi, n_tj) - n_tj)})
+        return cuts, ranges, work
+
+    @classmethod
+    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto"):
+        """Synthetic config-5 fleet of `total` robots (k_r ~ U{0..32} as CSR lists into the type's
+        shared sphere table); builds only this rank's shard."""
+        import numpy as np
+        from . import configs as Cf
+        from .engine import Engine
+        rng = np.random.default_rng(seed)
+        counts = rng.integers(0, Cf.N_SPHERES + 1, size=total)
+        _, ranges, work = cls.plan(total, world, counts)
+        n_tj = total // 2
+        self = cls()
+        self.parts = {}
+        self.work = 0.0
+        dev = torch.device("cuda", device)
+        for key, builder, sampler, first in (("two_joint", Cf.config5_two_joint, Cf.sample_two_joint_states, 0),
+                                             ("panda", Cf.config3, Cf.sample_panda_states, n_tj)):
+            lo, hi = ranges[rank][key]
+            n = hi - lo
+            if n <= 0:
+                continue
+            _, desc = builder(solve)
+            eng = Engine(desc, device)
+            trng = np.random.default_rng([seed, first, rank])
+            st = sampler(trng, n)
+            sph = Cf.sample_spheres(np.random.default_rng([seed, first]))   # one table per type, same on every rank
+            if key == "two_joint":   # the planar arm lives at z ~ 0.1, reach 2: spread the spheres there
+                sph[:, :2] *= 2.0
+                sph[:, 2] = 0.1 + 0.3 * np.random.default_rng([seed, 1]).uniform(-1, 1, len(sph)).astype(np.float32)
+            k = counts[first + lo:first + hi]
+            order = np.argsort(trng.random((n, Cf.N_SPHERES)), axis=1).astype(np.int32)   # a permutation per robot
+            take = np.arange(Cf.N_SPHERES)[None, :] < k[:, None]
+            csr_index = order[take]
+            csr_offset = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+            q, qd, goal = (torch.from_numpy(st[x]).to(dev) for x in ("q", "qd", "goal"))
+            out = torch.empty_like(q)
+            obs = eng.obstacles(spheres=torch.from_numpy(sph).to(dev), csr_offset=torch.from_numpy(csr_offset),
+                                csr_index=torch.from_numpy(csr_index))
+            launch, _ = eng.bind(q, qd, goal, obstacles=obs, out=out)
+            pairs = float(cls.CONTROL_POINTS[key] * k.sum())
+            self.parts[key] = dict(engine=eng, launch=launch, out=out, n=n, keep=(q, qd, goal, obs),
+                                   bytes=float(n * (cls.BYTES[key] + 4) + 4 * k.sum()),
+                                   flops=float(n * cls.BASE_FLOPS[key] + 240.0 * pairs))
+            self.work += float(work[first + lo:first + hi].sum())
+        self.n_two_joint = self.parts.get("two_joint", {}).get("n", 0)
+        self.n_panda = self.parts.get("panda", {}).get("n", 0)
+        self._dom = "panda" if "panda" in self.parts else "two_joint"
+        d = self.parts[self._dom]
+        self.dominant_bytes, self.dominant_flops, self.dominant_robots = d["bytes"], d["flops"], d["n"]
+        self._launches = [p["launch"] for p in self.parts.values()]
+        return self
+
+    def step(self):
+        for launch in self._launches:
+            launch()
+
+    def step_dominant(self):
+        self.parts[self._dom]["launch"]()
+
+    def dominant_kernel(self) -> str:
+        return self.parts[self._dom]["engine"].last_kernel()
