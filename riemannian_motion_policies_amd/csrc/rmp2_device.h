@@ -15,6 +15,7 @@
 //   pull-back / sum          rmp.py:142-150,165-167
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/rmp2.h"
@@ -33,10 +34,11 @@ struct DevOp {
   int32_t qidx;     // index into q or -1 (evaluated at 0)
   uint32_t anc_mask;  // bit j: dof j moves this frame
   int32_t leaf_begin, leaf_count;  // range in DevProgram::fk_leaves
-  float axis[3];
-  float Tc[12];
-  int32_t pad_;  // 96 bytes: 16-byte multiples so that the program can be staged with dwordx4 copies
+  float axis[3];    // joint axis in the joint frame; {axis, ctl} is one aligned 16-byte record (one s_load_dwordx4)
+  int32_t ctl;      // the walk's control word: (restore + 2) | (save + 1) << 2 | jtype << 4 | (qidx + 1) << 6 | has_leaf << 11
+  float Tc[12];     // 96 bytes: 16-byte multiples so that the program can be staged with dwordx4 copies
 };
+static_assert(offsetof(DevOp, axis) % 16 == 0 && offsetof(DevOp, Tc) % 16 == 0, "DevOp: {axis, ctl} and Tc are fetched as float4");
 
 struct DevLeaf {
   // head: fetched with ONE 64-byte scalar load (s_load_dwordx16)
@@ -64,7 +66,7 @@ struct DevProgram {
   int32_t n_ops, n_dof, n_frames, n_leaves;
   int32_t n_fk_leaves, n_id_leaves, goal_floats, solve_mode;
   uint32_t rev_mask;  // bit j: dof j is revolute (else prismatic)
-  int32_t pad_[3];
+  uint32_t dof_ops[3];  // op (schedule position) of the joint that owns dof j: 5 bits each, 6 dofs per word
   DevOp ops[kMaxOps];
   DevLeaf leaves[RMP2_MAX_LEAVES];
   int32_t fk_leaves[RMP2_MAX_LEAVES];  // leaf ids grouped by op

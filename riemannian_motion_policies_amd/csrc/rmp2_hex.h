@@ -461,7 +461,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   float* const s_goal = goal_base + wv * 16 * kHexRobots;
   float* const blk_out = goal_base + WAVES * 16 * kHexRobots;             // [WAVES * 4][n_dof] qdd tile of the block
   float* const sph_lds_base = blk_out + WAVES * kHexRobots * RMP2_MAX_DOF;
-  float* const stage_base = sph_lds_base + (CAP ? 8 : 4) * n_sph_lds;
+  float* const stage_base = sph_lds_base + sphere_lds_floats(CAP, n_sph_lds);
   // the staged program: same layout as the host's blob
   HexCtl* const s_ctl = reinterpret_cast<HexCtl*>(stage_base);
   HexOp* const s_hops = reinterpret_cast<HexOp*>(s_ctl + n_ops);
@@ -504,7 +504,14 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       const int i = u * kBlk + tid;
       if (i < blob16) reinterpret_cast<uint4*>(stage_base)[i] = bv[u];
     }
-    if (tid < nf4) reinterpret_cast<float4*>(sph_lds_base)[tid] = sv;
+    if (tid < nf4) {
+      if (CAP) {
+        reinterpret_cast<float4*>(sph_lds_base)[tid] = sv;
+      } else {  // image for the culled pair loop (rmp2_quad.h): {-2c, |c|^2 - thr^2} records, then the radii
+        reinterpret_cast<float4*>(sph_lds_base)[tid] = sphere_aux(sv, hdr.cull_c0);
+        sph_lds_base[4 * n_sph_lds + tid] = sv.w;
+      }
+    }
     if (lane < ng) s_goal[g_rr * 16 + g_jj] = gv;
     if (fastq) {
       if (lane < tile) {
@@ -529,9 +536,18 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     // leftovers of big programs / big obstacle tables
     if (blob16 > 4 * kBlk)
       stage_copy<kBlk>(reinterpret_cast<uint4*>(stage_base) + 4 * kBlk, blob + 4 * kBlk, blob16 - 4 * kBlk, tid);
-    if (nf4 > kBlk)
-      stage_copy<kBlk>(reinterpret_cast<float4*>(sph_lds_base) + kBlk, reinterpret_cast<const float4*>(obs.spheres) + kBlk,
-                       nf4 - kBlk, tid);
+    if (nf4 > kBlk) {
+      if (CAP) {
+        stage_copy<kBlk>(reinterpret_cast<float4*>(sph_lds_base) + kBlk, reinterpret_cast<const float4*>(obs.spheres) + kBlk,
+                         nf4 - kBlk, tid);
+      } else {
+        for (int i = kBlk + tid; i < nf4; i += kBlk) {
+          const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[i];
+          reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(sp, hdr.cull_c0);
+          sph_lds_base[4 * n_sph_lds + i] = sp.w;
+        }
+      }
+    }
     if (WAVES > 1)
       __syncthreads();  // the only cross-wave dependence: the shared staged program / obstacle table
     else
@@ -626,7 +642,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         h[0] = h[1] = h[2] = 0.f;
         const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
         if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
-          if (spheres_in_lds)
+          if (spheres_in_lds && !CAP)
+            pair_loop_culled<false, kHex>(sph_lds_base, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, s, P3, V3, A3, lh.P,
+                                          IP, S, h);
+          else if (spheres_in_lds)
             pair_loop<kPairsSharedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, s,
                                                   P3, V3, A3, lh.P, IP, S, h);
           else
@@ -645,7 +664,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
           int max_count = count;
 #pragma unroll
           for (int o = 32; o >= kHex; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
-          if (spheres_in_lds)
+          if (spheres_in_lds && !CAP)
+            pair_loop_culled<true, kHex>(sph_lds_base, n_sph_lds, obs.csr_index + b0, count, max_count, s, P3, V3, A3, lh.P,
+                                         IP, S, h);
+          else if (spheres_in_lds)
             pair_loop<kPairsRaggedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
                                                   P3, V3, A3, lh.P, IP, S, h);
           else

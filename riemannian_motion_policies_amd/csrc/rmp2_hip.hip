@@ -770,11 +770,14 @@ struct rmp2_handle {
   int n_id_leaves = 0;
   int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
+  float cull_c0 = 0.f;  // max over the distance leaves of (metric_modulation_radius + margin): beyond it a pair is culled
+  uint32_t dof_ops[3] = {0u, 0u, 0u};  // op that owns each dof (quad kernel: Jacobian columns come from the frame slots)
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
   int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
+  int quad_minw = 2;  // register cap of the throughput quad build: 2 waves per SIMD (env RMP2_QUAD_MINW=4, A/B only)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1050,6 +1053,15 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   P.n_leaf_ops = 0;
   for (int k = 0; k < F; ++k)
     if (P.ops[k].leaf_count > 0) P.leaf_ops[P.n_leaf_ops++] = k;
+  for (int k = 0; k < F; ++k) {
+    const DevOp& o = P.ops[k];
+    P.ops[k].ctl = (o.restore + 2) | ((o.save + 1) << 2) | (o.jtype << 4) | ((o.qidx + 1) << 6) | ((o.leaf_count > 0 ? 1 : 0) << 11);
+  }
+  // the op that owns each dof (its frame's origin is the joint origin o_j, its world axis z_j): 5 bits per dof
+  for (int w = 0; w < 3; ++w) P.dof_ops[w] = 0u;
+  for (int k = 0; k < F; ++k)
+    if (P.ops[k].qidx >= 0 && P.ops[k].jtype != RMP2_JOINT_FIXED)
+      P.dof_ops[P.ops[k].qidx / 6] |= (uint32_t)k << (5 * (P.ops[k].qidx % 6));
   P.n_id_leaves = nid;
   return RMP2_OK;
 }
@@ -1085,13 +1097,18 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + 16 * kRobotsPerWave * h->n_ops_step + (o.capsule ? 8 : 4) * n_sph_lds);
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
+                                            sphere_lds_floats(o.capsule, n_sph_lds));
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
-  // 512 registers; throughput build beyond: scalar-cache program walk, register cap for 2 waves per SIMD
+  // 512 registers; throughput build beyond: scalar-cache program walk, 256 registers (two waves per SIMD: the 16 waves
+  // a CU owes to a 65 536-robot fleet run as two even rounds of 8).  LDS is <= 10 KB per wave, so a 128-register build
+  // would keep all 16 resident (a SIMD issues a plain fp32 instruction every 2.2 cycles from four waves, every 3.3
+  // from two -- profiles/r02_valu_issue_rates.txt); measured, that build spills ~450 scratch accesses per wave and
+  // loses: 109 vs 89 us (profiles/r02_quad_minw_ab.txt)
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
@@ -1100,6 +1117,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                      hdr, q, qd, goal, gs, o, out, ro, R)
   if (latency) {
     if (o.capsule) RMP2_QUAD_LAUNCH(1, true, true); else RMP2_QUAD_LAUNCH(1, true, false);
+  } else if (h->quad_minw == 4) {  // A/B only (env RMP2_QUAD_MINW=4): 128 registers, four waves per SIMD
+    if (o.capsule) RMP2_QUAD_LAUNCH(4, false, true); else RMP2_QUAD_LAUNCH(4, false, false);
   } else {
     if (o.capsule) RMP2_QUAD_LAUNCH(2, false, true); else RMP2_QUAD_LAUNCH(2, false, false);
   }
@@ -1113,9 +1132,9 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   const int blocks = (R + per_block - 1) / per_block;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
+  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds));
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   h->last_kernel = "rmp2_step_hex_kernel (16 lanes per robot)";
   if (o.capsule)
@@ -1132,7 +1151,7 @@ template <int N>
 size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, (o.capsule ? 8 : 4) * n_sph_lds);
+  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds));
 }
 
 // big programs (many frames / leaves) do not fit four waves' working sets into one block's LDS: one wave per
@@ -1265,9 +1284,14 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
     const char* we = std::getenv("RMP2_HEX_WAVES");
     h->hex_waves = (we && std::atoi(we) == 1) ? 1 : 4;
   }
+  {
+    const char* we = std::getenv("RMP2_QUAD_MINW");
+    h->quad_minw = (we && std::atoi(we) == 4) ? 4 : 2;
+  }
   h->n_fk_leaves = P.n_fk_leaves;
   h->hex_is_chain = P.hex.is_chain;
   h->rev_mask = P.rev_mask;
+  for (int w = 0; w < 3; ++w) h->dof_ops[w] = P.dof_ops[w];
   {
     const char* kenv = std::getenv("RMP2_KERNEL");
     h->kernel_choice = !kenv ? 0
@@ -1277,6 +1301,8 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();
+  for (int l : h->distance_leaves)
+    h->cull_c0 = std::max(h->cull_c0, desc->leaves[l].params[7] + desc->leaves[l].params[0]);
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_POINT) h->has_point = true;
   hipError_t e = hipSetDevice(device);

@@ -197,7 +197,7 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
   };
   float4 na, nb;
   fetch(0, na, nb);
-#pragma unroll 2
+#pragma unroll 1
   for (int t = 0; t < trips; ++t) {
     float nh[3], d;
     const bool on = W * t + sub < count;
@@ -255,16 +255,150 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
   }
 }
 
+// ---- per-robot culling of the distance leaves' pairs ------------------------------------------------------------
+// ObstacleAvoidance's metric is EXACTLY zero beyond metric_modulation_radius (rmp2.py:191-195: tf.where(x > r, 0, ..)),
+// and a pair with zero metric contributes exactly nothing to (S, h).  In the cluttered scene 79 % of the (control
+// point, sphere) pairs are out of range, yet the full pair costs 2 exp + 4 rcp + rsq + ~60 FMAs.  So:
+//   pass 1  every lane tests its share of a 32-sphere chunk against the frame origin -- 3 FMAs and a compare per
+//           sphere on a staged table {-2 c, |c|^2 - thr^2}: |p - c|^2 <= thr^2  <=>  p.(-2c) + (|c|^2 - thr^2) <= -|p|^2,
+//           thr = (sphere radius + modulation radius + margin) with 2e-4 of slack (pairs inside the slack are
+//           evaluated and zeroed by the exact test; NaNs compare "in range" and propagate as before);
+//           the lanes of the robot OR their bits together: a per-(robot, frame) 32-bit mask, no LDS, no cross-robot
+//           traffic (the pooled variant of round 1 died on exactly that);
+//   pass 2  the set bits are dealt round-robin to the W lanes of the robot (lane s takes the s-th, (s+W)-th, ... set
+//           bit) and only those pairs run the transcendental chain.
+// Table image in LDS for K spheres: K x float4 {-2cx, -2cy, -2cz, w} followed by K radii.
+constexpr float kCullSlack = 1.0002f;
+__host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
+
+__device__ __forceinline__ float4 sphere_aux(const float4 sp, float c0) {
+  const float thr = fmaxf(sp.w + c0, 0.f);
+  const float cc = sp.x * sp.x + sp.y * sp.y + sp.z * sp.z;
+  return make_float4(-2.f * sp.x, -2.f * sp.y, -2.f * sp.z, fmaf(-thr * thr, kCullSlack, cc));
+}
+
+__device__ __forceinline__ uint32_t dpp_or(uint32_t v, uint32_t w) { return v | w; }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppu(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// position of the r-th (0-based) set bit of m; r < popcount(m) required
+__device__ __forceinline__ int select_bit(uint32_t m, int r) {
+  int pos = 0;
+  int c = __builtin_popcount(m & 0xffffu);
+  if (r >= c) { pos = 16; r -= c; }
+  c = __builtin_popcount((m >> pos) & 0xffu);
+  if (r >= c) { pos += 8; r -= c; }
+  c = __builtin_popcount((m >> pos) & 0xfu);
+  if (r >= c) { pos += 4; r -= c; }
+  c = __builtin_popcount((m >> pos) & 0x3u);
+  if (r >= c) { pos += 2; r -= c; }
+  c = (int)((m >> pos) & 1u);
+  if (r >= c) pos += 1;
+  return pos;
+}
+
+// RAGGED: positions index the robot's CSR list ci[0 .. count); otherwise positions ARE sphere indices
+template <bool RAGGED, int W>
+__device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, const int32_t* ci, int count, int max_count,
+                                                 int sub, const float P3[3], const float V3[3], const float A3[3],
+                                                 const float* P, const float* IP, float S[6], float h[3]) {
+  static_assert(W == 4 || W == 16, "quad or hex");
+  const float4* aux = reinterpret_cast<const float4*>(tab);
+  const float* rad = tab + 4 * n_tab;
+  const float vv = dot3(V3, V3);
+  const float npp = -dot3(P3, P3);
+  constexpr int kTests = 32 / W;
+  for (int base = 0; base < max_count; base += 32) {  // wave-uniform
+    // ---- pass 1: in-range mask of this robot's chunk ----
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < kTests; ++i) {
+      const int pos = base + sub + W * i;
+      const bool valid = pos < count;
+      int sidx = valid ? pos : 0;
+      if (RAGGED) sidx = valid ? ci[pos] : 0;
+      const float4 a = aux[sidx];
+      const float t = fmaf(P3[0], a.x, fmaf(P3[1], a.y, fmaf(P3[2], a.z, a.w)));
+      const bool keep = valid && !(t > npp);
+      m |= keep ? (1u << (W * i)) : 0u;
+    }
+    m <<= sub;
+    m |= dppu<kXor1>(m);
+    m |= dppu<kXor2>(m);
+    if (W == 16) {
+      m |= dppu<0x141>(m);  // row_half_mirror
+      m |= dppu<0x140>(m);  // row_mirror
+    }
+    // ---- pass 2: lane `sub` evaluates the set bits of rank sub, sub + W, ... ----
+    uint32_t rem = m;
+    int rank = sub;                      // W == 16: rank of the bit this lane takes next
+    const int total = __builtin_popcount(m);
+    if (W == 4) {  // drop the `sub` lowest set bits; every trip then takes the lowest and drops four
+      rem = sub > 0 ? (rem & (rem - 1u)) : rem;
+      rem = sub > 1 ? (rem & (rem - 1u)) : rem;
+      rem = sub > 2 ? (rem & (rem - 1u)) : rem;
+    }
+    while (true) {
+      const bool on = (W == 4) ? (rem != 0u) : (rank < total);
+      if (!__any(on)) break;
+      int j = 0;
+      if (W == 4) {
+        j = on ? (__builtin_ffs((int)rem) - 1) : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rem &= rem - 1u;   // (0 & anything stays 0)
+      } else {
+        j = on ? select_bit(m, rank) : 0;
+        rank += W;
+      }
+      const int pos = base + j;
+      int sidx = on ? pos : 0;
+      if (RAGGED) sidx = on ? ci[pos] : 0;
+      const float4 a = aux[sidx];
+      const float r = rad[sidx];
+      const float diff[3] = {fmaf(0.5f, a.x, P3[0]), fmaf(0.5f, a.y, P3[1]), fmaf(0.5f, a.z, P3[2])};  // p - c, exactly
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const float inv = rsq0(d2);
+      const float d = d2 * inv - r;
+      const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+      const float xdot = dot3(nh, V3);
+      const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+      float acc, met;
+      obstacle_pair(P, IP, d, xdot, acc, met);
+      if (!on) met = 0.f;
+      const float wgt = met * (acc - cd);
+      const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+      S[0] = fmaf(mn[0], nh[0], S[0]);
+      S[1] = fmaf(mn[0], nh[1], S[1]);
+      S[2] = fmaf(mn[0], nh[2], S[2]);
+      S[3] = fmaf(mn[1], nh[1], S[3]);
+      S[4] = fmaf(mn[1], nh[2], S[4]);
+      S[5] = fmaf(mn[2], nh[2], S[5]);
+      h[0] = fmaf(wgt, nh[0], h[0]);
+      h[1] = fmaf(wgt, nh[1], h[1]);
+      h[2] = fmaf(wgt, nh[2], h[2]);
+    }
+  }
+}
+
 // ---- the kernel -------------------------------------------------------------------------------
+// LDS per wave (16 robots).  The budget that matters: 160 KiB per CU / 16 waves = 10 240 B -- above it the 16 waves
+// a CU owes to a 65 536-robot fleet are not resident together (measured before the diet: 16.9 KB, 9 of 16 resident,
+// the other 7 ran as a second, half-empty round).  Per robot: the q / qd rows and ONE 12-float slot per frame of the
+// program.  A slot first carries the frame's local transform (phase 1 -> walk), then the frame's world quantities
+// [p, v, a, z] (walk -> leaf phase): its origin with J qd and Jdot qd, and the world axis of its joint -- which IS the
+// (o_j, z_j) record the Jacobian columns of dof j need (QuadHdr::dof_ops maps dof -> frame).  After the resolve slot 0
+// of the robot receives qdd (nothing reads the slots of a resolved robot again).
+constexpr int kSlot = 12;
 template <int N>
 struct QuadLds {
   static constexpr int kQ = 0;                                 // [16][N]
   static constexpr int kQd = kRobotsPerWave * N;               // [16][N]
-  static constexpr int kZo = 2 * kRobotsPerWave * N;           // [N*6][16]
-  static constexpr int kOut = kZo + 6 * N * kRobotsPerWave;    // [16][n_dof]
-  static constexpr int kLoc = kOut + kRobotsPerWave * N;       // [16 robots][n_ops][16]: Rl(9) tl(3) zl(3) ctl
-  static constexpr int kFloats = kLoc;                         // + dynamic: records, sphere table, staged program
+  static constexpr int kLoc = 2 * kRobotsPerWave * N;          // [16 robots][max(n_ops, 1)][12]
+  static constexpr int kFloats = kLoc;                         // + dynamic: slots, sphere table, staged program
 };
+__host__ __device__ constexpr int quad_slots(int n_ops) { return n_ops > 0 ? n_ops : 1; }
 
 // header of the program, passed BY VALUE as a kernel argument (lands in SGPRs with the kernarg
 // preload: the prologue needs no dependent round trip before it can issue the tile loads)
@@ -285,9 +419,11 @@ struct QuadHdr {
   int32_t n_levels;  // pointer-jumping rounds (rmp2_hex.h only)
   int32_t n_fk;      // leaves on FK task maps (rmp2_hex.h only)
   int32_t is_chain;  // every frame's parent is the previous frame of the program (rmp2_hex.h only)
+  uint32_t dof_ops[3];  // op that owns dof j, 5 bits each, 6 dofs per word (rmp2_quad.h only)
+  float cull_c0;        // max over the distance leaves of (metric_modulation_radius + margin): cull threshold
 };
 
-__device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * 16 * n_ops; }
+__device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
 
 // walk state of one lane: component `sub` of the world vectors, row `sub` of the rotation
 struct QuadState {
@@ -315,7 +451,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                       OutArgs out, RolloutArgs ro, int R) {
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
-  // dynamic LDS: [QuadLds<N>::kFloats floats | local transforms 16 robots x n_ops x 16 floats |
+  // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
   //               STAGE only: ops[n_ops] | leaves[n_leaves] | fk list | id list | goal tile 16 x 16 floats]
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -340,10 +476,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const int n_ops = hdr.n_ops, n_id = hdr.n_id;
   const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
-  float* const sph_lds_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops;  // 16-byte aligned
+  float* const sph_lds_base = lds + QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(n_ops);  // 16-byte aligned
   const uint32_t rev_mask = hdr.rev_mask;
   // staged copies (STAGE) live behind the local-transform records
-  float* const stage_base = lds + QuadLds<N>::kFloats + 16 * kRobotsPerWave * n_ops + (CAP ? 8 : 4) * n_sph_lds;
+  float* const stage_base = sph_lds_base + sphere_lds_floats(CAP, n_sph_lds);
   DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
@@ -374,8 +510,15 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
     if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
-      const int nf = (CAP ? 8 : 4) * n_sph_lds;
-      for (int i = lane; i < nf; i += kWave) sph_lds_base[i] = obs.spheres[i];
+      if (CAP) {
+        for (int i = lane; i < 8 * n_sph_lds; i += kWave) sph_lds_base[i] = obs.spheres[i];
+      } else {  // image for the culled pair loop: {-2c, |c|^2 - thr^2} records, then the radii
+        for (int i = lane; i < n_sph_lds; i += kWave) {
+          const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[i];
+          reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(sp, hdr.cull_c0);
+          sph_lds_base[4 * n_sph_lds + i] = sp.w;
+        }
+      }
     }
     if (STAGE) {
       const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
@@ -405,8 +548,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
   const float* my_q = &lds[QuadLds<N>::kQ + gi * N];
   const float* my_qd = &lds[QuadLds<N>::kQd + gi * N];
-  float* zo = &lds[QuadLds<N>::kZo + g];
-  float* my_out = &lds[QuadLds<N>::kOut + g * n_dof];
+  float* const loc = &lds[QuadLds<N>::kLoc + gi_loc(g, n_ops)];  // this robot's frame slots
+  float* my_out = loc;                                            // qdd lands in slot 0 once the robot is resolved
+  const int out_stride = kSlot * quad_slots(n_ops);
   const float* my_goal = !goal ? nullptr : (STAGE ? s_goal + gi * 16 : goal + (size_t)(live ? robot : 0) * goal_stride);
   uint32_t status = 0u;
   bool flagged = false;
@@ -418,7 +562,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // (kinematics.py:222-240).  They do not depend on the chain, so lane `sub` of the quad builds
   // the frames k = sub, sub+4, ... (branch-free: the joint type selects by arithmetic) and
   // leaves Rl (9), tl (3) and Rl @ axis (3) in LDS; the serial walk below only multiplies.
-  float* const loc = &lds[QuadLds<N>::kLoc + gi_loc(g, n_ops)];
   for (int k = sub; k < n_ops; k += kQuad) {
     const DevOp& opg = ops[k];  // lane-dependent record (LDS copy when staged, else vector loads)
     const int jt = opg.jtype, qi = opg.qidx;
@@ -435,7 +578,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     const bool rev = jt == RMP2_JOINT_REVOLUTE;
     // Rodrigues: cos*I + sin*[u]x + (1-cos)*u u^T ; for non-revolute joints T_variable's rotation is I exactly
     const float ut[9] = {0.f, -ax[2], ax[1], ax[2], 0.f, -ax[0], -ax[1], ax[0], 0.f};
-    float Rv[9], Tc[12], rec[16];
+    float Rv[9], Tc[12], rec[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) Tc[c] = opg.Tc[c];
 #pragma unroll
@@ -454,15 +597,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         rec[3 * r + c] = Tc[4 * r + 0] * Rv[c] + Tc[4 * r + 1] * Rv[3 + c] + Tc[4 * r + 2] * Rv[6 + c];
       rec[9 + r] = Tc[4 * r + 0] * tv[0] + Tc[4 * r + 1] * tv[1] + Tc[4 * r + 2] * tv[2] + Tc[4 * r + 3];
     }
+    float4* dst = reinterpret_cast<float4*>(loc + kSlot * k);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) rec[12 + r] = rec[3 * r] * ax[0] + rec[3 * r + 1] * ax[1] + rec[3 * r + 2] * ax[2];
-    // control word of the frame for the serial walk, packed into the record's 16th slot
-    const int packed = (opg.restore + 2) | ((opg.save + 1) << 2) | (jt << 4) | ((qi + 1) << 6) |
-                       ((opg.leaf_count > 0 ? 1 : 0) << 11);
-    rec[15] = __int_as_float(packed);
-    float4* dst = reinterpret_cast<float4*>(loc + 16 * k);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+    for (int c = 0; c < 3; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
   }
   __syncthreads();
 
@@ -474,23 +611,25 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     QuadState cur;
     QuadState slot[SLOTS > 0 ? SLOTS : 1];
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
-    float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2], n3 = rec4n[3];
+    float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2];
+    // {axis, ctl} of the frame: wave-uniform, one 16-byte fetch per frame (scalar cache, or the staged copy), one ahead
+    float4 nac = *reinterpret_cast<const float4*>(ops[0].axis);
     for (int k = 0; k < n_ops; ++k) {
-      const float4 r0_ = n0, r1_ = n1, r2_ = n2, r3_ = n3;
-      const int ctl = __builtin_amdgcn_readfirstlane(__float_as_int(r3_.w));
+      const float4 r0_ = n0, r1_ = n1, r2_ = n2, ac = nac;
+      const int ctl = uni<STAGE>(__float_as_int(ac.w));
       const int c_restore = (ctl & 3) - 2, c_save = ((ctl >> 2) & 3) - 1, c_jtype = (ctl >> 4) & 3;
       const int qi = ((ctl >> 6) & 31) - 1;
       const float qdv = qi >= 0 ? my_qd[qi] : 0.f;
       {  // next frame's record: issued now, consumed one iteration later
-        rec4n = reinterpret_cast<const float4*>(loc + 16 * min(k + 1, n_ops - 1));
+        const int kn = min(k + 1, n_ops - 1);
+        rec4n = reinterpret_cast<const float4*>(loc + kSlot * kn);
         n0 = rec4n[0];
         n1 = rec4n[1];
         n2 = rec4n[2];
-        n3 = rec4n[3];
+        nac = *reinterpret_cast<const float4*>(ops[kn].axis);
       }
       const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
       const float tl[3] = {r2_.y, r2_.z, r2_.w};
-      const float zl[3] = {r3_.x, r3_.y, r3_.z};
       if (c_restore == -2) {
         // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
 #pragma unroll
@@ -507,8 +646,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       for (int c = 0; c < 3; ++c) Rn[c] = cur.R[0] * Rl[c] + cur.R[1] * Rl[3 + c] + cur.R[2] * Rl[6 + c];
       const float pn = cur.R[0] * tl[0] + cur.R[1] * tl[1] + cur.R[2] * tl[2] + cur.p;
       const float rr = pn - cur.p;
-      // world joint axis: R_parent @ (R_local @ axis)
-      const float z = cur.R[0] * zl[0] + cur.R[1] * zl[1] + cur.R[2] * zl[2];
+      // world joint axis: my component of R_world @ axis (my row of the new world rotation)
+      const float z = Rn[0] * ac.x + Rn[1] * ac.y + Rn[2] * ac.z;
       // velocity / bias-acceleration recursion, one component per lane; (a x b)_i = a_{i+1} b_{i+2} - a_{i+2} b_{i+1}
       const float w1 = dpp<kRot1>(cur.w), w2 = dpp<kRot2>(cur.w);
       const float r1 = dpp<kRot1>(rr), r2 = dpp<kRot2>(rr);
@@ -537,17 +676,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       cur.al = aln;
       cur.v = vn;
       cur.a = an;
-      if (sub < 3) {
-        if (qi >= 0 && c_jtype != RMP2_JOINT_FIXED) {
-          zo[(qi * 6 + sub) * kRobotsPerWave] = z;
-          zo[(qi * 6 + 3 + sub) * kRobotsPerWave] = pn;
-        }
-        if ((ctl >> 11) & 1) {  // a frame with leaves: leave (p, v, a) for the leaf phase -- in the frame's own
-          float* fr = loc + 16 * k;  // record slot, which every lane of the quad has already consumed
-          fr[sub] = pn;
-          fr[3 + sub] = vn;
-          fr[6 + sub] = an;
-        }
+      if (sub < 3) {  // the frame's world record [p, v, a, z] replaces its local transform (consumed by every lane of
+        float* fr = loc + kSlot * k;  // the quad one iteration ago)
+        fr[sub] = pn;
+        fr[3 + sub] = vn;
+        fr[6 + sub] = an;
+        fr[9 + sub] = z;
       }
       if (SLOTS > 0 && c_save >= 0) {
 #pragma unroll
@@ -578,39 +712,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       op.leaf_begin = uni<STAGE>(op.leaf_begin);
       op.leaf_count = uni<STAGE>(op.leaf_count);
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
-      const float4* fr4 = reinterpret_cast<const float4*>(loc + 16 * k);
+      const float4* fr4 = reinterpret_cast<const float4*>(loc + kSlot * k);
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
       const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
-      // the columns of MY rows (lane-dependent dof index -> dynamic LDS address)
+      // Jacobian columns of the frame: formed AFTER the first leaf's (S, h) -- the pair loop is where the time goes and
+      // it runs with 36 fewer live registers this way (the kernel must fit 128 for four waves per SIMD)
       float mycol[ROWS][3];
-#pragma unroll
-      for (int m = 0; m < ROWS; ++m) {
-        const int i = sub + kQuad * m;
-        const bool act = (i < N) && ((op.anc_mask >> i) & 1u);
-        const int ii = act ? i : 0;
-        const float zj[3] = {zo[(ii * 6 + 0) * kRobotsPerWave], zo[(ii * 6 + 1) * kRobotsPerWave],
-                             zo[(ii * 6 + 2) * kRobotsPerWave]};
-        const float d[3] = {P3[0] - zo[(ii * 6 + 3) * kRobotsPerWave], P3[1] - zo[(ii * 6 + 4) * kRobotsPerWave],
-                            P3[2] - zo[(ii * 6 + 5) * kRobotsPerWave]};
-        float cr[3];
-        cross3(zj, d, cr);
-        const bool rev = (rev_mask >> ii) & 1u;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rev ? cr[c] : zj[c]) : 0.f;
-      }
-
-      // all columns in every lane: column j lives in lane (j & 3) as its local row j >> 2 -- three quad broadcasts per
-      // column instead of recomputing nine cross products per lane
-      float col[N][3];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          const float v = mycol[j >> 2][cc];
-          col[j][cc] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
-        }
-      }
-
       for (int li = 0; li < op.leaf_count; ++li) {
         const DevLeaf& lf = leaves[uni<STAGE>(fk_list[op.leaf_begin + li])];
         LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
@@ -640,7 +747,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
           if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
-            if (spheres_in_lds)
+            if (spheres_in_lds && !CAP)
+              pair_loop_culled<false, kQuad>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
+                                             IP, S, h);
+            else if (spheres_in_lds)
               pair_loop<kPairsSharedLds, CAP>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
                                          A3, lh.P, IP, S, h);
             else
@@ -659,7 +769,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             int max_count = count;
 #pragma unroll
             for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
-            if (spheres_in_lds)
+            if (spheres_in_lds && !CAP)
+              pair_loop_culled<true, kQuad>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3, V3, A3, lh.P,
+                                            IP, S, h);
+            else if (spheres_in_lds)
               pair_loop<kPairsRaggedLds, CAP>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3,
                                          A3, lh.P, IP, S, h);
             else
@@ -671,16 +784,72 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #pragma unroll
           for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
         }
-        // pull-back into MY rows:  f_i += col_i . h ;  A[i][j] += (S col_i) . col_j
+        if (li == 0) {
+          // the columns of MY rows (lane-dependent dof index -> dynamic LDS address); rows whose dof does not move the
+          // frame get a zero column, so everything below is branch-free
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const bool act = (i < N) && ((op.anc_mask >> i) & 1u);
+            const int ii = act ? i : 0;
+            // the frame slot of the joint that owns dof ii: [p = o_j | v | a | z_j]
+            const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
+            const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
+            const float4* js = reinterpret_cast<const float4*>(loc + kSlot * fo);
+            const float4 j0 = js[0], j2 = js[2];
+            const float zj[3] = {j2.y, j2.z, j2.w};
+            const float d[3] = {P3[0] - j0.x, P3[1] - j0.y, P3[2] - j0.z};
+            float cr[3];
+            cross3(zj, d, cr);
+            const bool rev = (rev_mask >> ii) & 1u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rev ? cr[c] : zj[c]) : 0.f;
+          }
+        }
+        // pull-back into MY rows:  f_i += col_i . h ;  A[i][j] += (S col_i) . col_j   (rmp.py:165-167).  J^T S J is
+        // symmetric (S is): only the BLOCK-UPPER part (row block m, columns j >= 4 m) is accumulated -- 15 of a lane's 27
+        // entries for n = 9, so 24 fewer live registers through the pair loops and 45 % fewer products; mirrored once
+        // below.  Column j lives in lane (j & 3) as its local row j >> 2: it is broadcast right where it is consumed.
+        float u[ROWS][3];
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
-          const float u[3] = {S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2],
-                              S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2],
-                              S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2]};
+          u[m][0] = S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2];
+          u[m][1] = S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2];
+          u[m][2] = S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2];
           fv[m] += (double)dot3(mycol[m], h);
+        }
 #pragma unroll
-          for (int j = 0; j < N; ++j)
-            if ((op.anc_mask >> j) & 1u) A[m][j] += (double)dot3(u, col[j]);
+        for (int j = 0; j < N; ++j) {
+          float cj[3];
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const float v = mycol[j >> 2][cc];
+            cj[cc] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
+          }
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m)
+            if (kQuad * m <= j) A[m][j] += (double)dot3(u[m], cj);
+        }
+      }
+    }
+    // ---- mirror the block-upper part: M[i][j] = M[j][i] for the blocks below the diagonal ------------------------
+    // lane s, local row m (global row i = s + 4 m), column 4 b + c (b < m):  the value sits in lane c as A[b][s + 4 m]
+#pragma unroll
+    for (int m = 1; m < ROWS; ++m) {
+#pragma unroll
+      for (int b = 0; b < m; ++b) {
+#pragma unroll
+        for (int c = 0; c < kQuad; ++c) {
+          double w = 0.0;
+#pragma unroll
+          for (int s2 = 0; s2 < kQuad; ++s2) {
+            if (s2 + kQuad * m < N) {  // compile time: the source column exists
+              const double v = A[b][s2 + kQuad * m];
+              const double t = c == 0 ? bcastd<0>(v) : c == 1 ? bcastd<1>(v) : c == 2 ? bcastd<2>(v) : bcastd<3>(v);
+              w = (sub == s2) ? t : w;
+            }
+          }
+          A[m][kQuad * b + c] = w;
         }
       }
     }
@@ -957,7 +1126,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       for (int i = 0; i < N; ++i)
         if (i < n_dof) finite = finite && (fabs(x[i]) < 1.7e308);
       flagged = flagged || !finite;
-      if (sub == 0) {
+      // slot 0 doubles as the qdd tile: a flagged robot keeps its slots for the careful pass below
+      if (sub == 0 && !flagged) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
           if (i < n_dof) my_out[i] = (float)x[i];
@@ -1027,10 +1197,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     }
   }
   {
-    const float* tile = &lds[QuadLds<N>::kOut];
+    const float* tile = &lds[QuadLds<N>::kLoc];
     const int count = min(kRobotsPerWave, R - r0) * n_dof;
     float* go = out.qdd + (size_t)r0 * n_dof;
-    for (int i = lane; i < count; i += kWave) go[i] = tile[i];
+    for (int i = lane; i < count; i += kWave) {
+      const int rr = i / n_dof, jj = i - rr * n_dof;
+      go[i] = tile[rr * out_stride + jj];
+    }
   }
   if (out.status && live && sub == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS
