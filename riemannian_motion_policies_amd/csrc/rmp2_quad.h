@@ -704,6 +704,22 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       for (int j = 0; j < N; ++j) A[m][j] = 0.0;
     }
 
+    // row-joint records: world axis z_i and origin o_i of the joints that own MY rows (slot [p = o | v | a | z] of the
+    // joint's frame), read once per pass instead of once per leaf frame
+    float rjz[ROWS][3], rjo[ROWS][3];
+    bool rjrev[ROWS];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int i = sub + kQuad * m;
+      const int ii = i < N ? i : 0;
+      const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
+      const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
+      const float4* js = reinterpret_cast<const float4*>(loc + kSlot * fo);
+      const float4 j0 = js[0], j2 = js[2];
+      rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
+      rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
+      rjrev[m] = (rev_mask >> ii) & 1u;
+    }
     // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
       const int k = uni<STAGE>(leaf_ops[t]);
@@ -785,25 +801,16 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
         }
         if (li == 0) {
-          // the columns of MY rows (lane-dependent dof index -> dynamic LDS address); rows whose dof does not move the
-          // frame get a zero column, so everything below is branch-free
+          // the columns of MY rows, z_i x (p - o_i) resp. z_i, from the row-joint records read once per pass; rows
+          // whose dof does not move the frame get a zero column, so everything below is branch-free
 #pragma unroll
           for (int m = 0; m < ROWS; ++m) {
-            const int i = sub + kQuad * m;
-            const bool act = (i < N) && ((op.anc_mask >> i) & 1u);
-            const int ii = act ? i : 0;
-            // the frame slot of the joint that owns dof ii: [p = o_j | v | a | z_j]
-            const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
-            const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
-            const float4* js = reinterpret_cast<const float4*>(loc + kSlot * fo);
-            const float4 j0 = js[0], j2 = js[2];
-            const float zj[3] = {j2.y, j2.z, j2.w};
-            const float d[3] = {P3[0] - j0.x, P3[1] - j0.y, P3[2] - j0.z};
+            const bool act = (op.anc_mask >> (sub + kQuad * m)) & 1u;  // (bits >= n_dof are never set)
+            const float d[3] = {P3[0] - rjo[m][0], P3[1] - rjo[m][1], P3[2] - rjo[m][2]};
             float cr[3];
-            cross3(zj, d, cr);
-            const bool rev = (rev_mask >> ii) & 1u;
+            cross3(rjz[m], d, cr);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rev ? cr[c] : zj[c]) : 0.f;
+            for (int c = 0; c < 3; ++c) mycol[m][c] = act ? (rjrev[m] ? cr[c] : rjz[m][c]) : 0.f;
           }
         }
         // pull-back into MY rows:  f_i += col_i . h ;  A[i][j] += (S col_i) . col_j   (rmp.py:165-167).  J^T S J is
@@ -813,6 +820,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         float u[ROWS][3];
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
+          u[m][0] = u[m][1] = u[m][2] = 0.f;
+          if (((op.anc_mask >> (kQuad * m)) & 0xfu) == 0u) continue;  // wave-uniform: no row of this block moves the frame
           u[m][0] = S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2];
           u[m][1] = S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2];
           u[m][2] = S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2];
@@ -820,6 +829,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
+          if (!((op.anc_mask >> j) & 1u)) continue;  // wave-uniform: dof j does not move this frame (its column is 0)
           float cj[3];
 #pragma unroll
           for (int cc = 0; cc < 3; ++cc) {
@@ -828,7 +838,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           }
 #pragma unroll
           for (int m = 0; m < ROWS; ++m)
-            if (kQuad * m <= j) A[m][j] += (double)dot3(u[m], cj);
+            if (kQuad * m <= j) A[m][j] += (double)dot3(u[m], cj);  // (a row block without ancestors adds exact zeros)
         }
       }
     }
@@ -908,6 +918,41 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         const double dm = (double)mdiag;
 #pragma unroll
         for (int j = 0; j < N; ++j) A[j >> 2][j] += (sub == (j & 3)) ? dm : 0.0;
+      } else if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+        // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) evaluated on the FULL matrix (quirk Q4): every off-diagonal
+        // entry is w, the diagonal is w / (1 - ratio_i^2).  A constant plus a diagonal: no n x n loop of products --
+        //   A_ij += w ,  A_ii += d_i - w ,  f_i += w sum_j xdd_j + (d_i - w) xdd_i
+        const float cutoff = P[0] - P[1];
+        const float w = P[3] / 1.0f;
+        float xo[ROWS], dg[ROWS], sx = 0.f;
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          const int i = sub + kQuad * m;
+          const float qdj = my_qd[i < N ? i : 0];
+          const float dv = fabsf(qdj) - cutoff;
+          const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
+          const float acc = -fabsf(P[2] * dv) * sgn;
+          xo[m] = (i < n_dof && !(fabsf(qdj) < cutoff)) ? acc : 0.f;
+          const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+          dg[m] = P[3] / (1.0f - ratio * ratio);
+          sx += xo[m];
+        }
+        sx = quad_sum(sx);
+        const double wd = (double)w;
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+          const int i = sub + kQuad * m;
+          const bool row_ok = i < n_dof;
+          const double wr = row_ok ? wd : 0.0;
+          const double dd = row_ok ? (double)dg[m] - wd : 0.0;  // exact: A_ii = w + (d_i - w) = d_i
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+            if (j < n_dof) A[m][j] += wr;
+#pragma unroll
+          for (int c = 0; c < kQuad; ++c)
+            if (kQuad * m + c < N) A[m][kQuad * m + c] += (sub == c) ? dd : 0.0;
+          fv[m] += (double)(row_ok ? fmaf(w, sx, (dg[m] - w) * xo[m]) : 0.f);
+        }
       } else {
         // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij)
         float zeta[N], xdd[N], cw[N], beta, wsc;
@@ -920,29 +965,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             full[j] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
           }
         };
-        if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
-          // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) on the FULL matrix (quirk Q4):
-          // off-diagonal = w, diagonal = w / (1 - ratio_i^2)
-          const float cutoff = P[0] - P[1];
-          float xdd_o[ROWS], zeta_o[ROWS];
-#pragma unroll
-          for (int m = 0; m < ROWS; ++m) {
-            const int i = sub + kQuad * m;
-            const float qdj = my_qd[i < N ? i : 0];
-            const float dv = fabsf(qdj) - cutoff;
-            const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
-            const float acc = -fabsf(P[2] * dv) * sgn;
-            xdd_o[m] = (fabsf(qdj) < cutoff) ? 0.f : acc;
-            const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
-            zeta_o[m] = P[3] / (1.0f - ratio * ratio);  // diagonal entry
-          }
-          expand(xdd_o, xdd);
-          expand(zeta_o, zeta);
-#pragma unroll
-          for (int j = 0; j < N; ++j) cw[j] = P[3] / 1.0f;  // off-diagonal entry
-          beta = 0.f;
-          wsc = 0.f;
-        } else if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+        if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
           // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
           const float rr_ = 0.15f;
           const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
@@ -1002,7 +1025,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           wsc = expf(-vn / 3.0f);
         }
         const float omb = 1.0f - beta;
-        const bool is_cap = lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP;
         const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
@@ -1019,13 +1041,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             // JointLimitAvoidance scales COLUMN j by the limit weight of joint j, which is exactly 0 unless
             // that joint is inside its limit band: skip the column when that holds for the whole wave
             if (is_jla && !__any(cw[j] != 0.f)) continue;
-            float a;
-            if (is_cap) {
-              a = (j == i) ? zeta[j] : cw[j];
-            } else {
-              const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
-              a = is_jla ? cw[j] * Hij : wsc * Hij;
-            }
+            const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
+            float a = is_jla ? cw[j] * Hij : wsc * Hij;
             a = row_ok ? a : 0.f;
             A[m][j] += (double)a;
             fi += a * xdd[j];
