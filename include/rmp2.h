@@ -222,7 +222,8 @@ int rmp2_step(rmp2_handle *h, const float *q, const float *qd, const float *goal
  * q and qd (device, [R][n_dof]) are advanced IN PLACE; out->qdd receives the last qdd, out->status the
  * OR of the per-step status words.  Goals and the sphere table are constant during the rollout;
  * RMP2_OBS_EXPLICIT_PAIRS is rejected (closest-point pairs are only valid for the state they were
- * computed at).  Resolve semantics are those of RMP2_SOLVE_AUTO. */
+ * computed at).  Resolve semantics are those of RMP2_SOLVE_AUTO; a handle created with RMP2_SOLVE_PINV is refused
+ * (RMP2_ERR_UNSUPPORTED) rather than silently resolved differently from what was asked for. */
 typedef struct rmp2_rollout_cfg {
   int32_t n_control_steps;
   int32_t substeps;

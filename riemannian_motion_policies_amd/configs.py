@@ -127,6 +127,58 @@ def exp05_panda(solve="auto") -> Tuple[KinematicTable, D.Desc]:
     return t, D.build_desc(t, specs, solve)
 
 
+# experiments/two_joint_robot/04_driving_into_jointlimits.py:48-51
+EXP04_TARGET_POLICY_PARAMS = [0.1, 1.0, 0.1]
+EXP04_JOINT_LIMIT_PARAMS = [0.2, 1.0]
+# experiments/franka_panda/04_nullspace_control.py:46-52
+PANDA04_TARGET_POLICY_PARAMS = [0.1, 1.0, 0.1]
+PANDA04_CONFIG_SPACE_BIASING_PARAMS = [0.01, 0.1, 0.05]
+PANDA04_Q0 = [np.pi / 2, -0.05, 0, -2.01, 0, 2.22, 0.79, 0.02, 0.02]
+
+
+def exp04_two_joint(solve="auto", with_damping=False) -> Tuple[KinematicTable, D.Desc]:
+    """experiments/two_joint_robot/04_driving_into_jointlimits.py:46-52: TargetPolicy on the IDENTITY map (goal is a
+    joint vector) + JointLimitAvoidance.  with_damping appends a JointDamping leaf (not in the script): the set then
+    carries an inertia term, so that the elimination resolve of every mapping is exercised, not only the pseudo-inverse."""
+    t = two_joint_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_IDENTITY, -1, EXP04_TARGET_POLICY_PARAMS, goal_len=2,
+                   name="rotate_joint1"),
+        D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, EXP04_JOINT_LIMIT_PARAMS,
+                   vec_a=TWO_JOINT_Q_LOW, vec_b=TWO_JOINT_Q_HIGH, name="joint_limit_avoidance"),
+    ]
+    if with_damping:
+        specs.append(D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, JOINT_DAMPING_PARAMS, name="joint_damping"))
+    return t, D.build_desc(t, specs, solve)
+
+
+def exp04_panda_identity_target(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """The exp-04 leaf pair on the 9-dof arm (not a reference script; the identity-map TargetPolicy at n = 9):
+    TargetPolicy(identity, goal = joint vector) + JointLimitAvoidance + JointDamping."""
+    t = panda_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_IDENTITY, -1, EXP04_TARGET_POLICY_PARAMS, goal_len=9,
+                   name="joint_target"),
+        D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, EXP04_JOINT_LIMIT_PARAMS,
+                   vec_a=PANDA_Q_LOW, vec_b=PANDA_Q_HIGH, name="joint_limit_avoidance"),
+        D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, JOINT_DAMPING_PARAMS, name="joint_damping"),
+    ]
+    return t, D.build_desc(t, specs, solve)
+
+
+def panda04_nullspace(solve="auto") -> Tuple[KinematicTable, D.Desc]:
+    """experiments/franka_panda/04_nullspace_control.py:41-52: TargetPolicy on FK(panda_grasptarget_hand)->pos +
+    ConfigurationSpaceBiasing (the older leaves of rmp.py on the Panda)."""
+    t = panda_table()
+    specs = [
+        D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                   PANDA04_TARGET_POLICY_PARAMS, goal_len=3, name="target"),
+        D.LeafSpec(D.LEAF_CONFIG_SPACE_BIASING, D.TASKMAP_IDENTITY, -1, PANDA04_CONFIG_SPACE_BIASING_PARAMS,
+                   vec_a=PANDA04_Q0, name="jointspace_biasing"),
+    ]
+    return t, D.build_desc(t, specs, solve)
+
+
 def sample_point_pairs(rng: np.random.Generator, R: int, n_leaves: int, B: int):
     """Datamanager fields of the attached-point leaves (data_management.py:14-16) as arrays:
     relative_position [R, n_leaves*B, 3] (joint frame), normal_vec [R, n_leaves*B, 3] (unit), distance

@@ -1454,6 +1454,11 @@ int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t
     return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: need n_control_steps >= 1, substeps >= 0, dt >= 0");
   if (obs && obs->mode == RMP2_OBS_EXPLICIT_PAIRS)
     return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: explicit closest-point pairs go stale as the robots move; use a sphere mode");
+  if (h->strict)
+    return fail(h, RMP2_ERR_UNSUPPORTED,
+                "rollout: solve = PINV (the strict pseudo-inverse for every robot) exists for single control steps only; "
+                "create the engine with RMP2_SOLVE_AUTO (same result wherever M is well conditioned, pseudo-inverse "
+                "fall-through per robot otherwise)");
   const RolloutArgs ro{cfg->n_control_steps, cfg->substeps, cfg->dt, q, qd};
   return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
 }

@@ -169,3 +169,60 @@ def test_shard_bounds_and_balanced_split():
     cuts = balanced_bounds(w, 4)
     loads = [w[cuts[r]:cuts[r + 1]].sum() for r in range(4)]
     assert cuts[0] == 0 and cuts[-1] == 200 and max(loads) - min(loads) <= 2 * w.max()
+
+
+def test_mixed_fleet_plan_is_a_balanced_partition():
+    """Config 5 across ranks: type-sorted fleet, contiguous cuts balanced by estimated work, every robot in
+    exactly one shard, per-type ranges consistent with the cuts."""
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    rng = np.random.default_rng(5)
+    total, world = 4096, 8
+    counts = rng.integers(0, 33, size=total)
+    cuts, ranges, work = MixedFleetShard.plan(total, world, counts)
+    assert cuts[0] == 0 and cuts[-1] == total and all(cuts[r] <= cuts[r + 1] for r in range(world))
+    n_tj = total // 2
+    covered_tj = sum(hi - lo for lo, hi in (r["two_joint"] for r in ranges))
+    covered_pd = sum(hi - lo for lo, hi in (r["panda"] for r in ranges))
+    assert covered_tj == n_tj and covered_pd == total - n_tj
+    for r in range(world):
+        (a, b), (c, d) = ranges[r]["two_joint"], ranges[r]["panda"]
+        assert (b - a) + (d - c) == cuts[r + 1] - cuts[r]
+    loads = [work[cuts[r]:cuts[r + 1]].sum() for r in range(world)]
+    assert max(loads) <= work.sum() / world + work.max()      # balanced to within one robot
+    assert max(cuts[r + 1] - cuts[r] for r in range(world)) > 1.5 * min(cuts[r + 1] - cuts[r] for r in range(world)), \
+        "TwoJoint robots are ~5x cheaper: a work-balanced cut must NOT be an equal-count cut"
+    # one rank: everything
+    cuts1, ranges1, _ = MixedFleetShard.plan(total, 1, counts)
+    assert cuts1 == [0, total] and ranges1[0] == {"two_joint": (0, n_tj), "panda": (0, total - n_tj)}
+
+
+def test_bind_and_explicit_stream_refuse_tensors_that_would_be_copied():
+    """Engine.bind() promises a launch on the CALLER's buffers; a tensor it would have to convert (wrong dtype, layout or
+    device) must raise instead of being copied once and read stale forever after (the same for step(stream=...))."""
+    import torch
+    from riemannian_motion_policies_amd.engine import _is_resident, _require_resident
+    dev = torch.device("cpu")
+    ok = torch.zeros((4, 9), dtype=torch.float32)
+    assert _is_resident(ok, dev)
+    assert not _is_resident(ok.double(), dev)
+    assert not _is_resident(torch.zeros((9, 4)).t(), dev)           # non-contiguous
+    assert not _is_resident(np.zeros((4, 9), np.float32), dev)     # not a tensor
+    assert not _is_resident(ok, torch.device("cuda", 0))            # wrong device
+    _require_resident(dev, q=ok, goal=None)
+    with pytest.raises(ValueError, match="qd must be a contiguous fp32 tensor"):
+        _require_resident(dev, q=ok, qd=ok.double())
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus N` outside a launcher starts its own ranks; with fewer devices than asked for it must fail loudly,
+    never benchmark fewer GPUs silently (round-1 finding)."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count()   # (does not initialise the GPU runtime)
+    if have > 0:
+        pytest.skip("starts a child process: only from a process on a box without GPUs (no fork + exec once a GPU is initialised)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "not silently running on fewer" in r.stderr and r.stdout.strip() == ""

@@ -177,3 +177,89 @@ def test_fused_rollout_matches_step_loop(hip_lib, workload, kernel):
             assert ok.float().mean().item() > 0.8
             assert err[ok].median().item() < 1e-5 and (err[ok] < 1e-3).float().mean().item() > 0.9
             assert (qf[ok] - q0[ok]).abs().max().item() > 1e-2  # the fleet actually moved
+
+
+def _oracle_rollout(desc, q, qd, goal, K, sub, dt, precision="f32", **obs):
+    """The reference's control loop (06_cluttered_environment.py:120-131: RMP at 10 Hz, plant at 100 Hz tracking qdd) with
+    the CPU oracle as the controller: K x (qdd = oracle step; `sub` ticks of qd = fma(dt, qdd, qd); q = fma(dt, qd, q)), the
+    ticks in fp32 fused-multiply-add arithmetic (the product a*b of two fp32 numbers is exact in fp64; one rounding to fp32).
+    Returns q, qd and the largest |qdd| each robot met on the way."""
+    import oracle as O
+    q, qd = q.astype(np.float32).copy(), qd.astype(np.float32).copy()
+    peak = np.zeros(len(q))
+    dt32 = np.float32(dt)
+
+    def fma(a, b, c):
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(np.float32)
+    for _ in range(K):
+        with np.errstate(all="ignore"):
+            qdd = O.step(desc, q, qd, goal, precision=precision, **obs)["qdd64"].astype(np.float32)
+            peak = np.maximum(peak, np.nan_to_num(np.abs(qdd).max(axis=1), nan=np.inf))
+            for _ in range(sub):
+                qd = fma(dt32, qdd, qd)
+                q = fma(dt32, qd, q)
+    return q, qd, peak
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad"])
+@pytest.mark.parametrize("workload", ["config2", "config3"])
+def test_fused_rollout_against_the_oracle(hip_lib, golden_dir, workload, kernel):
+    """rmp2_rollout against the ORACLE's closed loop (not against the HIP step), per robot, on every robot whose oracle
+    trajectory stays tame (finite, |qdd| <= 20 throughout): K = 3 control steps at 1e-5 * max(1, |.|) for q and qd;
+    K = 10 at 1e-5 for q and 1e-4 for qd; K = 40 (4 s of plant time) at 1e-3, there on the robots whose trajectory the
+    oracle's OWN fp32 and fp64 evaluations of the reference algorithm agree on to 1e-4: the closed loop amplifies
+    rounding differences by itself (joints inside the limit band: ~100x per 0.2 s in any implementation, the reference's
+    included), and a robot on which the algorithm disagrees with itself cannot pin anything.  Measured worst cases:
+    9e-7 / 1e-5 (q / qd) at K = 10."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, f"{workload}.npz"))
+    _, desc = Cf.config2() if workload == "config2" else Cf.config3()
+    old_env = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel
+    try:
+        eng = Engine(desc, 0)
+    finally:
+        if old_env is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old_env
+    sub, dt = 10, 0.01
+    okw = dict(spheres=g["spheres"]) if workload == "config3" else {}
+    obs = eng.obstacles(spheres=torch.from_numpy(g["spheres"])) if workload == "config3" else None
+    goal = torch.from_numpy(g["goal"]).cuda()
+    for K, rel, rel_v in ((3, 1e-5, 1e-5), (10, 1e-5, 1e-4), (40, 1e-3, 1e-3)):
+        q_ref, qd_ref, peak = _oracle_rollout(desc, g["q"], g["qd"], g["goal"], K, sub, dt, **okw)
+        qf, qdf = torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["qd"]).cuda()
+        st = torch.zeros(len(g["q"]), dtype=torch.int32, device="cuda")
+        eng.rollout(qf, qdf, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt, status=st)
+        torch.cuda.synchronize()
+        assert kernel in eng.last_kernel()
+        tame = np.isfinite(q_ref).all(axis=1) & np.isfinite(qd_ref).all(axis=1) & (peak <= 20.0)
+        if K > 10:
+            q64, qd64, _ = _oracle_rollout(desc, g["q"], g["qd"], g["goal"], K, sub, dt, precision="f64", **okw)
+            with np.errstate(all="ignore"):
+                tame &= (np.abs(q64 - q_ref).max(axis=1) <= 1e-4 * np.maximum(1.0, np.abs(q_ref).max(axis=1))) & \
+                        (np.abs(qd64 - qd_ref).max(axis=1) <= 1e-4 * np.maximum(1.0, np.abs(qd_ref).max(axis=1)))
+        assert tame.mean() > (0.95 if K <= 10 else 0.7), f"K={K}: only {tame.mean():.2f} of the oracle trajectories are tame"
+        eq = np.abs(qf.cpu().numpy() - q_ref).max(axis=1) / np.maximum(1.0, np.abs(q_ref).max(axis=1))
+        ev = np.abs(qdf.cpu().numpy() - qd_ref).max(axis=1) / np.maximum(1.0, np.abs(qd_ref).max(axis=1))
+        assert (eq[tame] <= rel).all() and (ev[tame] <= rel_v).all(), \
+            f"{workload} {kernel} K={K}: q err {eq[tame].max():.2e}, qd err {ev[tame].max():.2e} (tame {tame.sum()})"
+        assert np.abs(q_ref[tame] - g["q"][tame]).max() > 1e-3   # the fleet moved
+
+
+def test_rollout_refuses_a_strict_pinv_handle(hip_lib):
+    """rmp2_rollout resolves by elimination with per-robot pseudo-inverse fall-through; a handle created with solve="pinv"
+    asked for the strict pseudo-inverse on every robot and must be refused, not silently resolved otherwise."""
+    import torch
+    from riemannian_motion_policies_amd import _native, configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2("pinv")
+    eng = Engine(desc, 0)
+    s = Cf.sample_panda_states(np.random.default_rng(2), 8)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    eng.step(q, qd, goal)  # single steps are fine
+    with pytest.raises(_native.Rmp2Error, match="PINV"):
+        eng.rollout(q, qd, goal, n_control_steps=2)

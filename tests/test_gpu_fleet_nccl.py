@@ -1,0 +1,82 @@
+"""BASELINE config 4's defining element on real hardware: the sphere table all-gathered over RCCL (torch.distributed
+backend "nccl") on a side stream, double-buffered one step ahead, feeding the HIP control step.
+
+World size 1 -- the driver's GPU box has one device -- but the collective is the real one (ObstacleExchange issues
+all_gather_into_tensor whenever a process group exists), and so are the stream / event orderings between the producer of
+the local slice, the gather, the consuming kernel and the gather that overwrites the buffer two steps later.  The
+process group lives in THIS process: a GPU-initialised process must not fork + exec children on this pool.  Ranks > 1
+are covered on CPU by tests/test_fleet_gloo.py (gloo, world size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def nccl_group(hip_lib):
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    yield dist
+    if created:
+        dist.destroy_process_group()
+
+
+def test_rccl_obstacle_exchange_feeds_the_hip_step(nccl_group, golden_dir):
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    from riemannian_motion_policies_amd.fleet import ObstacleExchange
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    _, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    q, qd, goal = (torch.from_numpy(g[k]).to(dev) for k in ("q", "qd", "goal"))
+    K = len(g["spheres"])
+    exch = ObstacleExchange(K, dev)
+    assert exch.collective and exch.world == 1
+    # the obstacles move between control steps (the reference's "dynamic" obstacles are static bodies whose positions
+    # change from step to step, quirk Q6): step k must see table k, through whichever of the two buffers it lands in
+    tables = [g["spheres"].copy() for _ in range(5)]
+    for k, t in enumerate(tables):
+        t[:, :2] *= np.float32(1.0 + 0.03 * k)   # pushed outwards, away from the arms: clearance only grows (>= 0.05 m kept)
+    local = torch.from_numpy(tables[0]).to(dev)
+    produced = torch.cuda.Event()
+    produced.record(torch.cuda.current_stream(dev))
+    exch.start(local, produced=produced)
+    outs, seen = [], []
+    for k in range(4):
+        tbl = exch.finish()                       # current stream waits for the gather of table k
+        seen.append(tbl.data_ptr())
+        outs.append(eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tbl)).clone())
+        exch.consumed()                           # the gather that reuses this buffer must wait for this kernel
+        local.copy_(torch.from_numpy(tables[k + 1]).to(dev))   # producer of the next local slice, on the current stream
+        produced = torch.cuda.Event()
+        produced.record(torch.cuda.current_stream(dev))
+        exch.start(local, produced=produced)      # gathered into the OTHER buffer while the kernel of step k runs
+    exch.finish()
+    torch.cuda.synchronize(dev)
+    assert len(set(seen)) == 2 and seen[0] == seen[2] and seen[1] == seen[3], "the two table buffers must alternate"
+    assert "quad" in eng.last_kernel() or "hex" in eng.last_kernel()
+    for k in range(4):
+        ref = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[k])["qdd64"]
+        err = np.abs(outs[k].cpu().numpy() - ref).max(axis=1)
+        tol = ATOL * np.maximum(1.0, np.abs(ref).max(axis=1))
+        assert (err <= tol).all(), f"step {k}: worst {err.max():.3e}"
+    # the tables differ enough for a stale buffer to be caught
+    ref0 = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[0])["qdd64"]
+    ref3 = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[3])["qdd64"]
+    assert np.abs(ref0 - ref3).max() > 1e-3

@@ -124,3 +124,29 @@ def test_two_joint_template_and_status_paths(torch_mod, golden_dir, kernel):
     torch.cuda.synchronize()
     assert st.cpu().numpy()[0] & 1 and not np.isfinite(out.cpu().numpy()[0]).all()
     _check(out.cpu().numpy()[1:], ref["qdd64"][1:], f"two-joint + damping {kernel}, robots next to a NaN one")
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad", "lane"])
+@pytest.mark.parametrize("key", ["tj", "tjd", "pdi", "p04"])
+def test_exp04_sets_all_mappings(torch_mod, golden_dir, kernel, key):
+    """Identity-map TargetPolicy + JointLimitAvoidance (04_driving_into_jointlimits.py:46-52) on the TwoJoint and on the
+    Panda, and TargetPolicy(FK) + ConfigurationSpaceBiasing (04_nullspace_control.py:41-52), through every mapping,
+    against the autograd vectors.  `tj` (the script's own set) has no inertia leaf: whatever RMP2_KERNEL says it is
+    resolved by the strict pseudo-inverse kernel -- the reference's only resolve."""
+    torch = torch_mod
+    from riemannian_motion_policies_amd import configs as Cf
+    g = np.load(os.path.join(golden_dir, "exp04.npz"))
+    _, desc = {"tj": lambda: Cf.exp04_two_joint(), "tjd": lambda: Cf.exp04_two_joint(with_damping=True),
+               "pdi": Cf.exp04_panda_identity_target, "p04": Cf.panda04_nullspace}[key]()
+    eng = _engine(desc, kernel)
+    R, n = g[f"{key}_q"].shape
+    M = torch.empty((R, n, n), dtype=torch.float64, device="cuda")
+    f = torch.empty((R, n), dtype=torch.float64, device="cuda")
+    qdd = eng.step(torch.from_numpy(g[f"{key}_q"]), torch.from_numpy(g[f"{key}_qd"]), torch.from_numpy(g[f"{key}_goal"]),
+                   M=M, f=f)
+    torch.cuda.synchronize()
+    if key != "tj":
+        want = {"hex": "hex", "quad": "quad", "lane": "one lane"}[kernel]
+        assert want in eng.last_kernel(), eng.last_kernel()
+    assert np.abs(M.cpu().numpy() - g[f"{key}_M"]).max() < 5e-6 and np.abs(f.cpu().numpy() - g[f"{key}_f"]).max() < 5e-6
+    _check(qdd.cpu().numpy(), g[f"{key}_qdd"], f"exp04 {key} {kernel}")
