@@ -102,9 +102,9 @@ struct HexLds {
 
 // bytes of dynamic LDS a launch needs (host side)
 template <int N>
-inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats) {
-  const size_t per_wave = HexLds<N>::kFloats + kHexRobots * hex_pad(n_ops * 12) + 2 * kHexRobots * hex_pad(n_ops * 8) +
-                          16 * kHexRobots +
+inline size_t hex_lds_bytes(int waves, int n_ops, int blob16, int n_sphere_floats, bool with_wa = false) {
+  const size_t per_wave = HexLds<N>::kFloats + kHexRobots * hex_pad(n_ops * 12) +
+                          (with_wa ? 3 : 2) * kHexRobots * hex_pad(n_ops * 8) + 16 * kHexRobots +
                           kHexRobots * RMP2_MAX_DOF;
   return sizeof(float) * (waves * per_wave + n_sphere_floats) + 16 * (size_t)blob16;
 }
@@ -151,7 +151,7 @@ template <int N, int SLOTS>
 __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s, int g, const float* my_q,
                                                        const float* my_qd, float* T0, float* SCb, float* VAb,
                                                        float* DOF, const HexCtl* s_ctl, const HexOp* s_hops,
-                                                       const int32_t* s_jump, const uint32_t* s_op_anc,
+                                                       const int32_t* s_jump, const uint32_t* s_op_anc, float* WAb = nullptr,
                                                        unsigned long long* stp = nullptr, int* stn = nullptr) {
   const int n_ops = hdr.n_ops;
   float* const Tb0 = T0 + g * hex_pad(n_ops * 12);
@@ -410,6 +410,11 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
       for (int r = 0; r < 3; ++r) ak[r] = t1[r] + t2[r] + Y[slot][3 + r];
       VA[2 * kk[slot]] = make_float4(vk[slot][0], vk[slot][1], vk[slot][2], ak[0]);
       VA[2 * kk[slot] + 1] = make_float4(ak[1], ak[2], 0.f, 0.f);
+      if (WAb) {  // angular velocity and angular bias acceleration of the frame (attached-point leaves)
+        float4* const WA = reinterpret_cast<float4*>(WAb + g * hex_pad(n_ops * 8));
+        WA[2 * kk[slot]] = make_float4(Wk[0], Wk[1], Wk[2], ALk[0]);
+        WA[2 * kk[slot] + 1] = make_float4(ALk[1], ALk[2], 0.f, 0.f);
+      }
     }
   }
   hex_sync();
@@ -419,7 +424,10 @@ __device__ __forceinline__ const float* hex_kinematics(const QuadHdr& hdr, int s
 // WAVES = waves per block.  Each wave owns four robots and its own LDS working set; the waves of a block share one
 // staged copy of the program and of the obstacle table (loaded cooperatively, one real barrier after the prologue).
 // ROLL = build with the fused closed-loop rollout (control-step loop + plant ticks); the plain step carries none of it.
-template <int N, bool CAP, int WAVES, bool ROLL>
+// PT = build with the attached-point leaves (CollisionAvoidance on [FK, TaskmapRelative4x4, 4x4 -> position], taskmap.py:79-99,
+// rmp.py:264-315): every pair carries its own Jacobian (the point is offset from the frame origin); the plain build has
+// none of that code.
+template <int N, bool CAP, int WAVES, bool ROLL, bool PT = false>
 __global__ void __launch_bounds__(kWave * WAVES, 1)
 rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, const float* __restrict__ q,
                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
@@ -451,10 +459,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- LDS carve-up -----------------------------------------------------------------------------------
   // [per-wave static x WAVES | per-wave T SC VA x WAVES | per-wave goal tile x WAVES | block qdd tile | sphere table | program]
   float* const wl = lds + wv * HexLds<N>::kFloats;                       // this wave's static region
-  const int dyn_per_wave = kHexRobots * hex_pad(n_ops * 12) + 2 * kHexRobots * hex_pad(n_ops * 8);
+  const int dyn_per_wave = kHexRobots * hex_pad(n_ops * 12) + (PT ? 3 : 2) * kHexRobots * hex_pad(n_ops * 8);
   float* const T0 = lds + WAVES * HexLds<N>::kFloats + wv * dyn_per_wave;
   float* const SCb = T0 + kHexRobots * hex_pad(n_ops * 12);   // [4][n_ops][8] prefix-sum exchange
   float* const VAb = SCb + kHexRobots * hex_pad(n_ops * 8);   // [4][n_ops][8] (v, a) of every frame origin
+  float* const WAb = PT ? VAb + kHexRobots * hex_pad(n_ops * 8) : nullptr;  // [4][n_ops][8] (w, alpha), PT builds only
   const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
   float* const goal_base = lds + WAVES * (HexLds<N>::kFloats + dyn_per_wave);
@@ -572,9 +581,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
-    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 1>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc, WAb RMP2_KARGS);
   else
-    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc RMP2_KARGS);
+    TW = hex_kinematics<N, 2>(hdr, s, g, my_q, my_qd, T0, SCb, VAb, DOF, s_ctl, s_hops, s_jump, s_op_anc, WAb RMP2_KARGS);
   RMP2_STAMP();  // 2: kinematics done
 
   // ---- the fp64 system, one row per lane: A[j] = M[s][j], fv = f[s] -------------------------------------
@@ -596,26 +605,40 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const float4* va4 = reinterpret_cast<const float4*>(VAb + g * hex_pad(n_ops * 8) + k * 8);
     const float4 f0 = va4[0], f1 = va4[1];
     const float P3[3] = {tp.y, tp.z, tp.w}, V3[3] = {f0.x, f0.y, f0.z}, A3[3] = {f0.w, f1.x, f1.y};
-    // Jacobian column of MY dof at this frame's origin; all columns through LDS
-    float mycol[3] = {0.f, 0.f, 0.f};
-    if (s < N && ((op.anc_mask >> s) & 1u)) {
-      const float4* d4 = reinterpret_cast<const float4*>(DOF + s * 8);
-      const float4 z4 = d4[0], o4 = d4[1];
-      const float zj[3] = {z4.x, z4.y, z4.z};
-      const float dd[3] = {P3[0] - o4.x, P3[1] - o4.y, P3[2] - o4.z};
-      float cr[3];
-      cross3(zj, dd, cr);
+    // Jacobian column of MY dof at a point moving with this frame (its origin, or an attached point); all columns
+    // through LDS.  Columns of dofs that do not move the frame are written as zeros: no branches in the pull-back.
+    float mycol[3];
+    float col[N][3];
+    auto set_cols = [&](const float pt[3]) {
+      mycol[0] = mycol[1] = mycol[2] = 0.f;
+      if (s < N && ((op.anc_mask >> s) & 1u)) {
+        const float4* d4 = reinterpret_cast<const float4*>(DOF + s * 8);
+        const float4 z4 = d4[0], o4 = d4[1];
+        const float zj[3] = {z4.x, z4.y, z4.z};
+        const float dd[3] = {pt[0] - o4.x, pt[1] - o4.y, pt[2] - o4.z};
+        float cr[3];
+        cross3(zj, dd, cr);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) mycol[c] = my_rev ? cr[c] : zj[c];
-    }
-    COL[s] = make_float4(mycol[0], mycol[1], mycol[2], 0.f);
-    hex_sync();
-    float col[N][3];  // columns of dofs that do not move the frame were written as zeros: no branches needed
+        for (int c = 0; c < 3; ++c) mycol[c] = my_rev ? cr[c] : zj[c];
+      }
+      COL[s] = make_float4(mycol[0], mycol[1], mycol[2], 0.f);
+      hex_sync();
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float4 c4 = COL[j];
-      col[j][0] = c4.x, col[j][1] = c4.y, col[j][2] = c4.z;
-    }
+      for (int j = 0; j < N; ++j) {
+        const float4 c4 = COL[j];
+        col[j][0] = c4.x, col[j][1] = c4.y, col[j][2] = c4.z;
+      }
+    };
+    // pull-back into MY row:  f_s += col_s . h ;  A[s][j] += (S col_s) . col_j   (rmp.py:165-167)
+    auto pull_back = [&](const float S[6], const float h[3]) {
+      const float u[3] = {S[0] * mycol[0] + S[1] * mycol[1] + S[2] * mycol[2],
+                          S[1] * mycol[0] + S[3] * mycol[1] + S[4] * mycol[2],
+                          S[2] * mycol[0] + S[4] * mycol[1] + S[5] * mycol[2]};
+      fv += (double)dot3(mycol, h);
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[j] += (double)dot3(u, col[j]);
+    };
+    set_cols(P3);
     for (int li = 0; li < op.leaf_count; ++li) {
       const DevLeaf& lf = s_leaves[op.leaf_begin + li];  // staged in execution order
       LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);
@@ -623,7 +646,53 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       lh.taskmap = uni<true>(lh.taskmap);
       lh.goal_offset = uni<true>(lh.goal_offset);
       float S[6], h[3];
-      if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+      if (PT && lh.taskmap == RMP2_TASKMAP_FK_POINT) {
+        // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position], one trip per pair (taskmap.py:79-99):
+        //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J = Jacobian at x;  pulled back pair by
+        //   pair (rmp.py:165-167 with B pairs on the batch axis); every lane of the robot forms the small vectors
+        const int lidx = uni<true>(lf.index);
+        const int pb = obs.pair_begin[lidx];
+        const int cnt = obs.pair_begin[lidx + 1] - pb;
+        const size_t pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
+        const float4* t4 = reinterpret_cast<const float4*>(TW + k * 12);
+        const float4 r0 = t4[0], r1 = t4[1];
+        const float Rw[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, tp.x};
+        const float4* wa4 = reinterpret_cast<const float4*>(WAb + g * hex_pad(n_ops * 8) + k * 8);
+        const float4 w0 = wa4[0], w1 = wa4[1];
+        const float Wf[3] = {w0.x, w0.y, w0.z}, ALf[3] = {w0.w, w1.x, w1.y};
+#pragma nounroll
+        for (int trip = 0; trip < cnt; ++trip) {
+          const float* rel = obs.p_link + (pbase + trip) * 3;
+          const float* nvp = obs.p_obs + (pbase + trip) * 3;
+          const float dd = obs.dist[pbase + trip];
+          float r[3], pt[3], t1[3], t2[3], xdp[3], cp[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            r[c] = Rw[3 * c] * rel[0] + Rw[3 * c + 1] * rel[1] + Rw[3 * c + 2] * rel[2];
+            pt[c] = P3[c] + r[c];
+          }
+          cross3(Wf, r, t1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
+          cross3(Wf, t1, t2);
+          cross3(ALf, r, t1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) cp[c] = A3[c] + t1[c] + t2[c];
+          const float nv[3] = {nvp[0], nvp[1], nvp[2]};
+          float xdd[3], wgt;
+          leaf_collision_avoidance(lh.P, dd, nv, xdp, xdd, wgt);
+          S[0] = S[3] = S[5] = wgt;
+          S[1] = S[2] = S[4] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] = wgt * (xdd[c] - cp[c]);
+          hex_sync();  // every lane has taken its copy of the previous columns
+          set_cols(pt);
+          pull_back(S, h);
+        }
+        hex_sync();
+        set_cols(P3);  // back to the frame origin for the leaves that follow
+        continue;
+      } else if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
         float gl[3], xdd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
@@ -679,13 +748,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 #pragma unroll
         for (int c = 0; c < 3; ++c) h[c] = hex_sum(h[c]);
       }
-      // pull-back into MY row:  f_s += col_s . h ;  A[s][j] += (S col_s) . col_j   (rmp.py:165-167)
-      const float u[3] = {S[0] * mycol[0] + S[1] * mycol[1] + S[2] * mycol[2],
-                          S[1] * mycol[0] + S[3] * mycol[1] + S[4] * mycol[2],
-                          S[2] * mycol[0] + S[4] * mycol[1] + S[5] * mycol[2]};
-      fv += (double)dot3(mycol, h);
-#pragma unroll
-      for (int j = 0; j < N; ++j) A[j] += (double)dot3(u, col[j]);
+      pull_back(S, h);
     }
     hex_sync();  // COL is rewritten for the next frame
   }
@@ -840,8 +903,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 
   // ---- resolve: Gauss-Jordan in fp64 without row exchanges, one row per lane ------------------------------
   // (certification as lu_solve<N>, rmp2_solve.h: tiny pivot, multiplier growth, non-finite result -> careful path)
-  bool flagged;
-  {
+  bool flagged = true;
+  if (!hdr.strict) {  // (strict: solve = PINV asks for the pseudo-inverse on every robot, rmp.py:153 -- no elimination)
     // magnitudes are compared on the HIGH WORD of the doubles (monotone for non-negative values, NaN / Inf on top):
     // integer max at fp32 rate instead of dependent fp64 max chains.  scale = max |M_ij| rounded down to its high word.
     int scale_hi = 0;
@@ -932,12 +995,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       // ---- rare path: every lane of the robot runs the careful solve on the whole system -----------------
       double W[N * (N + 1)], T[N * (N + 1)], xp[N];
       for (int i = 0; i < N * (N + 1); ++i) W[i] = SYS[i];
-      status |= RMP2_STATUS_PINV_PATH;
+      if (!hdr.strict) status |= RMP2_STATUS_PINV_PATH;
       bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does)
       for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);
       if (!finite_in) {
         for (int i = 0; i < N; ++i) xp[i] = __builtin_nan("");
-      } else if (!lu_pivot_compact(W, T, N, xp)) {
+      } else if (hdr.strict || !lu_pivot_compact(W, T, N, xp)) {
         const int dropped = pinv_solve_compact(W, N, n_dof, xp);
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }

@@ -766,7 +766,7 @@ struct rmp2_handle {
   DevProgram* d_prog_full = nullptr;
   int n_template = 0;  // N of the kernel instantiation
   bool has_distance = false;
-  bool has_point = false;  // attached-point leaves (CollisionAvoidance): lane-per-robot kernel only
+  bool has_point = false;  // attached-point leaves (CollisionAvoidance): hex and lane-per-robot kernels
   int n_id_leaves = 0;
   int n_leaf_ops = 0;
   uint32_t rev_mask = 0;
@@ -1102,7 +1102,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput build beyond: scalar-cache program walk, 256 registers (two waves per SIMD: the 16 waves
   // a CU owes to a 65 536-robot fleet run as two even rounds of 8).  LDS is <= 10 KB per wave, so a 128-register build
@@ -1125,6 +1125,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
 #undef RMP2_QUAD_LAUNCH
 }
 
+constexpr size_t kLdsDefault = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
+
 template <int N, int WAVES, bool ROLL>
 void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                   const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
@@ -1132,26 +1134,40 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   const int blocks = (R + per_block - 1) / per_block;
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds));
+  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds),
+                                        h->has_point);
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0,
+                    h->strict ? 1 : 0};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
-  h->last_kernel = "rmp2_step_hex_kernel (16 lanes per robot)";
-  if (o.capsule)
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, true, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
-                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
+  h->last_kernel = h->strict ? "rmp2_step_hex_kernel (16 lanes per robot, strict pseudo-inverse)"
+                             : "rmp2_step_hex_kernel (16 lanes per robot)";
+#define RMP2_HEX_LAUNCH(CAP, PT)                                                                                          \
+  do {                                                                                                                    \
+    auto kern = rmp2_step_hex_kernel<N, CAP, WAVES, ROLL, PT>;                                                            \
+    if (bytes > kLdsDefault)                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
+                       ro, R);                                                                                            \
+  } while (0)
+  if (!ROLL && h->has_point)  // attached-point leaves (rollouts refuse them upstream; capsule tables: sphere modes only)
+    RMP2_HEX_LAUNCH(false, true);
+  else if (o.capsule)
+    RMP2_HEX_LAUNCH(true, false);
   else
-    hipLaunchKernelGGL((rmp2_step_hex_kernel<N, false, WAVES, ROLL>), dim3(blocks), dim3(kWave * WAVES), bytes, s, blob,
-                       h->hex_blob16, hdr, q, qd, goal, gs, o, out, ro, R);
+    RMP2_HEX_LAUNCH(false, false);
+#undef RMP2_HEX_LAUNCH
 }
 
-constexpr size_t kLdsLimit = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
+// A launch may ask for up to 64 KiB of dynamic LDS as it is; beyond that (up to the CU's 160 KiB) the function attribute is
+// raised first (launch_hex_w).
+constexpr size_t kLdsLimit = 160 * 1024;
 
 template <int N>
 size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds));
+  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds), h->has_point);
 }
 
 // big programs (many frames / leaves) do not fit four waves' working sets into one block's LDS: one wave per
@@ -1160,7 +1176,8 @@ template <int N>
 bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                 const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
-  if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit) {
+  // four-wave blocks while at least two of them fit a CU (the block shares one staged program); one-wave blocks beyond
+  if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit / 2) {
     if (rollout)
       launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
     else
@@ -1182,15 +1199,19 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // ConfigurationSpaceBiasing) are rank deficient by construction on redundant arms (e.g. a lone target policy:
   // rank <= 3 of 9): every robot would fall through to the pseudo-inverse anyway, so AUTO goes there directly
   // (register-resident Jacobi, same result).
-  if ((h->strict || h->likely_singular) && !rollout) return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
-  // Kernel choice (both produce the same numbers to fp32 rounding):
-  //  * quad-per-robot: shortest dependent chain and 4x the waves -- wins whenever the fleet cannot
-  //    fill the SIMDs on its own (R <= 16384) and for every set with distance leaves (the pair loop
-  //    splits 4 ways); the only kernel with the fused rollout loop;
-  //  * lane-per-robot: no redundant per-lane work -- wins for large fleets without distance leaves.
-  //  * sets with attached-point leaves (CollisionAvoidance: a Jacobian per pair) exist in the lane kernel only.
-  //  * hex (16 lanes per robot): the latency build for fleets that leave SIMDs idle under the quad mapping.
-  const bool hex_ok = !h->has_point && h->goal_floats <= 16 && !h->strict && !h->likely_singular;
+  const bool hex_forced = h->kernel_choice == 3;
+  if ((h->strict || h->likely_singular) && !rollout && !hex_forced)
+    return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
+  // Kernel choice (all mappings produce the same numbers to fp32 rounding):
+  //  * hex (16 lanes per robot, rmp2_hex.h): the latency build -- fleets up to 20 480 robots, where the other mappings
+  //    leave SIMDs idle; every leaf kind, both resolves, robots with up to 16 dofs; carries the fused rollout loop;
+  //  * quad (4 lanes per robot, rmp2_quad.h): the throughput build for sets with distance leaves (the pair loops split
+  //    4 ways); carries the fused rollout loop; no attached-point leaves;
+  //  * lane-per-robot (this file): no redundant per-lane work -- large fleets without distance leaves; the strict
+  //    pseudo-inverse (register-resident Jacobi) and attached-point leaves at any fleet size.
+  // hex carries every leaf kind and both resolves (strict: the pseudo-inverse on every robot through its careful path;
+  // slower than the lane kernel's register-resident Jacobi, so that path is taken on request / for n_dof > 9 only)
+  const bool hex_ok = h->goal_floats <= 16 && !(h->has_point && rollout);
   // measured (rocprofv3 kernel times, 3-leaf set / cluttered set, hex vs the kernel chosen otherwise):
   //   R =  4096:  8.7 / 19.7 us  vs  13.4 / 40.0        R = 20480: 16.9 / 47.2 us  vs  19.4 / 54.3
   //   R = 12288: 12.2 / 30.4 us  vs  14.5 / 42.6        R = 24576: 19.6 / 54.7 us  vs  19.7 / 54.9
@@ -1240,14 +1261,10 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (rc == RMP2_OK) rc = compile_program(*desc, Pfull, n_slots_full, err, /*prune=*/false);
   if (rc != RMP2_OK) return fail(nullptr, rc, err);
   if (desc->robot.n_dof > 9) {
-    // 10 .. 16 dofs: the hex kernel (one metric row per lane, 16 lanes per robot) is the only mapping instantiated
-    if (desc->solve_mode == RMP2_SOLVE_PINV)
-      return fail(nullptr, RMP2_ERR_UNSUPPORTED, "solve = PINV is instantiated for n_dof <= 9");
+    // 10 .. 16 dofs: the hex kernel (one metric row per lane, 16 lanes per robot) is the only mapping instantiated; it
+    // carries every leaf kind and both resolves
     if (desc->goal_floats > 16)
       return fail(nullptr, RMP2_ERR_UNSUPPORTED, "more than 16 goal floats per robot with n_dof > 9");
-    for (int l = 0; l < desc->n_leaves; ++l)
-      if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_POINT)
-        return fail(nullptr, RMP2_ERR_UNSUPPORTED, "attached-point leaves are instantiated for n_dof <= 9");
   }
   if (n_slots > 2 || n_slots_full > 2)
     return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kinematic tree needs more than 2 saved branch states");
@@ -1272,11 +1289,6 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
         (lf.kind == RMP2_LEAF_CSPACE_BIASING && lf.params[0] + lf.params[4] > 0.f) ||
         (lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING && lf.params[2] > 0.f))
       h->likely_singular = false;
-  }
-  if (h->likely_singular && h->n_template == 16) {
-    delete h;
-    return fail(nullptr, RMP2_ERR_UNSUPPORTED,
-                "a set without an inertia leaf resolves by the pseudo-inverse kernel, instantiated for n_dof <= 9");
   }
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;

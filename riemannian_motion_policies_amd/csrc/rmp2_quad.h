@@ -421,6 +421,7 @@ struct QuadHdr {
   int32_t is_chain;  // every frame's parent is the previous frame of the program (rmp2_hex.h only)
   uint32_t dof_ops[3];  // op that owns dof j, 5 bits each, 6 dofs per word (rmp2_quad.h only)
   float cull_c0;        // max over the distance leaves of (metric_modulation_radius + margin): cull threshold
+  int32_t strict;       // 1: solve = PINV, the pseudo-inverse on every robot (rmp2_hex.h only; the quad kernel is AUTO)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }

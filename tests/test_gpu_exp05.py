@@ -30,15 +30,30 @@ def _check(got, ref, what):
     assert (err <= tol).all(), f"{what}: worst {err.max():.3e}"
 
 
+def _engine(desc, kernel):
+    from riemannian_motion_policies_amd.engine import Engine
+    old = os.environ.get("RMP2_KERNEL")
+    if kernel:
+        os.environ["RMP2_KERNEL"] = kernel
+    try:
+        return Engine(desc, 0)
+    finally:
+        if old is None:
+            os.environ.pop("RMP2_KERNEL", None)
+        else:
+            os.environ["RMP2_KERNEL"] = old
+
+
+@pytest.mark.parametrize("kernel", ["hex", "lane"])
 @pytest.mark.parametrize("solve", ["auto", "pinv"])
 @pytest.mark.parametrize("key", ["tj", "pd"])
-def test_exp05_golden(torch_mod, golden_dir, key, solve):
+def test_exp05_golden(torch_mod, golden_dir, key, solve, kernel):
+    """Both mappings that carry the attached-point leaves, both resolves (hex + pinv = its strict careful path)."""
     torch = torch_mod
     from riemannian_motion_policies_amd import configs as Cf
-    from riemannian_motion_policies_amd.engine import Engine
     g = np.load(os.path.join(golden_dir, "exp05.npz"))
     _, desc = Cf.exp05_two_joint(solve) if key == "tj" else Cf.exp05_panda(solve)
-    eng = Engine(desc, 0)
+    eng = _engine(desc, kernel)
     R, n = g[f"{key}_q"].shape
     M = torch.empty((R, n, n), dtype=torch.float64, device="cuda")
     f = torch.empty((R, n), dtype=torch.float64, device="cuda")
@@ -47,12 +62,13 @@ def test_exp05_golden(torch_mod, golden_dir, key, solve):
     qdd = eng.step(torch.from_numpy(g[f"{key}_q"]), torch.from_numpy(g[f"{key}_qd"]), torch.from_numpy(g[f"{key}_goal"]),
                    obstacles=o, M=M, f=f)
     torch.cuda.synchronize()
+    assert ("hex" if kernel == "hex" else "one lane") in eng.last_kernel(), eng.last_kernel()
     assert np.abs(M.cpu().numpy() - g[f"{key}_M"]).max() < 5e-6
     assert np.abs(f.cpu().numpy() - g[f"{key}_f"]).max() < 2e-6
-    _check(qdd.cpu().numpy(), g[f"{key}_qdd"], f"exp05 {key}/{solve}")
+    _check(qdd.cpu().numpy(), g[f"{key}_qdd"], f"exp05 {key}/{solve}/{kernel}")
 
 
-@pytest.mark.parametrize("R,B", [(1, 1), (65, 3), (1000, 5)])
+@pytest.mark.parametrize("R,B", [(1, 1), (65, 3), (1000, 5), (30000, 2)])
 def test_exp05_batches_vs_oracle(torch_mod, R, B):
     torch = torch_mod
     import oracle as O
@@ -66,8 +82,11 @@ def test_exp05_batches_vs_oracle(torch_mod, R, B):
     o = eng.obstacles(p_link=torch.from_numpy(rel), p_obs=torch.from_numpy(nv), dist=torch.from_numpy(dist))
     qdd = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=o)
     torch.cuda.synchronize()
-    ref = O.step(desc, s["q"], s["qd"], s["goal"], p_link=rel, p_obs=nv, dist=dist)
-    _check(qdd.cpu().numpy(), ref["qdd64"], f"exp05 panda R={R} B={B}")
+    # default dispatch: the hex mapping up to 20 480 robots, the lane-per-robot kernel beyond
+    assert ("hex" if R <= 20480 else "one lane") in eng.last_kernel(), eng.last_kernel()
+    sub = slice(0, min(R, 1500))
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], p_link=rel[sub], p_obs=nv[sub], dist=dist[sub])
+    _check(qdd.cpu().numpy()[sub], ref["qdd64"], f"exp05 panda R={R} B={B}")
 
 
 def test_exp05_script_through_class_surface(torch_mod):

@@ -140,8 +140,8 @@ def test_deep_chain_more_frames_than_lanes(tmp_path, kernel, hip_lib):
 
 
 def test_twelve_dof_robot(tmp_path, hip_lib):
-    """10 .. 16 actuated dofs (the ABI's RMP2_MAX_DOF) run on the hex mapping's N = 16 template at every fleet size;
-    what has no N = 16 instantiation is refused at rmp2_create."""
+    """10 .. 16 actuated dofs (the ABI's RMP2_MAX_DOF) run on the hex mapping's N = 16 template at every fleet size,
+    with every leaf kind and both resolves (strict pseudo-inverse, attached-point leaves, sets without an inertia leaf)."""
     import torch
     import oracle as O
     from riemannian_motion_policies_amd import _native, descriptor as D, urdf
@@ -182,11 +182,53 @@ def test_twelve_dof_robot(tmp_path, hip_lib):
         assert np.abs(M.cpu().numpy()[sub] - ref["M"]).max() < 5e-6 * max(1.0, np.abs(ref["M"]).max())
         err = np.abs(out.cpu().numpy()[sub] - ref["qdd64"]).max(axis=1)
         assert (err <= ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))).all(), err.max()
-    # refused combinations name their reason
-    for bad, word in ((D.build_desc(t, specs, "pinv"), b"PINV"), (D.build_desc(t, specs[:1]), b"inertia")):
-        with pytest.raises(_native.Rmp2Error) as e:
-            Engine(bad, 0)
-        assert word in str(e.value).encode()
+    # ---- what round 1 refused beyond 9 dofs now runs on the hex mapping ------------------------------------------------
+    R = 130
+    q = rng.uniform(-1.2, 1.2, (R, n)).astype(np.float32)
+    qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+    goal = rng.uniform(-0.5, 0.5, (R, 3)).astype(np.float32)
+    tq, tqd, tg = (torch.from_numpy(x) for x in (q, qd, goal))
+
+    def check(out, ref, what, scale=1.0):
+        err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
+        assert (err <= scale * ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))).all(), f"{what}: {err.max():.3e}"
+
+    # (i) solve = "pinv": the strict pseudo-inverse (rmp.py:153, the reference's only resolve) on every robot
+    d_pinv = D.build_desc(t, specs, "pinv")
+    e_pinv = Engine(d_pinv, 0)
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    out = e_pinv.step(tq, tqd, tg, obstacles=e_pinv.obstacles(spheres=torch.from_numpy(sph)), status=st)
+    torch.cuda.synchronize()
+    assert "strict" in e_pinv.last_kernel() and not st.cpu().numpy().any()
+    check(out, O.step(d_pinv, q, qd, goal, spheres=sph), "12 dof, solve = pinv")
+    # (ii) a set WITHOUT an inertia leaf (identity-map TargetPolicy supplies a full-rank metric, but no leaf the
+    # dispatcher counts as inertia): was refused for n_dof > 9
+    tp = D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_IDENTITY, -1, [0.1, 1.0, 0.1], goal_len=n)
+    d_ni = D.build_desc(t, [specs[0], tp])
+    e_ni = Engine(d_ni, 0)
+    goal2 = np.concatenate([goal, np.clip(q + rng.uniform(-0.4, 0.4, q.shape), -2, 2).astype(np.float32)], axis=1)
+    out = e_ni.step(tq, tqd, torch.from_numpy(goal2))
+    torch.cuda.synchronize()
+    ref = O.step(d_ni, q, qd, goal2)
+    ok = np.array([np.linalg.cond(m) < 100.0 for m in ref["M"]])   # (as for config 1: beyond, fp32 leaves decide the digits)
+    assert ok.mean() > 0.5
+    err = np.abs(out.cpu().numpy() - ref["qdd64"]).max(axis=1)
+    assert (err[ok] <= ATOL * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))[ok]).all(), err[ok].max()
+    # (iii) attached-point leaves (CollisionAvoidance on [FK, TaskmapRelative4x4, 4x4 -> position]): a Jacobian per pair
+    ca = [0.1 * np.e, 0.3, 1.0, 0.3, 1.1, 1e5]
+    sp_pt = specs[:2] + [D.LeafSpec(D.LEAF_COLLISION_AVOIDANCE, D.TASKMAP_FK_POINT, fr, ca) for fr in (F - 1, F // 2, 1)]
+    d_pt = D.build_desc(t, sp_pt)
+    e_pt = Engine(d_pt, 0)
+    B = 3
+    rel = rng.uniform(-0.15, 0.15, (R, 3 * B, 3)).astype(np.float32)
+    nv = rng.normal(size=(R, 3 * B, 3))
+    nv = (nv / np.linalg.norm(nv, axis=-1, keepdims=True)).astype(np.float32)
+    dist = rng.uniform(0.05, 1.3, (R, 3 * B)).astype(np.float32)
+    out = e_pt.step(tq, tqd, tg, obstacles=e_pt.obstacles(p_link=torch.from_numpy(rel), p_obs=torch.from_numpy(nv),
+                                                          dist=torch.from_numpy(dist)))
+    torch.cuda.synchronize()
+    assert "hex" in e_pt.last_kernel()
+    check(out, O.step(d_pt, q, qd, goal, p_link=rel, p_obs=nv, dist=dist), "12 dof, attached-point leaves")
 
 
 @pytest.mark.parametrize("case", ["nine_dof_many_goals", "sixteen_dof"])
