@@ -93,7 +93,8 @@ struct HexLds {
   static constexpr int kRowStride = (2 * (N + 1) + 3) & ~3;             // one pivot row [A_k | f_k] as doubles
   static constexpr int kColStride = hex_pad(kHex * 4);                  // per-robot stride of COL / XCH
   static constexpr int kRow = kXch + kHexRobots * kColStride;           // [4][2][kRowStride]: two pivot rows per exchange
-  static constexpr int kSysStride = 2 * N * (N + 1);                    // the whole system [N][N+1] as doubles
+  static constexpr int kSysStride = 2 * (2 * N * (N + 1) + N);          // the whole system [N][N+1] as doubles, a working
+                                                                        // copy of it and x[N] for the careful solver
   static constexpr int kSys = kRow + kHexRobots * 2 * kRowStride;       // [4][kSysStride]
   static constexpr int kFloats = (kSys + kHexRobots * kSysStride + 3) & ~3;
   // dynamic: T [4][n_ops][12] | SC [4][n_ops][8] | VA [4][n_ops][8] | sphere table | staged program:
@@ -562,7 +563,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     else
       hex_sync();
   }
-  if (n_live <= 0) return;  // a wave past the fleet's tail (it has done its share of the staging)
+  // A wave past the fleet's tail has done its share of the staging and has no robot: it runs ZERO control steps below
+  // and meets the others at the block's final barrier (a barrier some waves never reach is undefined in the HIP model,
+  // even though gfx9's s_barrier happens to drop ended waves).
   RMP2_STAMP();  // 1: prologue done
   const bool spheres_in_lds = obs.n_spheres <= kLdsSpheres;
   const float* my_q = &wl[HexLds<N>::kQ + gi * N];
@@ -575,9 +578,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   uint32_t status = 0u;
 
   // closed-loop rollout (rmp2_rollout): n_iters control steps inside this launch; a plain step is one iteration
-  const int n_iters = ROLL ? ro.n_iters : 1;
+  const int n_iters = n_live <= 0 ? 0 : (ROLL ? ro.n_iters : 1);
+  // (the plain step's condition below is visibly "at most once": the compiler emits a branch, not a loop -- a run-time
+  // trip count costs the step ~3 k cycles of loop-carried state)
 #pragma nounroll
-  for (int it = 0; it < n_iters; ++it) {
+  for (int it = 0; ROLL ? (it < n_iters) : (it == 0 && n_live > 0); ++it) {
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
@@ -991,10 +996,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 
   if (__any(flagged && live)) {
     hex_sync();  // SYS rows of all lanes are in LDS
-    if (flagged) {
-      // ---- rare path: every lane of the robot runs the careful solve on the whole system -----------------
-      double W[N * (N + 1)], T[N * (N + 1)], xp[N];
-      for (int i = 0; i < N * (N + 1); ++i) W[i] = SYS[i];
+    if (flagged && s == 0) {
+      // ---- rare path: lane 0 of the robot runs the careful solve IN LDS, on the parked system (pivoted LU on a working
+      // copy, then the pseudo-inverse in place): no private arrays, so the kernel carries no scratch segment
+      double* const W = SYS;
+      double* const T = SYS + N * (N + 1);
+      double* const xp = T + N * (N + 1);
       if (!hdr.strict) status |= RMP2_STATUS_PINV_PATH;
       bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does)
       for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);
@@ -1007,10 +1014,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       bool finite = true;
       for (int i = 0; i < n_dof; ++i) {
         finite = finite && (fabs(xp[i]) < 1.7e308);
-        if (s == 0) my_out[i] = (float)xp[i];
+        my_out[i] = (float)xp[i];
       }
       if (!finite) status |= RMP2_STATUS_NONFINITE;
     }
+    hex_sync();
   }
 
   if (ROLL && ro.substeps > 0) {
@@ -1035,7 +1043,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- coalesced store of the BLOCK's qdd tile (16 robots, contiguous in HBM): whole cache lines instead of one
   // partial-line write per wave ----------------------------------------------------------------------------
   if (WAVES > 1)
-    __syncthreads();  // waves that returned past the fleet's tail no longer count
+    __syncthreads();  // every wave of the block, tail waves included
   else
     hex_sync();
   {
