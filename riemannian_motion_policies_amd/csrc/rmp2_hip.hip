@@ -1200,7 +1200,11 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // rank <= 3 of 9): every robot would fall through to the pseudo-inverse anyway, so AUTO goes there directly
   // (register-resident Jacobi, same result).
   const bool hex_forced = h->kernel_choice == 3;
-  if ((h->strict || h->likely_singular) && !rollout && !hex_forced)
+  // ... except on 2-dof robots, where the fall-through of a flagged robot is a 2 x 2 Jacobi: there the elimination
+  // mappings (with their split pair loops and culling) keep sets without an inertia leaf, e.g. the TwoJoint half of the
+  // mixed fleet (config 5)
+  const bool cheap_fallthrough = N == 2 && !h->strict;
+  if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough)
     return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
   // Kernel choice (all mappings produce the same numbers to fp32 rounding):
   //  * hex (16 lanes per robot, rmp2_hex.h): the latency build -- fleets up to 20 480 robots, where the other mappings
