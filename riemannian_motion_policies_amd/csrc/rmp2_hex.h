@@ -52,10 +52,10 @@ __device__ __forceinline__ float row_shr_or(float v, float fill) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(f, i, 0x110 + SH, 0xF, 0xF, false));
 }
 __device__ __forceinline__ int hex_maxi(int v) {
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, kXor1, 0xF, 0xF, false));
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, kXor2, 0xF, 0xF, false));
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, kRowHalfMirror, 0xF, 0xF, false));
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, kRowMirror, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, kXor1, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, kXor2, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, kRowHalfMirror, 0xF, 0xF, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, kRowMirror, 0xF, 0xF, true));
   return v;
 }
 __device__ __forceinline__ double hex_maxd(double v) {

@@ -41,17 +41,22 @@ constexpr int kRot1 = quad_perm(1, 2, 0, 3);  // lane i reads component (i+1) % 
 constexpr int kRot2 = quad_perm(2, 0, 1, 3);  // lane i reads component (i+2) % 3
 constexpr int kXor1 = quad_perm(1, 0, 3, 2), kXor2 = quad_perm(2, 3, 0, 1);
 
+// Every control used through these helpers (quad_perm, row_mirror, row_half_mirror) reads an IN-BOUNDS lane for every
+// lane, so "old" and bound_ctrl never decide a value -- but they decide the code: with old = the source and
+// bound_ctrl = 0 the compiler must keep `old` alive in the destination (v_mov + v_mov_dpp + the consuming op, three
+// instructions per use); with old = 0 and bound_ctrl = 1 it folds the permute into the consumer (v_add_f32_dpp,
+// v_max_f32_dpp, v_or_b32_dpp ...: ONE instruction), or emits the bare v_mov_dpp where it cannot.
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
   const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double dppd(double v) {
   const long long b = __builtin_bit_cast(long long, v);
   int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 template <int S>
@@ -280,7 +285,7 @@ __device__ __forceinline__ float4 sphere_aux(const float4 sp, float c0) {
 __device__ __forceinline__ uint32_t dpp_or(uint32_t v, uint32_t w) { return v | w; }
 template <int CTRL>
 __device__ __forceinline__ uint32_t dppu(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // position of the r-th (0-based) set bit of m; r < popcount(m) required
