@@ -10,13 +10,16 @@ def per_launch(d, counter):
 f, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 w, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 robots = int(sys.argv[4])
-# MI355X_MICROARCH.md section HBM: counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests
-# at 64 B for wide (16 B/lane) streams.  This kernel reads 4 B/lane: no doubling applied, both given.
+# MI355X_MICROARCH.md section HBM: counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reads
+# HALF the bytes of a coalesced stream -- measured for 16 B per lane there and for THIS engine's 4 B per lane (and
+# WRITE_SIZE exact for both) by tools/fetch_calib.hip on a known 512 MiB: profiles/r02_fetch_write_calibration.txt.
+# Correction applied: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
 out = {"workload": sys.argv[3], "robots": robots, "launches": min(nf, nw),
        "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
-       "hbm_bytes_per_launch": (f + w) * 1024.0,
-       "hbm_bytes_per_launch_if_fetch_doubled": (2 * f + w) * 1024.0,
+       "hbm_bytes_per_launch": (2 * f + w) * 1024.0,
+       "hbm_bytes_per_launch_uncorrected": (f + w) * 1024.0,
        "algorithmic_bytes_per_launch": 120 * robots,
-       "note": "FETCH_SIZE/WRITE_SIZE from separate --pmc passes; memory-side (fabric) requests, Infinity-Cache hits included"}
+       "note": "FETCH_SIZE/WRITE_SIZE from separate --pmc passes, gfx950 correction FETCH x2 (calibrated on this access "
+               "pattern); memory-side (fabric) requests, Infinity-Cache hits included"}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
