@@ -39,7 +39,11 @@ class ObstacleExchange:
     Two table buffers: the gather for step k + 1 can be in flight while the kernel of step k reads the other buffer
     (`start` right after launching the step; `finish` at the top of the next one).  Ordering is by events only:
     the gather waits for the producer of `local` and for the last kernel that read the buffer it overwrites; the
-    consuming step waits for the gather."""
+    consuming step waits for the gather.
+
+    Deployment note: HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); when the side
+    stream shares a queue with the compute stream the gather serialises behind the kernel it should overlap (+20 us per
+    step measured).  Export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises (bench.py does)."""
 
     def __init__(self, spheres_per_rank: int, device, group=None):
         self.group = group

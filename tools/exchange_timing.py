@@ -48,5 +48,20 @@ def bench_style():
     exch.consumed()
     exch.start(sph, produced=ev)
 print("round-1 loop (finish/obstacles+step/consumed/start): host %.1f us, wall %.1f us per step" % timeit(bench_style))
+tbl_last = exch.finish()
+bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out)[0] for t in exch.tables}
+exch.start(sph, produced=ev)
+def bound_style():
+    bound[exch.finish().data_ptr()]()
+    exch.consumed()
+    exch.start(sph, produced=ev)
+print("bench.py config4 loop (finish / bound launch / consumed / start): host %.1f us, wall %.1f us per step" % timeit(bound_style, 2000))
+exch.finish()
+# the same without the reader-done event (diagnostic only: the buffer a gather overwrites was last read two kernels ago)
+def no_consumed():
+    bound[exch.finish().data_ptr()]()
+    exch.start(sph, produced=ev)
+exch.start(sph, produced=ev)
+print("  ... without consumed():                                         host %.1f us, wall %.1f us per step" % timeit(no_consumed, 2000))
 exch.finish()
 dist.destroy_process_group()
