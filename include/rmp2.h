@@ -192,6 +192,12 @@ int rmp2_abi_version(void);
 size_t rmp2_sizeof_desc(void);
 size_t rmp2_sizeof_obstacles(void);
 
+/* Dry run of rmp2_create's host-side program compiler (descriptor validation, depth-first schedule with save / restore
+ * slots, pruning and folding of leaf-less fixed frames, ancestor / dof tables): RMP2_OK or the error rmp2_create would
+ * return for this descriptor, message via rmp2_last_error(NULL).  Needs no HIP device -- it is what a host-side tool
+ * (and the sanitizer build, tools/asan_compile_program.sh) can exercise without a GPU. */
+int rmp2_validate(const rmp2_desc *desc);
+
 /* Build an engine for one robot type + one RMP set on HIP device `device`.
  * Replaces: UrdfForwardKinematic.__init__ tables (kinematics.py:157-209) + the RmpCore
  * registry contents (rmp.py:114-131) as a flat, immutable "program".               */

@@ -837,7 +837,8 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     const int p = rb.parent[i];
     if (p >= i || p < -1) return err = "parent[] must be topologically ordered (parent < child)", RMP2_ERR_INVALID_ARGUMENT;
     if (rb.joint_type[i] < 0 || rb.joint_type[i] > 2) return err = "bad joint_type", RMP2_ERR_INVALID_ARGUMENT;
-    if (rb.q_index[i] >= n) return err = "q_index out of range", RMP2_ERR_INVALID_ARGUMENT;
+    if (rb.q_index[i] >= n || rb.q_index[i] < -1)  // (-1: a joint held at q = 0; found by the sanitizer run: -2 used to pass)
+      return err = "q_index out of range (-1 = evaluated at q = 0, else 0 .. n_dof - 1)", RMP2_ERR_INVALID_ARGUMENT;
   }
   // working tree (possibly pruned / folded); wf[i] refers to original frame wf[i].orig
   struct WFrame {
@@ -1248,6 +1249,25 @@ size_t rmp2_sizeof_obstacles(void) { return sizeof(rmp2_obstacles); }
 const char* rmp2_last_error(const rmp2_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 const char* rmp2_last_kernel(const rmp2_handle* h) { return h ? h->last_kernel : "none"; }
+
+int rmp2_validate(const rmp2_desc* desc) {
+  if (!desc) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
+  if (desc->abi_version != RMP2_ABI_VERSION)
+    return fail(nullptr, RMP2_ERR_ABI_MISMATCH, "rmp2_desc.abi_version does not match the library");
+  // (DevProgram is ~20 KB: on the heap, like rmp2_create's copies are short-lived stack objects of the same size)
+  std::vector<DevProgram> P(2);
+  int n_slots = 0, n_slots_full = 0;
+  std::string err;
+  std::vector<HexOp> hops;
+  int rc = compile_program(*desc, P[0], n_slots, err, /*prune=*/true, &hops);
+  if (rc == RMP2_OK) rc = compile_program(*desc, P[1], n_slots_full, err, /*prune=*/false);
+  if (rc != RMP2_OK) return fail(nullptr, rc, err);
+  if (desc->robot.n_dof > 9 && desc->goal_floats > 16)
+    return fail(nullptr, RMP2_ERR_UNSUPPORTED, "more than 16 goal floats per robot with n_dof > 9");
+  if (n_slots > 2 || n_slots_full > 2)
+    return fail(nullptr, RMP2_ERR_UNSUPPORTED, "kinematic tree needs more than 2 saved branch states");
+  return RMP2_OK;
+}
 
 int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (!desc || !out) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");

@@ -226,3 +226,34 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "not silently running on fewer" in r.stderr and r.stdout.strip() == ""
+
+
+def test_validate_runs_the_program_compiler_without_a_gpu(hip_lib):
+    """rmp2_validate = rmp2_create's host half (descriptor checks + program compiler), usable without a device: every
+    shipped configuration compiles; broken descriptors are rejected with the code and message rmp2_create would give."""
+    lib = C.CDLL(hip_lib)
+    lib.rmp2_validate.argtypes = [C.POINTER(D.Desc)]
+    lib.rmp2_last_error.restype = C.c_char_p
+    lib.rmp2_last_error.argtypes = [C.c_void_p]
+    for build in (Cf.config1, Cf.config2, Cf.config3, Cf.config5_two_joint, Cf.exp05_two_joint, Cf.exp05_panda,
+                  Cf.exp04_two_joint, Cf.exp04_panda_identity_target, Cf.panda04_nullspace):
+        for solve in ("auto", "pinv"):
+            _, d = build(solve)
+            assert lib.rmp2_validate(C.byref(d)) == 0, (build.__name__, lib.rmp2_last_error(None))
+    _, d = Cf.config2()
+    d.robot.q_index[2] = -2          # found by the sanitizer run (tools/asan_compile_program.sh): used to pass
+    assert lib.rmp2_validate(C.byref(d)) == -1 and b"q_index" in lib.rmp2_last_error(None)
+    _, d = Cf.config2()
+    d.robot.parent[3] = 5
+    assert lib.rmp2_validate(C.byref(d)) == -1 and b"topologically" in lib.rmp2_last_error(None)
+    _, d = Cf.config3()
+    d.leaves[5].frame = 99
+    assert lib.rmp2_validate(C.byref(d)) == -1 and b"frame" in lib.rmp2_last_error(None)
+    _, d = Cf.config3()
+    d.leaves[1].taskmap = D.TASKMAP_FK_DISTANCE   # JointVelocityCap on a distance map: no such kernel
+    d.leaves[1].frame = 3
+    assert lib.rmp2_validate(C.byref(d)) == -2
+    _, d = Cf.config3()
+    d.abi_version = 7
+    assert lib.rmp2_validate(C.byref(d)) == -5
+    assert lib.rmp2_validate(None) == -1
