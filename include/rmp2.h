@@ -192,6 +192,18 @@ int rmp2_abi_version(void);
 size_t rmp2_sizeof_desc(void);
 size_t rmp2_sizeof_obstacles(void);
 
+/* The reference's LEAF protocol on its own:  rmp.evaluate(x, xd) -> (xdd_des, A)  (rmp2.py:25-29, rmp.py:202-206) for a
+ * batch of B task-space points, outside any RmpCore (rmp2_step evaluates the leaves inside the fused control step and
+ * never calls this).  `leaf`: kind + params (+ vec_a / vec_b) as in rmp2_desc; taskmap / frame / goal_offset ignored.
+ *   k           task-space dimension: 3 (TargetAttractor, CollisionAvoidance), 1 (ObstacleAvoidance), 1 .. RMP2_MAX_DOF
+ *               for the identity-map leaves and TargetPolicy
+ *   x, xd       device [B][k];   goal  device [k] (TargetAttractor, TargetPolicy) else NULL
+ *   dist, nvec  device [B], [B][3]: CollisionAvoidance's data-fed distance / normal (else NULL)
+ *   xdd, A      device [B][k], [B][k][k] (row major)
+ * TargetPolicy's norms are global in the reference (rmp.py:243: B = 1 there); here every row is its own evaluation. */
+int rmp2_leaf_evaluate(int device, const rmp2_leaf *leaf, int32_t k, const float *x, const float *xd, const float *goal,
+                       const float *dist, const float *nvec, float *xdd, float *A, int32_t B, void *stream);
+
 /* Dry run of rmp2_create's host-side program compiler (descriptor validation, depth-first schedule with save / restore
  * slots, pruning and folding of leaf-less fixed frames, ancestor / dof tables): RMP2_OK or the error rmp2_create would
  * return for this descriptor, message via rmp2_last_error(NULL).  Needs no HIP device -- it is what a host-side tool

@@ -751,6 +751,112 @@ rmp2_diff_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
   }
 }
 
+
+// =========================================================================================
+// device: one leaf on its own -- the reference's leaf protocol  rmp.evaluate(x, xd) -> (xdd, A)
+// (rmp2.py:25-29, rmp.py:202-206), one lane per row of the batch, libm-accurate formulas
+// =========================================================================================
+__global__ void __launch_bounds__(kWave)
+rmp2_leaf_kernel(rmp2_leaf lf, int k, const float* __restrict__ x, const float* __restrict__ xd,
+                 const float* __restrict__ goal, const float* __restrict__ dist, const float* __restrict__ nvec,
+                 float* __restrict__ xdd_o, float* __restrict__ A_o, int B) {
+  const int b = blockIdx.x * kWave + threadIdx.x;
+  if (b >= B) return;
+  const float* P = lf.params;
+  const float* xb = x + (size_t)b * k;
+  const float* vb = xd + (size_t)b * k;
+  float* xo = xdd_o + (size_t)b * k;
+  float* Ao = A_o + (size_t)b * k * k;
+  for (int i = 0; i < k * k; ++i) Ao[i] = 0.f;
+  auto put_sym3 = [&](const float S[6]) {
+    Ao[0] = S[0], Ao[1] = S[1], Ao[2] = S[2];
+    Ao[3] = S[1], Ao[4] = S[3], Ao[5] = S[4];
+    Ao[6] = S[2], Ao[7] = S[4], Ao[8] = S[5];
+  };
+  switch (lf.kind) {
+    case RMP2_LEAF_TARGET_ATTRACTOR: {  // rmp2.py:52-83, k = 3
+      const float xx[3] = {xb[0], xb[1], xb[2]}, vv[3] = {vb[0], vb[1], vb[2]}, g[3] = {goal[0], goal[1], goal[2]};
+      float acc[3], S[6];
+      leaf_target_attractor(P, xx, vv, g, acc, S);
+      for (int i = 0; i < 3; ++i) xo[i] = acc[i];
+      put_sym3(S);
+    } break;
+    case RMP2_LEAF_OBSTACLE_AVOIDANCE: {  // rmp2.py:183-196, k = 1
+      float acc, met;
+      leaf_obstacle_avoidance(P, xb[0], vb[0], acc, met);
+      xo[0] = acc;
+      Ao[0] = met;
+    } break;
+    case RMP2_LEAF_COLLISION_AVOIDANCE: {  // rmp.py:264-315, k = 3, data-fed d and n
+      const float nv[3] = {nvec[3 * b], nvec[3 * b + 1], nvec[3 * b + 2]}, vv[3] = {vb[0], vb[1], vb[2]};
+      float acc[3], w;
+      leaf_collision_avoidance(P, dist[b], nv, vv, acc, w);
+      for (int i = 0; i < 3; ++i) xo[i] = acc[i], Ao[4 * i] = w;
+    } break;
+    case RMP2_LEAF_JOINT_DAMPING: {  // rmp2.py:127-137
+      float s2 = 0.f;
+      for (int i = 0; i < k; ++i) s2 += vb[i] * vb[i];
+      const float nrm = sqrtf(s2), m = P[1] * nrm + P[2];
+      for (int i = 0; i < k; ++i) xo[i] = -(P[0] * nrm) * vb[i], Ao[i * k + i] = m;
+    } break;
+    case RMP2_LEAF_CSPACE_BIASING: {  // rmp2.py:212-226
+      float s2 = 0.f;
+      for (int i = 0; i < k; ++i) s2 += (xb[i] - lf.vec_a[i]) * (xb[i] - lf.vec_a[i]);
+      const float en = sqrtf(s2), m = P[0] + P[4];
+      for (int i = 0; i < k; ++i) {
+        const float e = xb[i] - lf.vec_a[i];
+        const float pos = (en < P[3]) ? (-e * P[1]) : (-P[3] * (e / en) * P[1]);
+        xo[i] = pos + (-P[2] * vb[i]);
+        Ao[i * k + i] = m;
+      }
+    } break;
+    case RMP2_LEAF_CONFIG_SPACE_BIASING: {  // rmp.py:330-347
+      for (int i = 0; i < k; ++i) xo[i] = P[0] * (lf.vec_a[i] - xb[i]) - P[1] * vb[i], Ao[i * k + i] = P[2];
+    } break;
+    case RMP2_LEAF_JOINT_VELOCITY_CAP: {  // rmp2.py:100-112, metric on the FULL matrix (quirk Q4)
+      const float cutoff = P[0] - P[1];
+      for (int i = 0; i < k; ++i) {
+        const float dv = fabsf(vb[i]) - cutoff;
+        const float sgn = (vb[i] > 0.f) ? 1.f : (vb[i] < 0.f ? -1.f : 0.f);
+        xo[i] = (fabsf(vb[i]) < cutoff) ? 0.f : -fabsf(P[2] * dv) * sgn;
+        const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+        for (int j = 0; j < k; ++j) Ao[i * k + j] = (i == j) ? P[3] / (1.0f - ratio * ratio) : P[3] / 1.0f;
+      }
+    } break;
+    case RMP2_LEAF_JOINT_LIMIT_AVOIDANCE: {  // rmp.py:357-382, A = H diag(w) (quirk Q2)
+      const float rr = 0.15f, c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
+      const float qd_max = (float)(20.0 * (2.0 * 3.14159265358979323846) / 60.0);
+      float cw[RMP2_MAX_DOF], zeta[RMP2_MAX_DOF], s2 = 0.f;
+      for (int i = 0; i < k; ++i) {
+        const float range = lf.vec_b[i] - lf.vec_a[i];
+        const float d = fminf((lf.vec_b[i] - xb[i]) / range, (xb[i] - lf.vec_a[i]) / range);
+        cw[i] = d > rr ? 0.f : c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
+        zeta[i] = vb[i] / qd_max;
+        s2 += zeta[i] * zeta[i];
+        xo[i] = -P[0] * xb[i] - P[1] * vb[i];
+      }
+      const float nrm = sqrtf(s2), hh = nrm + 1.0f / 5.0f * logf(1.0f + expf(-2.0f * 5.0f * nrm));
+      for (int i = 0; i < k; ++i) zeta[i] /= hh;
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) Ao[i * k + j] = cw[j] * (0.9f * (zeta[i] * zeta[j]) + 0.1f * (i == j ? 1.f : 0.f));
+    } break;
+    case RMP2_LEAF_TARGET_POLICY: {  // rmp.py:241-260 on a k-dimensional task space (one row = one evaluation: the
+      const float alpha = P[0], beta_d = P[1], c = P[2];  // reference's norms are global, i.e. B = 1)
+      float v[RMP2_MAX_DOF], s2 = 0.f, f2 = 0.f;
+      for (int i = 0; i < k; ++i) v[i] = goal[i] - xb[i], s2 += v[i] * v[i];
+      const float vn = sqrtf(s2);
+      const float inv_h = 1.0f / (vn + c * logf(1.0f + expf(-2.0f * c * vn)));
+      for (int i = 0; i < k; ++i) xo[i] = alpha * (inv_h * v[i]) - beta_d * vb[i], f2 += xo[i] * xo[i];
+      const float fn = sqrtf(f2), hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+      const float beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f), w = expf(-vn / 3.0f);
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+          Ao[i * k + j] = w * (beta * ((xo[i] / hs) * (xo[j] / hs)) + (1.0f - beta) * (i == j ? 1.f : 0.f));
+    } break;
+    default: break;
+  }
+}
+
 // =========================================================================================
 // host: handle, program compiler, launches
 // =========================================================================================
@@ -1249,6 +1355,36 @@ size_t rmp2_sizeof_obstacles(void) { return sizeof(rmp2_obstacles); }
 const char* rmp2_last_error(const rmp2_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 const char* rmp2_last_kernel(const rmp2_handle* h) { return h ? h->last_kernel : "none"; }
+
+int rmp2_leaf_evaluate(int device, const rmp2_leaf* leaf, int32_t k, const float* x, const float* xd, const float* goal,
+                       const float* dist, const float* nvec, float* xdd, float* A, int32_t B, void* stream) {
+  if (!leaf || !x || !xd || !xdd || !A || B < 0) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
+  int want = -1;  // task-space dimension the leaf kind fixes (-1: any 1 .. RMP2_MAX_DOF)
+  bool needs_goal = false, needs_pairs = false;
+  switch (leaf->kind) {
+    case RMP2_LEAF_TARGET_ATTRACTOR: want = 3, needs_goal = true; break;
+    case RMP2_LEAF_OBSTACLE_AVOIDANCE: want = 1; break;
+    case RMP2_LEAF_COLLISION_AVOIDANCE: want = 3, needs_pairs = true; break;
+    case RMP2_LEAF_TARGET_POLICY: needs_goal = true; break;
+    case RMP2_LEAF_JOINT_VELOCITY_CAP: case RMP2_LEAF_JOINT_DAMPING: case RMP2_LEAF_CSPACE_BIASING:
+    case RMP2_LEAF_JOINT_LIMIT_AVOIDANCE: case RMP2_LEAF_CONFIG_SPACE_BIASING: break;
+    default: return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "unknown leaf kind");
+  }
+  if (k < 1 || k > RMP2_MAX_DOF || (want > 0 && k != want))
+    return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "task-space dimension does not fit this leaf kind");
+  if (needs_goal && !goal) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "this leaf needs a goal");
+  if (needs_pairs && (!dist || !nvec)) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "CollisionAvoidance needs dist and nvec");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return fail(nullptr, RMP2_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
+  if (B == 0) return RMP2_OK;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) HIP_TRY(nullptr, hipSetDevice(device));
+  hipLaunchKernelGGL(rmp2_leaf_kernel, dim3((B + kWave - 1) / kWave), dim3(kWave), 0, (hipStream_t)stream, *leaf, k, x, xd,
+                     goal, dist, nvec, xdd, A, B);
+  HIP_TRY(nullptr, hipGetLastError());
+  return RMP2_OK;
+}
 
 int rmp2_validate(const rmp2_desc* desc) {
   if (!desc) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");

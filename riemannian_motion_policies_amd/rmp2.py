@@ -1,7 +1,8 @@
 """RMP2-style leaf policies with the reference's names and constructor signatures
 (rmp2.py:6-226).  Each class is a *descriptor*: it stores its parameters and serialises to
 one `rmp2_leaf` record; the (xdd_des, A) formulas themselves run inside the HIP kernels
-(csrc/rmp2_leaves.h), quirks included.
+(csrc/rmp2_device.h, csrc/rmp2_quad.h), quirks included.  The reference's leaf protocol `rmp.evaluate(x, xd)` is
+served by a small kernel of its own (rmp2_leaf_evaluate); RmpCore.evaluate never goes through it.
 """
 from __future__ import annotations
 
@@ -9,6 +10,18 @@ import numpy as np
 
 from . import descriptor as D
 from .taskmap import IdentityTaskmap, classify
+
+
+class LeafResult(np.ndarray):
+    """ndarray with the `.numpy()` callers of the reference's tensors use."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def as_plain(v):
+    """Array view of a goal / data holder (list, ndarray, or a Datamanager-style holder with .numpy())."""
+    return v.numpy() if hasattr(v, "numpy") else v
 
 
 class RiemannianMotionPolicy:
@@ -20,9 +33,49 @@ class RiemannianMotionPolicy:
         self.name = name
         self.taskmap = taskmap
 
-    def evaluate(self, x, xd, *args, **kwargs):
-        raise NotImplementedError(
-            "leaf policies are evaluated inside the fused HIP control step; call RmpCore.evaluate(q, qd)")
+    def evaluate(self, x, xd, device: int = 0):
+        """The reference's leaf protocol (rmp2.py:25-29, rmp.py:202-206): x, xd [B, k] (or [k]) -> (xdd_des [B, k],
+        A [B, k, k]) as ndarrays with `.numpy()`, computed on the GPU by rmp2_leaf_evaluate.  RmpCore.evaluate does not
+        use this (the leaves run inside the fused control step); it exists for callers that inspect one leaf."""
+        import ctypes as C
+        import torch
+        from . import _native
+        if not torch.cuda.is_available():
+            raise _native.Rmp2Error("no HIP device visible; leaf evaluation has no CPU fallback")
+        dev = torch.device("cuda", device)
+        xt = torch.as_tensor(np.asarray(x, dtype=np.float32)).reshape(-1, np.asarray(x).shape[-1]).to(dev).contiguous()
+        vt = torch.as_tensor(np.asarray(xd, dtype=np.float32)).reshape(xt.shape).to(dev).contiguous()
+        B, k = xt.shape
+        spec = D.LeafSpec(self.KIND, D.TASKMAP_IDENTITY, -1, self._params(), *self._vectors(), name=self.name)
+        rec = D.Leaf()
+        rec.kind = spec.kind
+        for i, p in enumerate(spec.params):
+            rec.params[i] = p
+        for name, vec in (("vec_a", spec.vec_a), ("vec_b", spec.vec_b)):
+            if vec is not None:
+                if len(vec) != k:
+                    raise ValueError(f"{type(self).__name__}: {name} has {len(vec)} entries, x has {k} columns")
+                for i, v in enumerate(vec):
+                    getattr(rec, name)[i] = v
+        g = self._goal()
+        gt = None if g is None else torch.as_tensor(np.asarray(as_plain(g), dtype=np.float32).reshape(-1)).to(dev)
+        if gt is not None and gt.numel() != k:
+            raise ValueError(f"{type(self).__name__}: goal has {gt.numel()} entries, x has {k} columns")
+        dist = nvec = None
+        if self.KIND == D.LEAF_COLLISION_AVOIDANCE:
+            dist = torch.as_tensor(np.asarray(as_plain(self.d), dtype=np.float32).reshape(-1)).to(dev).contiguous()
+            nvec = torch.as_tensor(np.asarray(as_plain(self.vec), dtype=np.float32).reshape(-1, 3)).to(dev).contiguous()
+            if dist.numel() != B or nvec.shape[0] != B:
+                raise ValueError("CollisionAvoidance: d / vec must have one entry per row of x")
+        xdd = torch.empty((B, k), dtype=torch.float32, device=dev)
+        A = torch.empty((B, k, k), dtype=torch.float32, device=dev)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        rc = _native.lib().rmp2_leaf_evaluate(device, C.byref(rec), k, xt.data_ptr(), vt.data_ptr(), ptr(gt), ptr(dist),
+                                              ptr(nvec), xdd.data_ptr(), A.data_ptr(), B,
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc)
+        torch.cuda.synchronize(dev)
+        return xdd.cpu().numpy().view(LeafResult), A.cpu().numpy().view(LeafResult)
 
     # descriptor protocol -----------------------------------------------------------
     def _params(self):
