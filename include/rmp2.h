@@ -269,7 +269,10 @@ int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R,
 
 /* Task-map differentiation of the FK map of `frame`
  * (UrdfForwardKinematic.differentiate, kinematics.py:250-270):
- *   x[R][16] = vec(T), xd[R][16] = J qd, J[R][16][n_dof], c[R][16] = Jdot qd.       */
+ *   x[R][16] = vec(T), xd[R][16] = J qd, J[R][16][n_dof], c[R][16] = Jdot qd.
+ * The two differentiate entry points are debug / test entries: they use a per-robot scratch buffer owned by the handle
+ * (grown, with a device synchronisation, on the first call at a larger R), so calls on ONE handle must be issued on one
+ * stream at a time; rmp2_step / rmp2_rollout / rmp2_forward_kinematics have no such state. */
 int rmp2_differentiate(rmp2_handle *h, const float *q, const float *qd, int32_t frame, float *x, float *xd,
                        float *J, float *c, int32_t R, void *stream);
 
