@@ -81,6 +81,15 @@ struct DevProgram {
     int32_t jump[5][kMaxOps];         // jump[l][k]: the op 2^l levels above op k, -1 = above the base
     uint32_t op_anc[kMaxOps];         // bit j: op j is op k itself or one of its ancestors
   } hex;
+  // The leaf phase of the scalar-cache program walk (quad kernel, large fleets), flattened so that a frame costs ONE
+  // dependent scalar fetch instead of four (leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id]): one 16-byte record
+  // per leaf-bearing frame, fetched a frame ahead, and the FK-map leaves in execution order.
+  struct LeafFrame {
+    int32_t op;         // schedule position of the frame
+    uint32_t anc_mask;  // dofs that move it
+    int32_t leaf_begin, leaf_count;  // range in exec_leaves
+  } leaf_frames[kMaxOps];
+  DevLeaf exec_leaves[RMP2_MAX_LEAVES];
 };
 
 // Local transform of one frame as an affine function of (cos q, sin q, q), precomputed on the host in fp64:

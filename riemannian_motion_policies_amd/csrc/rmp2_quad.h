@@ -727,12 +727,26 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       rjrev[m] = (rev_mask >> ii) & 1u;
     }
     // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
+    // (scalar-cache walk: the frame's flattened record is fetched one frame ahead -- a dependent scalar fetch costs
+    // ~200 cycles and the old chain leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id] had four of them per frame)
+    int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
-      const int k = uni<STAGE>(leaf_ops[t]);
-      OpCtl op = *reinterpret_cast<const OpCtl*>(&ops[k]);
-      op.anc_mask = (uint32_t)uni<STAGE>((int)op.anc_mask);
-      op.leaf_begin = uni<STAGE>(op.leaf_begin);
-      op.leaf_count = uni<STAGE>(op.leaf_count);
+      int k;
+      OpCtl op;
+      if (STAGE) {
+        k = uni<STAGE>(leaf_ops[t]);
+        op = *reinterpret_cast<const OpCtl*>(&ops[k]);
+        op.anc_mask = (uint32_t)uni<STAGE>((int)op.anc_mask);
+        op.leaf_begin = uni<STAGE>(op.leaf_begin);
+        op.leaf_count = uni<STAGE>(op.leaf_count);
+      } else {
+        const int4 lfr = lfr_next;
+        lfr_next = *reinterpret_cast<const int4*>(&prog->leaf_frames[min(t + 1, hdr.n_leaf_ops - 1)]);
+        k = lfr.x;
+        op.anc_mask = (uint32_t)lfr.y;
+        op.leaf_begin = lfr.z;
+        op.leaf_count = lfr.w;
+      }
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
       const float4* fr4 = reinterpret_cast<const float4*>(loc + kSlot * k);
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
@@ -741,7 +755,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       // it runs with 36 fewer live registers this way (the kernel must fit 128 for four waves per SIMD)
       float mycol[ROWS][3];
       for (int li = 0; li < op.leaf_count; ++li) {
-        const DevLeaf& lf = leaves[uni<STAGE>(fk_list[op.leaf_begin + li])];
+        const DevLeaf& lf = STAGE ? leaves[uni<STAGE>(fk_list[op.leaf_begin + li])] : prog->exec_leaves[op.leaf_begin + li];
         LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
         lh.kind = uni<STAGE>(lh.kind);
         lh.taskmap = uni<STAGE>(lh.taskmap);
