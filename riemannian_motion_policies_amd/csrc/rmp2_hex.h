@@ -1063,8 +1063,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   if (out.status && live && s == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS
   RMP2_STAMP();  // 6: stored
-  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: f buffer receives the stamps
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)blockIdx.x * 8;
+  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: the stamps follow the f rows
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)R * n_dof + (size_t)blockIdx.x * 16;
     for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
   }
 #endif

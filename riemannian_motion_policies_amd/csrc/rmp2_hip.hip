@@ -883,7 +883,9 @@ struct rmp2_handle {
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
   int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
-  int quad_minw = 2;  // register cap of the throughput quad build: 2 waves per SIMD (env RMP2_QUAD_MINW=4, A/B only)
+  int quad_minw = 0;  // register cap of the throughput quad build: 0 = by fleet size (2 or 3 waves per SIMD, launch_quad);
+                      // env RMP2_QUAD_MINW=2|3|4 pins it (A/B only)
+  int n_simd = 1024;  // SIMDs of the device (4 per CU)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1216,12 +1218,17 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
-  // 512 registers; throughput build beyond: scalar-cache program walk, 256 registers (two waves per SIMD: the 16 waves
-  // a CU owes to a 65 536-robot fleet run as two even rounds of 8).  LDS is <= 10 KB per wave, so a 128-register build
-  // would keep all 16 resident (a SIMD issues a plain fp32 instruction every 2.2 cycles from four waves, every 3.3
-  // from two -- profiles/r02_valu_issue_rates.txt); measured, that build spills ~450 scratch accesses per wave and
-  // loses: 109 vs 89 us (profiles/r02_quad_minw_ab.txt)
+  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256 or 168 registers (two or three
+  // waves per SIMD).  Three waves retire the leaf phases ~10 % faster per robot (1.10 vs 0.99 G steps/s at 262 144
+  // robots), but a SIMD's share of the fleet has to divide into rounds: with b = waves owed per SIMD, two waves win for
+  // b <= 2 and 3 < b <= 4 (the 65 536-robot fleet: 2 + 2 beats 3 + 1, 68.8 vs 76.1 us), three everywhere else
+  // (profiles/r02_quad_minw_ab.txt).  Four waves (128 registers, ~200 scratch accesses per wave) lose at every size.
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
+  int minw = h->quad_minw;
+  if (minw == 0) {
+    const double b = (double)blocks / (double)h->n_simd;
+    minw = (b <= 2.0 || (b > 3.0 && b <= 4.0)) ? 2 : 3;
+  }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP)                                                                              \
@@ -1229,8 +1236,10 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                      hdr, q, qd, goal, gs, o, out, ro, R)
   if (latency) {
     if (o.capsule) RMP2_QUAD_LAUNCH(1, true, true); else RMP2_QUAD_LAUNCH(1, true, false);
-  } else if (h->quad_minw == 4) {  // A/B only (env RMP2_QUAD_MINW=4): 128 registers, four waves per SIMD
+  } else if (minw == 4) {  // A/B only (env RMP2_QUAD_MINW=4): 128 registers, four waves per SIMD
     if (o.capsule) RMP2_QUAD_LAUNCH(4, false, true); else RMP2_QUAD_LAUNCH(4, false, false);
+  } else if (minw == 3) {  // 168 registers, three waves per SIMD
+    if (o.capsule) RMP2_QUAD_LAUNCH(3, false, true); else RMP2_QUAD_LAUNCH(3, false, false);
   } else {
     if (o.capsule) RMP2_QUAD_LAUNCH(2, false, true); else RMP2_QUAD_LAUNCH(2, false, false);
   }
@@ -1463,7 +1472,11 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   }
   {
     const char* we = std::getenv("RMP2_QUAD_MINW");
-    h->quad_minw = (we && std::atoi(we) == 4) ? 4 : 2;
+    const int wv = we ? std::atoi(we) : 0;
+    h->quad_minw = (wv >= 2 && wv <= 4) ? wv : 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->n_simd = 4 * prop.multiProcessorCount;
   }
   h->n_fk_leaves = P.n_fk_leaves;
   h->hex_is_chain = P.hex.is_chain;

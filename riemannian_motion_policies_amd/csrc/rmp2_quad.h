@@ -466,8 +466,14 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   unsigned long long st_[8];
   int st_n = 0;
 #define RMP2_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[st_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+  // ... and accumulated time per segment of the FK-leaf loop (row entries 8..15 of the stamp buffer)
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_t = 0;
+#define RMP2_SEG_BEGIN() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); seg_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define RMP2_SEG(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_[i] += t_ - seg_t; seg_t = t_; } while (0)
 #else
 #define RMP2_STAMP() do {} while (0)
+#define RMP2_SEG_BEGIN() do {} while (0)
+#define RMP2_SEG(i) do {} while (0)
 #endif
   RMP2_STAMP();
   const int lane = threadIdx.x;
@@ -614,8 +620,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // instruction in its body is latency.  The frame's control word travels inside its LDS record;
   // frames that carry leaves drop (p, v, a) into LDS for the leaf phase below.
   if (n_ops > 0) {
-    QuadState cur;
-    QuadState slot[SLOTS > 0 ? SLOTS : 1];
+    // zero-initialised on purpose: left uninitialised, the compiler closes the undefined value at loop entry with the
+    // previous control step's state, i.e. carries 8 (1 + SLOTS) registers across the WHOLE step for nothing (16 fewer
+    // registers in the 256-register build; in the 128-register build the walk's state otherwise lives in scratch)
+    QuadState cur = {};
+    QuadState slot[SLOTS > 0 ? SLOTS : 1] = {};
     const float4* rec4n = reinterpret_cast<const float4*>(loc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2];
     // {axis, ctl} of the frame: wave-uniform, one 16-byte fetch per frame (scalar cache, or the staged copy), one ahead
@@ -712,7 +721,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
     // row-joint records: world axis z_i and origin o_i of the joints that own MY rows (slot [p = o | v | a | z] of the
     // joint's frame), read once per pass instead of once per leaf frame
+    // (the 128-register build keeps only the records' LDS addresses and re-reads them per frame: 18 registers)
+    constexpr bool kRowRecsInRegs = MINW < 4;
     float rjz[ROWS][3], rjo[ROWS][3];
+    const float4* rjs[ROWS];
     bool rjrev[ROWS];
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
@@ -720,10 +732,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const int ii = i < N ? i : 0;
       const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
       const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
-      const float4* js = reinterpret_cast<const float4*>(loc + kSlot * fo);
-      const float4 j0 = js[0], j2 = js[2];
-      rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
-      rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
+      rjs[m] = reinterpret_cast<const float4*>(loc + kSlot * fo);
+      if (kRowRecsInRegs) {
+        const float4 j0 = rjs[m][0], j2 = rjs[m][2];
+        rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
+        rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
+      }
       rjrev[m] = (rev_mask >> ii) & 1u;
     }
     // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
@@ -747,6 +761,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         op.leaf_begin = lfr.z;
         op.leaf_count = lfr.w;
       }
+      RMP2_SEG_BEGIN();
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
       const float4* fr4 = reinterpret_cast<const float4*>(loc + kSlot * k);
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
@@ -754,6 +769,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       // Jacobian columns of the frame: formed AFTER the first leaf's (S, h) -- the pair loop is where the time goes and
       // it runs with 36 fewer live registers this way (the kernel must fit 128 for four waves per SIMD)
       float mycol[ROWS][3];
+      if (MINW >= 4) {  // (as for the walk's state: an undefined value at loop entry is closed with the previous frame's columns,
+#pragma unroll       //  nine registers live through the pair loop; the 256-register build has them to spare)
+        for (int m = 0; m < ROWS; ++m) mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;
+      }
       for (int li = 0; li < op.leaf_count; ++li) {
         const DevLeaf& lf = STAGE ? leaves[uni<STAGE>(fk_list[op.leaf_begin + li])] : prog->exec_leaves[op.leaf_begin + li];
         LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
@@ -762,6 +781,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         lh.goal_offset = uni<STAGE>(lh.goal_offset);
         const int lf_kind = lh.kind;
         float S[6], h[3];
+        RMP2_SEG(0);  // frame record + leaf head on chip
         if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
           float gl[3], xdd[3];
 #pragma unroll
@@ -815,17 +835,24 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
               pair_loop<kPairsRaggedGlobal, CAP>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
                                             P3, V3, A3, lh.P, IP, S, h);
           }
+          RMP2_SEG(2);  // distance leaf: cull + pair trips
 #pragma unroll
           for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
 #pragma unroll
           for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
         }
+        RMP2_SEG(1);  // target leaf (S, h) / the quad sums of a distance leaf
         if (li == 0) {
           // the columns of MY rows, z_i x (p - o_i) resp. z_i, from the row-joint records read once per pass; rows
           // whose dof does not move the frame get a zero column, so everything below is branch-free
 #pragma unroll
           for (int m = 0; m < ROWS; ++m) {
             const bool act = (op.anc_mask >> (sub + kQuad * m)) & 1u;  // (bits >= n_dof are never set)
+            if (!kRowRecsInRegs) {
+              const float4 j0 = rjs[m][0], j2 = rjs[m][2];
+              rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
+              rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
+            }
             const float d[3] = {P3[0] - rjo[m][0], P3[1] - rjo[m][1], P3[2] - rjo[m][2]};
             float cr[3];
             cross3(rjz[m], d, cr);
@@ -837,6 +864,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         // symmetric (S is): only the BLOCK-UPPER part (row block m, columns j >= 4 m) is accumulated -- 15 of a lane's 27
         // entries for n = 9, so 24 fewer live registers through the pair loops and 45 % fewer products; mirrored once
         // below.  Column j lives in lane (j & 3) as its local row j >> 2: it is broadcast right where it is consumed.
+        RMP2_SEG(3);  // Jacobian columns of my rows
         float u[ROWS][3];
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
@@ -860,6 +888,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           for (int m = 0; m < ROWS; ++m)
             if (kQuad * m <= j) A[m][j] += (double)dot3(u[m], cj);  // (a row block without ancestors adds exact zeros)
         }
+        RMP2_SEG(4);  // pull-back
       }
     }
     // ---- mirror the block-upper part: M[i][j] = M[j][i] for the blocks below the diagonal ------------------------
@@ -1245,9 +1274,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   if (out.status && live && sub == 0) out.status[robot] = status;
 #ifdef RMP2_STAMPS
   RMP2_STAMP();  // 6: stored
-  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: f buffer receives the stamps
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)blockIdx.x * 8;
+  if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: the stamps follow the f rows
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)R * n_dof + (size_t)blockIdx.x * 16;
     for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
+    for (int i = 0; i < 8; ++i) dst[8 + i] = seg_[i];
   }
 #endif
 }

@@ -23,15 +23,21 @@ for name, desc in sets.items():
     eng = Engine(desc, 0)
     obs = eng.obstacles(spheres=sph) if name == "config3" else None
     g = goal if desc.goal_floats else None
-    f = torch.zeros((R, 9), dtype=torch.float64, device="cuda")
+    n_blocks = (R + 3) // 4 if os.environ.get("RMP2_HEX_WAVES") == "1" else (R + 15) // 16
+    buf = torch.zeros(R * 9 + 16 * n_blocks, dtype=torch.float64, device="cuda")  # f rows, then 16 stamps per block
+    f = buf[: R * 9].view(R, 9)
     for _ in range(5):
         eng.step(q, qd, g, obstacles=obs, f=f)
     torch.cuda.synchronize()
     per_block = 16  # quad: 16 robots per wave-block; hex: 4 waves x 4 robots per block
     if os.environ.get("RMP2_KERNEL") == "hex" and os.environ.get("RMP2_HEX_WAVES") == "1":
         per_block = 4
-    st = f.cpu().numpy().view(np.uint64).reshape(-1)[: ((R + per_block - 1) // per_block) * 8].reshape(-1, 8).astype(np.int64)
+    st = buf.cpu().numpy().view(np.uint64)[R * 9 : R * 9 + ((R + per_block - 1) // per_block) * 16].reshape(-1, 16).astype(np.int64)
+    seg = np.median(st[:, 8:13], axis=0)
     d = np.diff(st[:, :7], axis=1)
     med = np.median(d, axis=0)
     tot = np.median(st[:, 6] - st[:, 0])
     print(f"R={R} {name:22s} total {tot:8.0f} cyc | " + " ".join(f"{n}={m:.0f}" for n, m in zip(names, med)))
+    if seg.any():  # quad kernel only: the FK-leaf loop by segment, summed over the frames
+        print(" " * 12 + "fk leaves by segment: " + " ".join(f"{n}={m:.0f}" for n, m in zip(
+            ["fetch(frame,leaf head)", "target leaf / quad sums", "cull+pair trips", "my columns", "pull-back"], seg)))

@@ -19,7 +19,7 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 constexpr int kIters = 512;
 constexpr int kUnroll = 16;  // independent chains per wave
 
-enum Op { FMA32, FMA32_DEP, PKFMA32, EXP2, RCP, RSQ, FMA64, ADD64, CVT64, DPP_MOV, DPP_ADD, MIX_PAIR };
+enum Op { FMA32, FMA32_DEP, PKFMA32, EXP2, RCP, RSQ, FMA64, ADD64, CVT64, DPP_MOV, DPP_ADD, MIX_PAIR, FMA_SALU, FMA_SALU2, FMA_LDS, FMA_BRANCH, FMA_BRANCH_NT, FMA_EXECZ };
 
 template <int OP>
 __global__ void __launch_bounds__(1024) rate_kernel(float* out, unsigned long long* cyc, float seed) {
@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(1024) rate_kernel(float* out, unsigned long lo
   const float m = 0.999f + seed * 1e-6f, c = seed * 1e-3f;
   const double md = (double)m, cd = (double)c;
   const float2_ mp = {m, m}, cp = {c, c};
+  float lacc = 0.f;
+  lds[threadIdx.x] = seed;
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma nounroll
@@ -59,6 +61,19 @@ __global__ void __launch_bounds__(1024) rate_kernel(float* out, unsigned long lo
         const int v = __builtin_bit_cast(int, a[i]);
         a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));  // add with a DPP operand
       }
+      // does scalar / LDS / branch work issue beside the VALU stream or in its place?  (per 4 FMAs: one s_add_u32, two
+      // of them, one ds_read_b32, one taken uniform branch; the table counts the FMAs only)
+      if (OP == FMA_SALU || OP == FMA_SALU2 || OP == FMA_LDS || OP == FMA_BRANCH || OP == FMA_BRANCH_NT || OP == FMA_EXECZ) {
+        a[i] = fmaf(a[i], m, c);
+        if ((i & 3) == 3) {
+          if (OP == FMA_SALU || OP == FMA_SALU2) asm volatile("s_add_u32 s90, s90, 1" ::: "s90", "scc");
+          if (OP == FMA_SALU2) asm volatile("s_add_u32 s91, s91, 1" ::: "s91", "scc");
+          if (OP == FMA_LDS) lacc += lds[(threadIdx.x + i) & 1023];
+          if (OP == FMA_BRANCH_NT) asm volatile("s_cmp_eq_u32 s90, 0x12345\n\ts_cbranch_scc1 1f\n\ts_nop 0\n1:" ::: "scc");
+          if (OP == FMA_EXECZ) asm volatile("s_cbranch_execz 1f\n\ts_nop 0\n1:" :::);  // the guard of a divergent if: not taken
+          if (OP == FMA_BRANCH) asm volatile("s_cmp_lg_u32 s90, 0x12345\n\ts_cbranch_scc1 1f\n\ts_nop 0\n1:" ::: "scc");
+        }
+      }
       if (OP == MIX_PAIR) {
         // the shape of one obstacle pair: ~8 fma per transcendental
         float x = a[i];
@@ -72,6 +87,7 @@ __global__ void __launch_bounds__(1024) rate_kernel(float* out, unsigned long lo
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < kUnroll; ++i) s += a[i] + (float)d[i] + p[i].x + p[i].y;
+  s += lacc;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -120,5 +136,11 @@ int main() {
   run<DPP_MOV>("dpp_mov", 1, out, cyc);
   run<DPP_ADD>("dpp_mov+add", 2, out, cyc);
   run<MIX_PAIR>("8fma+rcp", 9, out, cyc);
+  run<FMA_SALU>("4fma|1salu", 1, out, cyc);
+  run<FMA_SALU2>("4fma|2salu", 1, out, cyc);
+  run<FMA_LDS>("4fma|1lds", 1, out, cyc);
+  run<FMA_BRANCH>("4fma|branch", 1, out, cyc);
+  run<FMA_BRANCH_NT>("4fma|br-not-taken", 1, out, cyc);
+  run<FMA_EXECZ>("4fma|execz-guard", 1, out, cyc);
   return 0;
 }
