@@ -1216,7 +1216,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0};
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
+                    blocks > 4 * h->n_simd ? 2 : 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256 or 168 registers (two or three
   // waves per SIMD).  Three waves retire the leaf phases ~10 % faster per robot (1.10 vs 0.99 G steps/s at 262 144

@@ -427,6 +427,8 @@ struct QuadHdr {
   uint32_t dof_ops[3];  // op that owns dof j, 5 bits each, 6 dofs per word (rmp2_quad.h only)
   float cull_c0;        // max over the distance leaves of (metric_modulation_radius + margin): cull threshold
   int32_t strict;       // 1: solve = PINV, the pseudo-inverse on every robot (rmp2_hex.h only; the quad kernel is AUTO)
+  int32_t prio_tail;    // wave priority of the phases after the FK leaves (rmp2_quad.h only): 0 when a SIMD's share of the
+                        // fleet is at most a round or two, 2 when waves keep arriving (see the s_setprio note in the kernel)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -476,6 +478,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #define RMP2_SEG(i) do {} while (0)
 #endif
   RMP2_STAMP();
+  // Wave priority falls as the step progresses (s_setprio 3 -> 2 -> 1 -> 0/2).  The SIMD's arbiter otherwise serves its
+  // oldest wave first: waves that started together finish staggered and the last one runs alone, at a fraction of the
+  // issue rate.  With the lagging wave preferred they finish together: 68.5 -> 66.9 us at 65 536 robots (two rounds of
+  // two waves), 51.5 -> 49.1 at 49 152 (one round of three), 73.0 -> 68.5 for the 128-register build.  When a SIMD owes
+  // many rounds the serial tail (identity leaves, resolve) goes back to priority 2 instead of 0, so that a wave about to
+  // free its slot is not starved by the newcomers: 237.2 -> 234.4 us at 262 144 (0 there costs +1.4 %).
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int sub = lane & 3;
   const int g = lane >> 2;
@@ -569,6 +578,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
 #pragma nounroll
   for (int it = 0; it < ro.n_iters; ++it) {
+  __builtin_amdgcn_s_setprio(3);  // (every control step of a fused rollout starts over)
   flagged = false;
   // ---- phase 1: local transforms T_constant @ T_variable(q) of ALL frames, in parallel -------
   // (kinematics.py:222-240).  They do not depend on the chain, so lane `sub` of the quad builds
@@ -705,6 +715,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
   }
+  __builtin_amdgcn_s_setprio(2);
   RMP2_STAMP();  // 2: walk done
 
 #pragma nounroll
@@ -745,6 +756,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // ~200 cycles and the old chain leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id] had four of them per frame)
     int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
+      if (2 * t == hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
       int k;
       OpCtl op;
       if (STAGE) {
@@ -913,6 +925,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
     }
 
+    if (hdr.prio_tail) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
     RMP2_STAMP();  // 3: FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
     for (int li = 0; li < n_id; ++li) {
