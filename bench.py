@@ -350,14 +350,16 @@ def worker(args) -> int:
                 # the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
                 local_ready = torch.cuda.Event()
                 local_ready.record(torch.cuda.current_stream(dev))
-                # one pre-marshalled launch per table buffer (the exchange alternates between two fixed buffers)
-                bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out)[0]
+                # one pre-marshalled launch per table buffer (the exchange alternates between two fixed buffers); each
+                # launch signals "this table has been read" through its own completion (no event packet between steps)
+                bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out,
+                                                done_fence=exch.reader_fence(t))[0]
                          for t in exch.tables}
                 exch.start(local, produced=local_ready)
 
                 def one_step():
                     bound[exch.finish().data_ptr()]()
-                    exch.consumed()
+                    exch.consumed(attached=True)
                     exch.start(local, produced=local_ready)
         kern = timer.run(one_step, args.steps, args.warmup)
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]

@@ -224,6 +224,22 @@ const char *rmp2_last_error(const rmp2_handle *h);
  * benchmarks and profiles name the kernel they measured from this instead of restating the dispatch rule. */
 const char *rmp2_last_kernel(const rmp2_handle *h);
 
+/* Stream-ordering fences for the obstacle exchange of a sharded fleet (fleet.py ObstacleExchange; the reference has
+ * no counterpart -- its environment is a host-side list, rmp.py:264-315 reads it in Python).  A fence is a HIP event
+ * WITHOUT timing and WITHOUT the system-scope release a default event carries: between two kernels of one stream a
+ * default event's record costs ~7 us on MI355X (L2 write-back + the next kernel's cold start), a device-scope one
+ * orders the same work for ~1 us.  Valid for work that stays on one GPU (the step kernel reading a table the RCCL
+ * kernel of the same device wrote, and the write-after-read the other way); host-visible results still need an
+ * ordinary event or a stream synchronisation.  `stream` is a hipStream_t (NULL = default stream). */
+int rmp2_fence_create(int device, void **fence);
+int rmp2_fence_record(void *fence, void *stream);          /* fence = everything enqueued on `stream` so far */
+int rmp2_fence_wait(void *fence, void *stream);            /* later work on `stream` waits for the fence      */
+int rmp2_fence_destroy(void *fence);
+/* Attach `fence` to the handle: every later rmp2_step / rmp2_rollout on `h` signals it when its kernel completes -- the
+ * effect of rmp2_fence_record right behind the launch, but carried by the dispatch itself (no extra packet between two
+ * steps; ~3 us per step in the exchange loop).  NULL detaches.  A launch with a fence attached is not stream-capturable. */
+int rmp2_set_step_fence(rmp2_handle *h, void *fence);
+
 /* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
  *   q, qd       device [R][n_dof] fp32
  *   goal        device [R][goal_floats] (goal_stride = goal_floats) or one shared row

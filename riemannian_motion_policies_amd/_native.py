@@ -38,6 +38,11 @@ def lib():
     l.rmp2_last_kernel.restype = C.c_char_p
     l.rmp2_last_kernel.argtypes = [C.c_void_p]
     l.rmp2_validate.argtypes = [C.POINTER(D.Desc)]
+    l.rmp2_fence_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    l.rmp2_fence_record.argtypes = [C.c_void_p, C.c_void_p]
+    l.rmp2_fence_wait.argtypes = [C.c_void_p, C.c_void_p]
+    l.rmp2_fence_destroy.argtypes = [C.c_void_p]
+    l.rmp2_set_step_fence.argtypes = [C.c_void_p, C.c_void_p]
     l.rmp2_leaf_evaluate.argtypes = [C.c_int, C.POINTER(D.Leaf), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     l.rmp2_create.argtypes = [C.POINTER(D.Desc), C.c_int, C.POINTER(C.c_void_p)]

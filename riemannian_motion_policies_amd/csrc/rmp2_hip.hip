@@ -7,6 +7,7 @@
 // and step: q, qd in, qdd out (+ goal): 120 B for the Panda.  Which kernel runs a step is decided
 // by fleet size in dispatch_solve(): rmp2_hex.h (<= 20480 robots), rmp2_quad.h, or rmp2_step_kernel below.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -886,6 +887,7 @@ struct rmp2_handle {
   int quad_minw = 0;  // register cap of the throughput quad build: 0 = by fleet size (2 or 3 waves per SIMD, launch_quad);
                       // env RMP2_QUAD_MINW=2|3|4 pins it (A/B only)
   int n_simd = 1024;  // SIMDs of the device (4 per CU)
+  void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1180,6 +1182,17 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   return RMP2_OK;
 }
 
+// A step launch: plain, or -- when a completion fence is attached to the handle (rmp2_set_step_fence) -- with the
+// fence as the dispatch's own completion signal (hipExtLaunchKernelGGL stop event): no separate packet behind the kernel.
+#define RMP2_STEP_LAUNCH(h_, kern_, grid_, block_, bytes_, stream_, ...)                                            \
+  do {                                                                                                              \
+    if ((h_)->step_fence)                                                                                           \
+      hipExtLaunchKernelGGL(kern_, grid_, block_, bytes_, stream_, nullptr, static_cast<hipEvent_t>((h_)->step_fence), 0, \
+                            __VA_ARGS__);                                                                           \
+    else                                                                                                            \
+      hipLaunchKernelGGL(kern_, grid_, block_, bytes_, stream_, __VA_ARGS__);                                       \
+  } while (0)
+
 template <int N, int SLOTS, bool STRICT>
 void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                  const OutArgs& out, int R, hipStream_t s) {
@@ -1187,11 +1200,11 @@ void launch_step(const rmp2_handle* h, const float* q, const float* qd, const fl
   h->last_kernel = STRICT ? "rmp2_step_kernel<STRICT> (one lane per robot, Jacobi pseudo-inverse)"
                           : "rmp2_step_kernel (one lane per robot)";
   if (h->has_point || o.capsule)
-    hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT, true>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
-                       o, out, R);
+    RMP2_STEP_LAUNCH(h, (rmp2_step_kernel<N, SLOTS, STRICT, true>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
+                     o, out, R);
   else
-    hipLaunchKernelGGL((rmp2_step_kernel<N, SLOTS, STRICT, false>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
-                       o, out, R);
+    RMP2_STEP_LAUNCH(h, (rmp2_step_kernel<N, SLOTS, STRICT, false>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, qd, goal, gs,
+                     o, out, R);
 }
 
 template <int N, bool STRICT>
@@ -1233,8 +1246,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP)                                                                              \
-  hipLaunchKernelGGL((rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, \
-                     hdr, q, qd, goal, gs, o, out, ro, R)
+  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, \
+                   hdr, q, qd, goal, gs, o, out, ro, R)
   if (latency) {
     if (o.capsule) RMP2_QUAD_LAUNCH(1, true, true); else RMP2_QUAD_LAUNCH(1, true, false);
   } else if (minw == 4) {  // A/B only (env RMP2_QUAD_MINW=4): 128 registers, four waves per SIMD
@@ -1269,8 +1282,8 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
     auto kern = rmp2_step_hex_kernel<N, CAP, WAVES, ROLL, PT>;                                                            \
     if (bytes > kLdsDefault)                                                                                               \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
-                       ro, R);                                                                                            \
+    RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
+                     ro, R);                                                                                              \
   } while (0)
   if (!ROLL && h->has_point)  // attached-point leaves (rollouts refuse them upstream; capsule tables: sphere modes only)
     RMP2_HEX_LAUNCH(false, true);
@@ -1370,6 +1383,40 @@ size_t rmp2_sizeof_obstacles(void) { return sizeof(rmp2_obstacles); }
 const char* rmp2_last_error(const rmp2_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 const char* rmp2_last_kernel(const rmp2_handle* h) { return h ? h->last_kernel : "none"; }
+
+// ---- device-scope fences (include/rmp2.h) ---------------------------------------------------------------------------
+int rmp2_fence_create(int device, void** fence) {
+  if (!fence) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
+  *fence = nullptr;
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) return fail(nullptr, RMP2_ERR_HIP, "hipGetDevice failed");
+  if (prev != device && hipSetDevice(device) != hipSuccess) return fail(nullptr, RMP2_ERR_HIP, "hipSetDevice failed");
+  hipEvent_t ev = nullptr;
+  const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
+  if (prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) return fail(nullptr, RMP2_ERR_HIP, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(e));
+  *fence = ev;
+  return RMP2_OK;
+}
+int rmp2_fence_record(void* fence, void* stream) {
+  if (!fence) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null fence");
+  const hipError_t e = hipEventRecord(static_cast<hipEvent_t>(fence), static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? RMP2_OK : fail(nullptr, RMP2_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+}
+int rmp2_fence_wait(void* fence, void* stream) {
+  if (!fence) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null fence");
+  const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(fence), 0);
+  return e == hipSuccess ? RMP2_OK : fail(nullptr, RMP2_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+}
+int rmp2_set_step_fence(rmp2_handle* h, void* fence) {
+  if (!h) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null handle");
+  h->step_fence = fence;
+  return RMP2_OK;
+}
+int rmp2_fence_destroy(void* fence) {
+  if (!fence) return RMP2_OK;
+  return hipEventDestroy(static_cast<hipEvent_t>(fence)) == hipSuccess ? RMP2_OK : fail(nullptr, RMP2_ERR_HIP, "hipEventDestroy failed");
+}
 
 int rmp2_leaf_evaluate(int device, const rmp2_leaf* leaf, int32_t k, const float* x, const float* xd, const float* goal,
                        const float* dist, const float* nvec, float* xdd, float* A, int32_t B, void* stream) {

@@ -46,6 +46,7 @@ class Engine:
         self.n_frames = desc.robot.n_frames
         self._h = C.c_void_p()
         self._lib = _native.lib()
+        self._fence_attached = False  # a bound launch attached a completion fence to the handle (bind(done_fence=))
         _native.check(self._lib.rmp2_create(C.byref(desc), self.device.index or 0, C.byref(self._h)))
         self._dist_leaves = D.distance_leaf_indices(desc)
 
@@ -125,6 +126,8 @@ class Engine:
         stream, unordered against `stream`)."""
         if stream is not None:
             _require_resident(self.device, q=q, qd=qd, goal=goal)
+        if self._fence_attached:
+            self._attach_fence(None)
         q, qd = _f32(q, self.device), _f32(qd, self.device)
         if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
             raise ValueError(f"q and qd must be [R, {self.n_dof}], got {tuple(q.shape)} / {tuple(qd.shape)}")
@@ -167,12 +170,14 @@ class Engine:
         return out
 
     def bind(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
-             out: Optional[torch.Tensor] = None, stream=None):
+             out: Optional[torch.Tensor] = None, stream=None, done_fence=None):
         """Pre-validate and pre-marshal one step on FIXED device buffers (the usual control loop:
         the simulator writes q/qd in place, the engine writes qdd in place).  Returns
         (launch, out): `launch()` is a bare C-ABI call (~2 us of host time).  The launch reads the caller's buffers
         themselves, so q, qd and goal must be contiguous fp32 tensors on the engine's device (anything else would be
-        copied once and the copy, not the caller's buffer, would be read forever after)."""
+        copied once and the copy, not the caller's buffer, would be read forever after).
+        `done_fence` (fleet._Fence): signalled by the launch's own completion (rmp2_set_step_fence) -- what the
+        obstacle exchange needs to know before it overwrites the table this launch reads."""
         _require_resident(self.device, q=q, qd=qd, goal=goal if self.desc.goal_floats else None, out=out)
         out = self.step(q, qd, goal, obstacles=obstacles, out=out, stream=stream)  # validates + warms up
         R = q.shape[0]
@@ -189,12 +194,28 @@ class Engine:
         out_ref = C.byref(o)
         fn, h, qp, qdp = self._lib.rmp2_step, self._h, q.data_ptr(), qd.data_ptr()
         keep.append(o)
+        if done_fence is None:
+            def launch(_keep=keep):
+                if self._fence_attached:
+                    self._attach_fence(None)
+                rc = fn(h, qp, qdp, goal_ptr, goal_stride, obs_ref, out_ref, R, s)
+                if rc:
+                    _native.check(rc, h)
+        else:
+            keep.append(done_fence)
+            setf, fh = self._lib.rmp2_set_step_fence, done_fence._h
 
-        def launch(_keep=keep):
-            rc = fn(h, qp, qdp, goal_ptr, goal_stride, obs_ref, out_ref, R, s)
-            if rc:
-                _native.check(rc, h)
+            def launch(_keep=keep):
+                setf(h, fh)
+                self._fence_attached = True
+                rc = fn(h, qp, qdp, goal_ptr, goal_stride, obs_ref, out_ref, R, s)
+                if rc:
+                    _native.check(rc, h)
         return launch, out
+
+    def _attach_fence(self, fence) -> None:
+        self._lib.rmp2_set_step_fence(self._h, fence._h if fence is not None else None)
+        self._fence_attached = fence is not None
 
     def rollout(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
                 n_control_steps: int = 1, substeps: int = 10, dt: float = 0.01, out: Optional[torch.Tensor] = None,

@@ -33,6 +33,35 @@ def balanced_bounds(weights, world: int):
     return cuts
 
 
+class _Fence:
+    """Device-scope stream fence (include/rmp2.h rmp2_fence_*): a HIP event without timing and without the system-scope
+    release of a default event (torch.cuda.Event is one).  Between two kernels of one stream a default event's record
+    costs ~7 us on MI355X; this one ~1 us.  Only for ordering work of ONE GPU."""
+
+    def __init__(self, device: torch.device):
+        import ctypes
+        from . import _native
+        self._lib = _native.lib()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.rmp2_fence_create(device.index or 0, ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("rmp2_fence_create: " + self._lib.rmp2_last_error(None).decode())
+
+    def record(self, stream: "torch.cuda.Stream") -> None:
+        if self._lib.rmp2_fence_record(self._h, stream.cuda_stream) != 0:
+            raise RuntimeError("rmp2_fence_record: " + self._lib.rmp2_last_error(None).decode())
+
+    def wait(self, stream: "torch.cuda.Stream") -> None:
+        if self._lib.rmp2_fence_wait(self._h, stream.cuda_stream) != 0:
+            raise RuntimeError("rmp2_fence_wait: " + self._lib.rmp2_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            self._lib.rmp2_fence_destroy(self._h)
+        except Exception:
+            pass
+
+
 class ObstacleExchange:
     """All-gather of the per-rank slices of the shared sphere table [K, 4] (RCCL, side stream).
 
@@ -55,9 +84,11 @@ class ObstacleExchange:
         self.tables = [torch.zeros((self.world * spheres_per_rank, 4), dtype=torch.float32, device=self.device)
                        for _ in range(2)]
         self.side = torch.cuda.Stream(self.device) if cuda else None
-        self.ready = [torch.cuda.Event() for _ in range(2)] if cuda else None
-        self.reader_done = [None, None]   # event after the last kernel that read buffer b
-        self._reader_events = [torch.cuda.Event() for _ in range(2)] if cuda else None
+        # (fences, not torch events: a default event between two step kernels costs ~7 us of the step, see _Fence)
+        fences = cuda and self.collective
+        self.ready = [_Fence(self.device) for _ in range(2)] if fences else None
+        self.reader_done = [None, None]   # fence after the last kernel that read buffer b
+        self._reader_events = [_Fence(self.device) for _ in range(2)] if fences else None
         self._next, self._pending, self._last = 0, [], None
 
     @property
@@ -73,16 +104,20 @@ class ObstacleExchange:
         b = self._next
         self._next ^= 1
         self._pending.append(b)
+        if len(self._pending) > 2:
+            raise RuntimeError("ObstacleExchange has two table buffers: finish() a gather before starting a third")
         if not self.collective:
             self.tables[b].copy_(local)
             return
         if self.side is not None:
-            if produced is not None:
+            if isinstance(produced, _Fence):
+                produced.wait(self.side)
+            elif produced is not None:
                 self.side.wait_event(produced)
             else:
                 self.side.wait_stream(torch.cuda.current_stream(self.device))
             if self.reader_done[b] is not None:
-                self.side.wait_event(self.reader_done[b])
+                self.reader_done[b].wait(self.side)
             with torch.cuda.stream(self.side):
                 dist.all_gather_into_tensor(self.tables[b], local.contiguous(), group=self.group)
                 self.ready[b].record(self.side)
@@ -94,14 +129,23 @@ class ObstacleExchange:
         b = self._pending.pop(0)
         self._last = b
         if self.collective and self.side is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.ready[b])
+            self.ready[b].wait(torch.cuda.current_stream(self.device))
         return self.tables[b]
 
-    def consumed(self) -> None:
-        """Call after launching the kernel that reads the table returned by the last finish()."""
+    def reader_fence(self, table: torch.Tensor):
+        """The fence the exchange waits on before it overwrites `table` (one of self.tables): hand it to
+        Engine.bind(done_fence=) so that the reading launch signals it itself, then call consumed(attached=True)."""
+        if self._reader_events is None:
+            return None
+        return self._reader_events[[t.data_ptr() for t in self.tables].index(table.data_ptr())]
+
+    def consumed(self, attached: bool = False) -> None:
+        """Call after launching the kernel that reads the table returned by the last finish().  attached=True: that
+        launch carried reader_fence(table) as its completion fence -- nothing to record here."""
         if self.collective and self.side is not None and self._last is not None:
             ev = self._reader_events[self._last]
-            ev.record(torch.cuda.current_stream(self.device))
+            if not attached:
+                ev.record(torch.cuda.current_stream(self.device))
             self.reader_done[self._last] = ev
 
 

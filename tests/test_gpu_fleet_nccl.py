@@ -80,3 +80,59 @@ def test_rccl_obstacle_exchange_feeds_the_hip_step(nccl_group, golden_dir):
     ref0 = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[0])["qdd64"]
     ref3 = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[3])["qdd64"]
     assert np.abs(ref0 - ref3).max() > 1e-3
+
+
+def test_bound_launches_signal_the_reader_fence_themselves(nccl_group, golden_dir):
+    """bench.py's config-4 loop: one pre-marshalled launch per table buffer, each carrying the exchange's reader fence as
+    its completion fence (rmp2_set_step_fence) instead of an event recorded behind it; the producer of the local slice
+    orders itself with a device-scope fence too.  Moving tables, many steps: a gather that overwrote a table too early,
+    or a step that read one too early, shows as a wrong q-double-dot."""
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    from riemannian_motion_policies_amd.fleet import ObstacleExchange, _Fence
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    _, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    q, qd, goal = (torch.from_numpy(g[k]).to(dev) for k in ("q", "qd", "goal"))
+    K, steps = len(g["spheres"]), 12
+    exch = ObstacleExchange(K, dev)
+    tables = [g["spheres"].copy() for _ in range(steps + 1)]
+    for k, t in enumerate(tables):
+        t[:, :2] *= np.float32(1.0 + 0.02 * k)
+    staged = [torch.from_numpy(t).to(dev) for t in tables]
+    local = staged[0].clone()
+    out = torch.empty_like(q)
+    bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out,
+                                    done_fence=exch.reader_fence(t))[0] for t in exch.tables}
+    produced = _Fence(dev)
+    cur = torch.cuda.current_stream(dev)
+    produced.record(cur)
+    exch.start(local, produced=produced)
+    outs = []
+    for k in range(steps):
+        bound[exch.finish().data_ptr()]()
+        exch.consumed(attached=True)
+        outs.append(out.clone())
+        local.copy_(staged[k + 1])               # next slice, on the current stream, behind the launch
+        produced.record(cur)
+        exch.start(local, produced=produced)
+    exch.finish()
+    # an un-fenced step afterwards detaches the fence again (the handle's fence is sticky by design)
+    plain = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=staged[3]))
+    torch.cuda.synchronize(dev)
+    # this test is about WHICH table a step read, not about near-contact rounding (the outward drift brings some spheres
+    # within 0.05 m of an arm, where fp32 FK rounding is amplified to a few 1e-5, tests/test_gpu_kernel_variants.py):
+    # 1e-4 relative, against tables that differ by > 1e-3 from one step to the next
+    refs = [O.step(desc, g["q"], g["qd"], g["goal"], spheres=t)["qdd64"] for t in tables[:steps]]
+    for k in list(range(steps)) + [None]:
+        ref = refs[3 if k is None else k]
+        got = (plain if k is None else outs[k]).cpu().numpy()
+        err = np.abs(got - ref).max(axis=1)
+        tol = 1e-4 * np.maximum(1.0, np.abs(ref).max(axis=1))
+        assert (err <= tol).all(), f"step {k}: worst {err.max():.3e}"
+    assert min(np.abs(refs[k] - refs[k + 1]).max() for k in range(steps - 1)) > 1e-3
+    with pytest.raises(RuntimeError):
+        exch.start(local); exch.start(local); exch.start(local)

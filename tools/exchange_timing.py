@@ -64,4 +64,14 @@ def no_consumed():
 exch.start(sph, produced=ev)
 print("  ... without consumed():                                         host %.1f us, wall %.1f us per step" % timeit(no_consumed, 2000))
 exch.finish()
+# the reader-done fence carried by the launch itself (Engine.bind(done_fence=), rmp2_set_step_fence)
+boundf = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out, done_fence=exch.reader_fence(t))[0]
+          for t in exch.tables}
+def fenced_style():
+    boundf[exch.finish().data_ptr()]()
+    exch.consumed(attached=True)
+    exch.start(sph, produced=ev)
+exch.start(sph, produced=ev)
+print("  ... reader fence attached to the launch:                        host %.1f us, wall %.1f us per step" % timeit(fenced_style, 2000))
+exch.finish()
 dist.destroy_process_group()
