@@ -202,3 +202,55 @@ def test_culling_is_exact_and_hardware_approximations_are_bounded(torch_mod, ker
     assert np.median(e_fast[near]) <= 4 * max(np.median(e_acc[near]), 1e-6), (np.median(e_fast[near]), np.median(e_acc[near]))
     assert np.quantile(e_fast[near], 0.95) <= 4 * max(np.quantile(e_acc[near], 0.95), 1e-5), \
         (np.quantile(e_fast[near], 0.95), np.quantile(e_acc[near], 0.95))
+
+
+def _engine_env(desc, **env):
+    from riemannian_motion_policies_amd.engine import Engine
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Engine(desc, 0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_quad_register_caps_agree_bitwise_at_fleet_sizes(torch_mod):
+    """BASELINE-size property (no oracle at this size): the throughput quad kernel is built three times -- 256, 168 and 128
+    registers = two, three, four waves per SIMD -- and `launch_quad` picks two or three from the fleet size.  The builds
+    run the same arithmetic in the same order, so their outputs must be IDENTICAL bit for bit, at a size where the rule
+    picks three waves (49 152 robots, one round of three) and at the BASELINE size (65 536, two rounds of two); the
+    fused rollout too (priorities are reset every control step)."""
+    torch = torch_mod
+    from riemannian_motion_policies_amd import configs as Cf
+    _, desc = Cf.config3()
+    sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng(7))).cuda()
+    for R in (49152, 65536):
+        s = Cf.sample_panda_states(np.random.default_rng(R), R)
+        q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+        outs, stats = {}, {}
+        for cap in ("auto", 2, 3, 4):
+            eng = _engine_env(desc, RMP2_KERNEL="quad") if cap == "auto" else _engine_env(desc, RMP2_KERNEL="quad", RMP2_QUAD_MINW=cap)
+            st = torch.zeros(R, dtype=torch.int32, device="cuda")
+            outs[cap] = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=sph), status=st).clone()
+            stats[cap] = st.clone()
+            assert "quad" in eng.last_kernel()
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs["auto"]).all()
+        for cap in (2, 3, 4):
+            assert torch.equal(outs[cap], outs["auto"]), f"R={R}: the {cap}-wave build differs from the dispatched one"
+            assert torch.equal(stats[cap], stats["auto"])
+    # rollout: 3 control steps fused, two caps
+    R = 49152
+    s = Cf.sample_panda_states(np.random.default_rng(5), R)
+    res = []
+    for cap in (2, 3):
+        eng = _engine_env(desc, RMP2_KERNEL="quad", RMP2_QUAD_MINW=cap)
+        q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+        qdd = eng.rollout(q, qd, goal, obstacles=eng.obstacles(spheres=sph), n_control_steps=3, substeps=4, dt=0.002)
+        res.append((q.clone(), qd.clone(), qdd.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
