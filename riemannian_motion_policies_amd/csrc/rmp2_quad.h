@@ -308,7 +308,8 @@ __device__ __forceinline__ int select_bit(uint32_t m, int r) {
 template <bool RAGGED, int W>
 __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, const int32_t* ci, int count, int max_count,
                                                  int sub, const float P3[3], const float V3[3], const float A3[3],
-                                                 const float* P, const float* IP, float S[6], float h[3]) {
+                                                 const float* P, const float* IP, float S[6], float h[3],
+                                                 unsigned long long* dbg = nullptr) {
   static_assert(W == 4 || W == 16, "quad or hex");
   const float4* aux = reinterpret_cast<const float4*>(tab);
   const float* rad = tab + 4 * n_tab;
@@ -345,9 +346,15 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       rem = sub > 1 ? (rem & (rem - 1u)) : rem;
       rem = sub > 2 ? (rem & (rem - 1u)) : rem;
     }
+#ifdef RMP2_STAMPS
+    if (dbg) dbg[1] += (unsigned long long)total;  // in-range pairs of the first robot of the wave
+#endif
     while (true) {
       const bool on = (W == 4) ? (rem != 0u) : (rank < total);
       if (!__any(on)) break;
+#ifdef RMP2_STAMPS
+      if (dbg) dbg[0] += 1ull;  // trips of the wave
+#endif
       int j = 0;
       if (W == 4) {
         j = on ? (__builtin_ffs((int)rem) - 1) : 0;
@@ -816,8 +823,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const float* sph_lds = sph_lds_base;
           if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds && !CAP)
+#ifdef RMP2_STAMPS
+              pair_loop_culled<false, kQuad>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
+                                             IP, S, h, &seg_[5]);
+#else
               pair_loop_culled<false, kQuad>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
                                              IP, S, h);
+#endif
             else if (spheres_in_lds)
               pair_loop<kPairsSharedLds, CAP>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
                                          A3, lh.P, IP, S, h);

@@ -38,6 +38,9 @@ for name, desc in sets.items():
     med = np.median(d, axis=0)
     tot = np.median(st[:, 6] - st[:, 0])
     print(f"R={R} {name:22s} total {tot:8.0f} cyc | " + " ".join(f"{n}={m:.0f}" for n, m in zip(names, med)))
+    if st[:, 13].any():  # quad kernel, culled sphere mode: pair-loop trips of the wave and in-range pairs of its first robot
+        print(" " * 12 + f"pair loop: {st[:, 13].mean():.1f} trips per wave-step (max {st[:, 13].max()}), "
+              f"{st[:, 14].mean():.1f} in-range pairs per robot-step (of 240)")
     if seg.any():  # quad kernel only: the FK-leaf loop by segment, summed over the frames
         print(" " * 12 + "fk leaves by segment: " + " ".join(f"{n}={m:.0f}" for n, m in zip(
             ["fetch(frame,leaf head)", "target leaf / quad sums", "cull+pair trips", "my columns", "pull-back"], seg)))
