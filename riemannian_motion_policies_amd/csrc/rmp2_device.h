@@ -83,7 +83,8 @@ struct DevProgram {
   } hex;
   // The leaf phase of the scalar-cache program walk (quad kernel, large fleets), flattened so that a frame costs ONE
   // dependent scalar fetch instead of four (leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id]): one 16-byte record
-  // per leaf-bearing frame, fetched a frame ahead, and the FK-map leaves in execution order.
+  // per leaf-bearing frame, fetched a frame ahead, and the FK-map leaves in execution order (followed by the
+  // identity-map leaves in theirs: exec_leaves[n_fk_leaves + i]).
   struct LeafFrame {
     int32_t op;         // schedule position of the frame
     uint32_t anc_mask;  // dofs that move it

@@ -1169,6 +1169,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     P.leaf_frames[t] = {P.leaf_ops[t], o.anc_mask, o.leaf_begin, o.leaf_count};
   }
   for (int i = 0; i < nfk; ++i) P.exec_leaves[i] = P.leaves[P.fk_leaves[i]];
+  for (int i = 0; i < nid; ++i) P.exec_leaves[nfk + i] = P.leaves[P.id_leaves[i]];  // (nfk + nid = n_leaves <= RMP2_MAX_LEAVES)
   for (int k = 0; k < F; ++k) {
     const DevOp& o = P.ops[k];
     P.ops[k].ctl = (o.restore + 2) | ((o.save + 1) << 2) | (o.jtype << 4) | ((o.qidx + 1) << 6) | ((o.leaf_count > 0 ? 1 : 0) << 11);

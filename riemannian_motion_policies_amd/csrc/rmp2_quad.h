@@ -394,6 +394,13 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
   }
 }
 
+// v[4 m + sub] of a wave-uniform per-dof vector of the program (leaf va / vb): four scalar-cache words and three
+// selects instead of a lane-indexed vector load from global memory (a full memory latency in the middle of a leaf)
+__device__ __forceinline__ float pick4(const float* v, int m, int sub) {
+  const float a0 = v[4 * m], a1 = v[4 * m + 1], a2 = v[4 * m + 2], a3 = v[4 * m + 3];
+  return sub == 0 ? a0 : (sub == 1 ? a1 : (sub == 2 ? a2 : a3));
+}
+
 // ---- the kernel -------------------------------------------------------------------------------
 // LDS per wave (16 robots).  The budget that matters: 160 KiB per CU / 16 waves = 10 240 B -- above it the 16 waves
 // a CU owes to a 65 536-robot fleet are not resident together (measured before the diet: 16.9 KB, 9 of 16 resident,
@@ -941,7 +948,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     RMP2_STAMP();  // 3: FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
     for (int li = 0; li < n_id; ++li) {
-      const DevLeaf& lfr = leaves[uni<STAGE>(id_list[li])];
+      // (scalar-cache walk: the identity leaves follow the FK leaves in exec_leaves[], in execution order -- no index fetch)
+      const DevLeaf& lfr = STAGE ? leaves[uni<STAGE>(id_list[li])] : prog->exec_leaves[hdr.n_fk + li];
       const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte load
       struct {
         int kind, goal_offset;
@@ -980,11 +988,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {
             acc = -(P[0] * nrm) * qdi;
           } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {
-            const float e = qi_ - lf.va[ii];
+            const float e = qi_ - (STAGE ? lf.va[ii] : pick4(lf.va, m, sub));
             const float pos = (nrm < P[3]) ? (-e * P[1]) : (-P[3] * (e / nrm) * P[1]);
             acc = pos + (-P[2] * qdi);
           } else {
-            acc = P[0] * (lf.va[ii] - qi_) - P[1] * qdi;
+            acc = P[0] * ((STAGE ? lf.va[ii] : pick4(lf.va, m, sub)) - qi_) - P[1] * qdi;
           }
           fv[m] += (double)(mdiag * acc);
         }
@@ -1050,9 +1058,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const int i = sub + kQuad * m;
             const int ii = i < N ? i : 0;
             const float qj = my_q[ii], qdj = my_qd[ii];
-            const float irange = rcp1(lf.vb[ii] - lf.va[ii]);
-            const float du = (lf.vb[ii] - qj) * irange;
-            const float dl = (qj - lf.va[ii]) * irange;
+            const float lo_ = STAGE ? lf.va[ii] : pick4(lf.va, m, sub), hi_ = STAGE ? lf.vb[ii] : pick4(lf.vb, m, sub);
+            const float irange = rcp1(hi_ - lo_);
+            const float du = (hi_ - qj) * irange;
+            const float dl = (qj - lo_) * irange;
             const float d = fminf(du, dl);
             const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
             cw_o[m] = (i < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
