@@ -5,7 +5,7 @@
 // leaf (xdd, A) evaluation -> pull-back J^T A J / J^T A (xdd - c) -> sum over leaves (fp64) ->
 // resolve (fp64 elimination, pseudo-inverse fall-through) -> qdd.  Algorithmic HBM traffic per robot
 // and step: q, qd in, qdd out (+ goal): 120 B for the Panda.  Which kernel runs a step is decided
-// by fleet size in dispatch_solve(): rmp2_hex.h (<= 20480 robots), rmp2_quad.h, or rmp2_step_kernel below.
+// by fleet size in dispatch_solve(): rmp2_hex.h (<= 8192 robots), rmp2_quad.h, or rmp2_step_kernel below.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -1343,7 +1343,7 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough)
     return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
   // Kernel choice (all mappings produce the same numbers to fp32 rounding):
-  //  * hex (16 lanes per robot, rmp2_hex.h): the latency build -- fleets up to 20 480 robots, where the other mappings
+  //  * hex (16 lanes per robot, rmp2_hex.h): the latency build -- fleets up to 8 192 robots, where the other mappings
   //    leave SIMDs idle; every leaf kind, both resolves, robots with up to 16 dofs; carries the fused rollout loop;
   //  * quad (4 lanes per robot, rmp2_quad.h): the throughput build for sets with distance leaves (the pair loops split
   //    4 ways); carries the fused rollout loop; no attached-point leaves;
@@ -1352,15 +1352,24 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // hex carries every leaf kind and both resolves (strict: the pseudo-inverse on every robot through its careful path;
   // slower than the lane kernel's register-resident Jacobi, so that path is taken on request / for n_dof > 9 only)
   const bool hex_ok = h->goal_floats <= 16 && !(h->has_point && rollout);
-  // measured (rocprofv3 kernel times, 3-leaf set / cluttered set, hex vs the kernel chosen otherwise):
-  //   R =  4096:  8.7 / 19.7 us  vs  13.4 / 40.0        R = 20480: 16.9 / 47.2 us  vs  19.4 / 54.3
-  //   R = 12288: 12.2 / 30.4 us  vs  14.5 / 42.6        R = 24576: 19.6 / 54.7 us  vs  19.7 / 54.9
-  //   R = 16384: 14.9 / 41.6 us  vs  14.5 / 42.9        R = 32768: 25.8 / 71.8 us  vs  19.9 / 56.3
-  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= 20480)) &&
+  // measured (bench.py, us per step, round 2 kernels; profiles/r02_dispatch_sweep.txt):
+  //   cluttered set (config 3)   R:  4096   8192  10240  16384  20480  32768
+  //     hex                         19.0   22.2   36.6   42.2   55.4   81.3
+  //     quad                        29.0   30.6   30.7   31.0   35.6   35.1
+  //   3-leaf set (config 2)      R:  4096   8192  10240  16384  32768  40960  65536  131072
+  //     hex                          7.6    8.9   14.0   16.7   31.0
+  //     quad                        13.0   13.6   14.0   13.9   16.8   25.7   31.0   68.5
+  //     lane                        19.4   19.4   19.5   19.5   20.3   20.3   21.5   39.4
+  // (hex holds two waves per SIMD: beyond 8 192 robots it runs a second round.)  Attached-point leaves exist in the hex
+  // and lane mappings only: those sets keep the older hex / lane cut at 20 480 robots.  So do 2-dof robots, whose hex
+  // step is short enough for the second round not to matter (TwoJoint half of config 5, 16 384 robots with ragged
+  // sphere lists: hex 16.9 us, quad 36.5).
+  const int hex_max = (h->has_point || N == 2) ? 20480 : 8192;
+  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= hex_max)) &&
       launch_hex<N>(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
-                                 (h->kernel_choice == 0 && !h->has_distance && R > 16384));
+                                 (h->kernel_choice == 0 && !h->has_distance && R > 32768));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
     case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;

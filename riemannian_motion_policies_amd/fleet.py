@@ -267,9 +267,15 @@ class MixedFleetShard:
             out = torch.empty_like(q)
             obs = eng.obstacles(spheres=torch.from_numpy(sph).to(dev), csr_offset=torch.from_numpy(csr_offset),
                                 csr_index=torch.from_numpy(csr_index))
-            launch, _ = eng.bind(q, qd, goal, obstacles=obs, out=out)
+            # the two types' kernels are independent: the TwoJoint part runs on a side stream, beside the Pandas'
+            side = torch.cuda.Stream(dev) if key == "two_joint" and ranges[rank]["panda"][1] > ranges[rank]["panda"][0] else None
+            launch, _ = eng.bind(q, qd, goal, obstacles=obs, out=out, stream=side.cuda_stream if side is not None else None)
+            if side is not None:
+                self._side, self._side_launch = side, launch
+                self._fork, self._join = _Fence(dev), _Fence(dev)
             pairs = float(cls.CONTROL_POINTS[key] * k.sum())
-            self.parts[key] = dict(engine=eng, launch=launch, out=out, n=n, keep=(q, qd, goal, obs),
+            self.parts[key] = dict(engine=eng, launch=launch, out=out, n=n, keep=(q, qd, goal, obs), desc=desc,
+                                   host=dict(spheres=sph, csr_offset=csr_offset, csr_index=csr_index),
                                    bytes=float(n * (cls.BYTES[key] + 4) + 4 * k.sum()),
                                    flops=float(n * cls.BASE_FLOPS[key] + 240.0 * pairs))
             self.work += float(work[first + lo:first + hi].sum())
@@ -279,11 +285,25 @@ class MixedFleetShard:
         d = self.parts[self._dom]
         self.dominant_bytes, self.dominant_flops, self.dominant_robots = d["bytes"], d["flops"], d["n"]
         self._launches = [p["launch"] for p in self.parts.values()]
+        self._device = dev
         return self
 
+    _side = None
+
     def step(self):
-        for launch in self._launches:
-            launch()
+        """One control step of the shard.  With both types present the two kernels overlap: the side stream forks off the
+        current stream (it sees everything enqueued so far, e.g. the simulator's state update) and joins it again."""
+        if self._side is None:
+            for launch in self._launches:
+                launch()
+            return
+        cur = torch.cuda.current_stream(self._device)
+        self._fork.record(cur)
+        self._fork.wait(self._side)
+        self._side_launch()
+        self._join.record(self._side)
+        self.parts[self._dom]["launch"]()
+        self._join.wait(cur)
 
     def step_dominant(self):
         self.parts[self._dom]["launch"]()

@@ -348,3 +348,45 @@ def test_euler_taskmap_golden(torch_mod, golden_dir):
         assert np.abs(J - g[f"f{fr}_J"]).max() < 5e-6
         assert np.abs(c - g[f"f{fr}_c"]).max() < 2e-6
         assert np.abs(tm.forward(g["q"]) - g[f"f{fr}_x"]).max() < 2e-6
+
+
+def test_mixed_fleet_shard_overlapped_step_against_the_oracle(torch_mod):
+    """BASELINE config 5 as bench.py drives it (fleet.MixedFleetShard.synthetic, 4 096 robots here): both robot types on
+    one GPU, the TwoJoint kernel on a side stream beside the Pandas' (fork / join by device-scope fences).  Against the
+    oracle on the first robots of each type, and -- the ordering -- a state update enqueued on the CURRENT stream right
+    before step() must be seen by both kernels, and the results must be complete when the current stream continues."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    shard = MixedFleetShard.synthetic(4096, 1, 0, 0)
+    assert shard._side is not None and set(shard.parts) == {"two_joint", "panda"}
+    new_state = {}
+    for key, part in shard.parts.items():
+        q, qd, goal, _ = part["keep"]
+        new_state[key] = (q.clone().mul_(0.9), qd.clone().mul_(-0.5))
+    for rep in range(3):
+        shard.step()
+    # a state update on the current stream, immediately followed by the step and by a reader on the current stream
+    copies = {}
+    for key, part in shard.parts.items():
+        q, qd, goal, _ = part["keep"]
+        q.copy_(new_state[key][0])
+        qd.copy_(new_state[key][1])
+    shard.step()
+    for key, part in shard.parts.items():
+        copies[key] = part["out"].clone()          # reader on the current stream, no host synchronisation before it
+    torch.cuda.synchronize()
+    n_ref = 192
+    for key, part in shard.parts.items():
+        q, qd, goal, _ = part["keep"]
+        h = part["host"]
+        off = h["csr_offset"][: n_ref + 1]
+        ref = O.step(part["desc"], q[:n_ref].cpu().numpy(), qd[:n_ref].cpu().numpy(), goal[:n_ref].cpu().numpy(),
+                     spheres=h["spheres"], csr_offset=off, csr_index=h["csr_index"][: off[-1]])["qdd64"]
+        got = copies[key][:n_ref].cpu().numpy()
+        err = np.abs(got - ref).max(axis=1)
+        tol = 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))
+        # near-contact robots of the ragged fleet: the relative bound of test_config5_* applies
+        ok = (err <= tol) | (err <= 1e-3 * np.abs(ref).max(axis=1))
+        assert ok.mean() >= 0.98 and np.isfinite(got).all(), f"{key}: worst {err.max():.3e}, {(~ok).sum()} of {n_ref} out"
+        assert torch.equal(copies[key], part["out"])
