@@ -228,6 +228,8 @@ class Engine:
                 raise ValueError("rollout needs contiguous fp32 CUDA tensors (they are updated in place)")
         if q.dim() != 2 or q.shape[1] != self.n_dof or q.shape != qd.shape:
             raise ValueError(f"q and qd must be [R, {self.n_dof}]")
+        if self._fence_attached:
+            self._attach_fence(None)
         R = q.shape[0]
         goal_ptr, goal_stride = None, 0
         if self.desc.goal_floats:
