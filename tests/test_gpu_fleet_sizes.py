@@ -1,0 +1,45 @@
+"""Default dispatch at awkward fleet sizes: block tails (R not a multiple of the robots per wave / block), the cuts between
+the three mappings (dispatch_solve, csrc/rmp2_hip.hip: hex up to 8 192 robots, quad beyond, lane beyond 32 768 for sets
+without distance leaves) and between the quad kernel's register caps (two / three waves per SIMD by fleet size).  Against
+the oracle on the first and last robots of the fleet and a random sample in between; the kernel that ran is asserted, so a
+moved cut shows up here and not only in a benchmark."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = {
+    # R: (kernel of config 2, kernel of config 3)
+    1: ("hex", "hex"), 17: ("hex", "hex"), 4097: ("hex", "hex"), 8192: ("hex", "hex"), 8193: ("quad", "quad"),
+    20481: ("quad", "quad"), 32768: ("quad", "quad"), 32769: ("one lane", "quad"), 49153: ("one lane", "quad"),
+    70001: ("one lane", "quad"),
+}
+
+
+@pytest.mark.parametrize("name", ["config2", "config3"])
+def test_awkward_fleet_sizes_default_dispatch(hip_lib, name):
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = getattr(Cf, name)()
+    eng = Engine(desc, 0)
+    for R, kernels in SIZES.items():
+        rng = np.random.default_rng(R)
+        s = Cf.sample_panda_states(rng, R)
+        sph = Cf.sample_spheres(rng)
+        sph[:, 2] += 1.2                       # above the arms: clearances stay out of the near-contact regime
+        obs = eng.obstacles(spheres=torch.from_numpy(sph)) if name == "config3" else None
+        st = torch.zeros(R, dtype=torch.int32, device="cuda")
+        out = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=obs, status=st)
+        torch.cuda.synchronize()
+        assert kernels[name == "config3"] in eng.last_kernel(), f"{name} R={R}: {eng.last_kernel()}"
+        sub = np.unique(np.concatenate([np.arange(min(R, 40)), np.arange(max(0, R - 40), R), rng.integers(0, R, 200)]))
+        kw = dict(spheres=sph) if name == "config3" else {}
+        ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], **kw)["qdd64"]
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), f"{name} R={R}: non-finite output"
+        err = np.abs(got[sub] - ref).max(axis=1)
+        tol = 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))     # the tolerance of tests/test_gpu_parity.py
+        assert (err <= tol).all(), f"{name} R={R}: worst {err.max():.3e} ({eng.last_kernel()})"
+        assert int((st != 0).sum()) == 0
