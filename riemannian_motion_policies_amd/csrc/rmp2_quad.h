@@ -658,7 +658,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const int ctl = uni<STAGE>(__float_as_int(ac.w));
       const int c_restore = (ctl & 3) - 2, c_save = ((ctl >> 2) & 3) - 1, c_jtype = (ctl >> 4) & 3;
       const int qi = ((ctl >> 6) & 31) - 1;
-      const float qdv = qi >= 0 ? my_qd[qi] : 0.f;
+      // branch-free joint handling (a taken scalar branch costs a two-wave SIMD the work of ~5 instructions): the joint
+      // velocity is read unconditionally and the joint type enters as two wave-uniform 0 / 1 factors
+      const float qdv = my_qd[max(qi, 0)];
+      const float f_rev = (c_jtype == RMP2_JOINT_REVOLUTE && qi >= 0) ? 1.0f : 0.0f;
+      const float f_pri = (c_jtype == RMP2_JOINT_PRISMATIC && qi >= 0) ? 1.0f : 0.0f;
       {  // next frame's record: issued now, consumed one iteration later
         const int kn = min(k + 1, n_ops - 1);
         rec4n = reinterpret_cast<const float4*>(loc + kSlot * kn);
@@ -669,15 +673,17 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
       const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
       const float tl[3] = {r2_.y, r2_.z, r2_.w};
-      if (c_restore == -2) {
-        // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
+      if (c_restore != -1) {  // (one test for the common case: the frame continues from its predecessor)
+        if (c_restore == -2) {
+          // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
 #pragma unroll
-        for (int m = 0; m < 3; ++m) cur.R[m] = (m == sub) ? 1.0f : 0.0f;
-        cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
-      } else if (SLOTS > 0 && c_restore >= 0) {
+          for (int m = 0; m < 3; ++m) cur.R[m] = (m == sub) ? 1.0f : 0.0f;
+          cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
+        } else if (SLOTS > 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < SLOTS; ++s2)
-          if (c_restore == s2) cur = slot[s2];
+          for (int s2 = 0; s2 < SLOTS; ++s2)
+            if (c_restore == s2) cur = slot[s2];
+        }
       }
       // world: my row of  R_parent @ R_local, my component of  R_parent @ t_local + p_parent
       float Rn[3];
@@ -695,19 +701,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const float t2 = a1 * r2 - a2 * r1;  // alpha_p x r
       const float t1a = dpp<kRot1>(t1), t1b = dpp<kRot2>(t1);
       const float t3 = w1 * t1b - w2 * t1a;  // w_p x (w_p x r)
-      float wn = cur.w, aln = cur.al, vn = cur.v + t1, an = cur.a + t2 + t3;
-      if (c_jtype != RMP2_JOINT_FIXED) {
-        const float zq = z * qdv;
-        const float zq1 = dpp<kRot1>(zq), zq2 = dpp<kRot2>(zq);
-        const float t4 = w1 * zq2 - w2 * zq1;  // w_p x (z qd)
-        if (c_jtype == RMP2_JOINT_REVOLUTE) {
-          wn += zq;
-          aln += t4;
-        } else {
-          vn += zq;
-          an += 2.0f * t4;
-        }
-      }
+      const float zq = z * qdv;
+      const float zq1 = dpp<kRot1>(zq), zq2 = dpp<kRot2>(zq);
+      const float t4 = w1 * zq2 - w2 * zq1;  // w_p x (z qd)
+      // (x + 1 * y and x + 0 * y are exact: same values as the branched form)
+      const float wn = fmaf(f_rev, zq, cur.w), aln = fmaf(f_rev, t4, cur.al);
+      const float vn = fmaf(f_pri, zq, cur.v + t1), an = fmaf(2.0f * f_pri, t4, cur.a + t2 + t3);
 #pragma unroll
       for (int c = 0; c < 3; ++c) cur.R[c] = Rn[c];
       cur.p = pn;
