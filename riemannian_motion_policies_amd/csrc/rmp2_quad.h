@@ -1,6 +1,7 @@
-// rmp2_quad.h -- the production control-step kernel: FOUR LANES (one DPP quad) PER ROBOT.
+// rmp2_quad.h -- the throughput control-step kernel: FOUR LANES (one DPP quad) PER ROBOT (fleets beyond 8 192 robots;
+// rmp2_hex.h below that, see dispatch_solve in rmp2_hip.hip).
 //
-// Why a quad: at the fleet sizes that matter (4 096 .. 65 536 robots per GPU) a
+// Why a quad: at the fleet sizes that matter (8 192 .. 65 536+ robots per GPU) a
 // lane-per-robot mapping gives at most one wave per SIMD and every step is one long dependent
 // instruction stream (measured: 22 us for the 3-leaf Panda set, 183 us for the cluttered set,
 // identical at R = 4 096 and R = 65 536 -- pure latency).  Spreading one robot over a quad
@@ -454,7 +455,8 @@ struct QuadState {
 };
 
 // MINW = minimum waves per SIMD the register allocator must leave room for: 1 (up to 512
-// registers, no spills) for fleets that cannot put two waves on a SIMD anyway, 2 for larger ones.
+// registers, no spills) for fleets that cannot put two waves on a SIMD anyway; 2 or 3 (256 / 168 registers) for larger
+// ones, chosen from the fleet size in launch_quad (rmp2_hip.hip); 4 (128 registers) is an A/B build only.
 // STAGE = true: the whole program (ops, leaf records, lists) and the goal rows are copied into LDS
 // in the SAME burst of loads that brings the q / qd tile on chip.  At the kernel boundary every
 // XCD's L2 starts cold, so each DEPENDENT scalar/global load round costs ~1000 cycles (measured);
