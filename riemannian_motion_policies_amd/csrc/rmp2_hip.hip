@@ -888,6 +888,7 @@ struct rmp2_handle {
                       // env RMP2_QUAD_MINW=2|3|4 pins it (A/B only)
   int n_simd = 1024;  // SIMDs of the device (4 per CU)
   void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
+  bool symmetric = false;      // no leaf with a non-symmetric metric (JointLimitAvoidance, quirk Q2) in the set
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1233,31 +1234,42 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
                     blocks > 4 * h->n_simd ? 2 : 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
-  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256 or 168 registers (two or three
-  // waves per SIMD).  Three waves retire the leaf phases ~10 % faster per robot (1.10 vs 0.99 G steps/s at 262 144
-  // robots), but a SIMD's share of the fleet has to divide into rounds: with b = waves owed per SIMD, two waves win for
-  // b <= 2 and 3 < b <= 4 (the 65 536-robot fleet: 2 + 2 beats 3 + 1, 68.8 vs 76.1 us), three everywhere else
-  // (profiles/r02_quad_minw_ab.txt).  Four waves (128 registers, ~200 scratch accesses per wave) lose at every size.
+  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
+  // or four waves per SIMD).  More waves retire the leaf phases faster per robot (1.10 vs 0.99 G steps/s at 262 144
+  // robots with three instead of two), but a SIMD's share of the fleet has to divide into rounds.  With b = waves owed
+  // per SIMD (profiles/r02_quad_minw_ab.txt): two waves for b <= 2, three for b <= 3 and wherever four do not divide b;
+  // the 128-register build pays ~150 scratch accesses per wave and only wins in the symmetric form of the kernel (its
+  // elimination keeps 15 instead of 27 doubles per lane) where b is a multiple of four -- the 65 536-robot fleet: 63.9 us
+  // against 66.0 with two waves and 76.8 with three.  Sets with a JointLimitAvoidance leaf (general form): two waves for
+  // 3 < b <= 4, three otherwise.
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
+  const bool symk = h->symmetric && N == 9 && !o.capsule;
   int minw = h->quad_minw;
   if (minw == 0) {
-    const double b = (double)blocks / (double)h->n_simd;
-    minw = (b <= 2.0 || (b > 3.0 && b <= 4.0)) ? 2 : 3;
+    const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
+    if (bc <= 2) minw = 2;
+    else if (bc == 3) minw = 3;
+    else if (bc % 4 == 0) minw = symk ? 4 : (bc == 4 ? 2 : 3);
+    else minw = 3;
   }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
-#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP)                                                                              \
-  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP>), dim3(blocks), dim3(kWave), bytes, s, h->d_prog, \
-                   hdr, q, qd, goal, gs, o, out, ro, R)
-  if (latency) {
-    if (o.capsule) RMP2_QUAD_LAUNCH(1, true, true); else RMP2_QUAD_LAUNCH(1, true, false);
-  } else if (minw == 4) {  // A/B only (env RMP2_QUAD_MINW=4): 128 registers, four waves per SIMD
-    if (o.capsule) RMP2_QUAD_LAUNCH(4, false, true); else RMP2_QUAD_LAUNCH(4, false, false);
-  } else if (minw == 3) {  // 168 registers, three waves per SIMD
-    if (o.capsule) RMP2_QUAD_LAUNCH(3, false, true); else RMP2_QUAD_LAUNCH(3, false, false);
-  } else {
-    if (o.capsule) RMP2_QUAD_LAUNCH(2, false, true); else RMP2_QUAD_LAUNCH(2, false, false);
-  }
+#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM)                                                                         \
+  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM>), dim3(blocks), dim3(kWave), bytes, s,    \
+                   h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
+  // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
+  // template with sphere tables (symk above); everything else takes the general form
+#define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \
+  do {                                                                                                                  \
+    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false);                                                          \
+    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9));                                                      \
+    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false);                                                                   \
+  } while (0)
+  if (latency) RMP2_QUAD_BY_CAP(1, true);
+  else if (minw == 4) RMP2_QUAD_BY_CAP(4, false);  // 128 registers, four waves per SIMD
+  else if (minw == 3) RMP2_QUAD_BY_CAP(3, false);  // 168 registers, three waves per SIMD
+  else RMP2_QUAD_BY_CAP(2, false);
+#undef RMP2_QUAD_BY_CAP
 #undef RMP2_QUAD_LAUNCH
 }
 
@@ -1522,6 +1534,10 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
         (lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING && lf.params[2] > 0.f))
       h->likely_singular = false;
   }
+  h->symmetric = true;  // every kind but JointLimitAvoidance (A = w * H scales COLUMNS, quirk Q2) has a symmetric metric
+  for (int l = 0; l < desc->n_leaves; ++l)
+    if (desc->leaves[l].kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) h->symmetric = false;
+  if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // A/B: 0 = general form
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
   {

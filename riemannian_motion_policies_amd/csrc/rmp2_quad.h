@@ -25,6 +25,7 @@
 // hardware approximations refined to <= 1 ulp (Newton step / compensated argument); sin/cos
 // use a Cody-Waite + minimax kernel (<= 1 ulp for |q| <= 8192, ocml beyond).
 #pragma once
+#include <type_traits>
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
 
@@ -469,7 +470,9 @@ __device__ __forceinline__ int uni(int v) {
   return STAGE ? __builtin_amdgcn_readfirstlane(v) : v;
 }
 
-template <int N, int SLOTS, int MINW, bool STAGE, bool CAP>
+// SYM = every leaf of the set has a symmetric metric (no JointLimitAvoidance, quirk Q2; decided at rmp2_create): the
+// system stays in block-upper form through the identity leaves and the elimination.
+template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
@@ -925,25 +928,32 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     }
     // ---- mirror the block-upper part: M[i][j] = M[j][i] for the blocks below the diagonal ------------------------
     // lane s, local row m (global row i = s + 4 m), column 4 b + c (b < m):  the value sits in lane c as A[b][s + 4 m]
+    // Sets whose leaves are all symmetric (hdr.sym) never need the lower blocks on the fast path: the identity leaves
+    // add symmetric terms and the elimination takes its multipliers from the broadcast pivot row (M[i][k] = M[k][i]);
+    // the mirror is then only run for the debug output of M and for the careful solver of a flagged robot.
+    auto mirror = [&]() {
 #pragma unroll
-    for (int m = 1; m < ROWS; ++m) {
+      for (int m = 1; m < ROWS; ++m) {
 #pragma unroll
-      for (int b = 0; b < m; ++b) {
+        for (int b = 0; b < m; ++b) {
 #pragma unroll
-        for (int c = 0; c < kQuad; ++c) {
-          double w = 0.0;
+          for (int c = 0; c < kQuad; ++c) {
+            double w = 0.0;
 #pragma unroll
-          for (int s2 = 0; s2 < kQuad; ++s2) {
-            if (s2 + kQuad * m < N) {  // compile time: the source column exists
-              const double v = A[b][s2 + kQuad * m];
-              const double t = c == 0 ? bcastd<0>(v) : c == 1 ? bcastd<1>(v) : c == 2 ? bcastd<2>(v) : bcastd<3>(v);
-              w = (sub == s2) ? t : w;
+            for (int s2 = 0; s2 < kQuad; ++s2) {
+              if (s2 + kQuad * m < N) {  // compile time: the source column exists
+                const double v = A[b][s2 + kQuad * m];
+                const double t = c == 0 ? bcastd<0>(v) : c == 1 ? bcastd<1>(v) : c == 2 ? bcastd<2>(v) : bcastd<3>(v);
+                w = (sub == s2) ? t : w;
+              }
             }
+            A[m][kQuad * b + c] = w;
           }
-          A[m][kQuad * b + c] = w;
         }
       }
-    }
+    };
+    constexpr bool sym = SYM;
+    if (!sym) mirror();
 
     if (hdr.prio_tail) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
     RMP2_STAMP();  // 3: FK leaves done
@@ -1030,7 +1040,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const double dd = row_ok ? (double)dg[m] - wd : 0.0;  // exact: A_ii = w + (d_i - w) = d_i
 #pragma unroll
           for (int j = 0; j < N; ++j)
-            if (j < n_dof) A[m][j] += wr;
+            if (j < n_dof && (j >= kQuad * m || !sym)) A[m][j] += wr;  // (sym: the blocks below the diagonal are not kept)
 #pragma unroll
           for (int c = 0; c < kQuad; ++c)
             if (kQuad * m + c < N) A[m][kQuad * m + c] += (sub == c) ? dd : 0.0;
@@ -1138,6 +1148,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
+    if (sym && out.M && pass == 0) mirror();  // (wave-uniform; the lower blocks it fills are not read by the sym resolve)
     if (pass == 0 && live) {
 #pragma unroll
       for (int m = 0; m < ROWS; ++m) {
@@ -1164,46 +1175,62 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     if (pass == 0) {
       // ---- resolve: row-distributed fp64 elimination without row exchanges -------------------
       // (certification and fall-through exactly as lu_solve<N>, rmp2_solve.h)
-      double scale = 0.0;
-#pragma unroll
-      for (int m = 0; m < ROWS; ++m)
-#pragma unroll
-        for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(A[m][j]));
-      scale = fmax(scale, dppd<kXor1>(scale));
-      scale = fmax(scale, dppd<kXor2>(scale));
-      const double tiny = 1e-11 * scale;
-      flagged = !(scale > 0.0) || !(scale < 1.7e308);
       double lmax = 0.0;
       double inv_piv[N];
+      // symmetric sets: only the block-upper part (row block m, columns >= 4 m) is read and updated;
+      // a multiplier whose entry lies below the diagonal blocks is taken from the broadcast pivot row, M[i][k] = M[k][i]
+      auto eliminate = [&](auto symc) {
+        constexpr bool SYME = decltype(symc)::value;
+        double scale = 0.0;
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const int ks = k & 3, km = k >> 2;
-        // broadcast row k (columns k..N-1) and b_k from its owner
-        double rowk[N], bk;
+        for (int m = 0; m < ROWS; ++m)
 #pragma unroll
-        for (int j = k; j < N; ++j) {
-          const double v = A[km][j];
-          rowk[j] = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
+          for (int j = SYME ? kQuad * m : 0; j < N; ++j) scale = fmax(scale, fabs(A[m][j]));
+        scale = fmax(scale, dppd<kXor1>(scale));
+        scale = fmax(scale, dppd<kXor2>(scale));
+        const double tiny = 1e-11 * scale;
+        flagged = !(scale > 0.0) || !(scale < 1.7e308);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const int ks = k & 3, km = k >> 2;
+          // broadcast row k (columns k..N-1) and b_k from its owner
+          double rowk[N], bk;
+#pragma unroll
+          for (int j = k; j < N; ++j) {
+            const double v = A[km][j];
+            rowk[j] = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
+          }
+          {
+            const double v = fv[km];
+            bk = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
+          }
+          const bool bad = !(fabs(rowk[k]) > tiny);
+          flagged = flagged || bad;
+          const double inv = bad ? 0.0 : rcpd(rowk[k]);
+          inv_piv[k] = inv;
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            if (kQuad * m + 3 <= k) continue;  // no lane has a row i = sub + 4m > k in this block
+            const int i = sub + kQuad * m;
+            double aik;
+            if (!SYME || kQuad * m <= k) {
+              aik = A[m][k];  // stored: general form, or column k inside / right of the diagonal block
+            } else {          // below the diagonal blocks: M[i][k] = M[k][i], element i = 4 m + sub of the pivot row
+              aik = rowk[kQuad * m];
+#pragma unroll
+              for (int c = 1; c < kQuad; ++c)
+                if (kQuad * m + c < N) aik = (sub == c) ? rowk[kQuad * m + c] : aik;
+            }
+            const double l = (i > k) ? aik * inv : 0.0;
+            lmax = fmax(lmax, fabs(l));
+#pragma unroll
+            for (int j = k + 1; j < N; ++j)
+              if (!SYME || j >= kQuad * m) A[m][j] = fma(-l, rowk[j], A[m][j]);
+            fv[m] = fma(-l, bk, fv[m]);
+          }
         }
-        {
-          const double v = fv[km];
-          bk = ks == 0 ? bcastd<0>(v) : ks == 1 ? bcastd<1>(v) : ks == 2 ? bcastd<2>(v) : bcastd<3>(v);
-        }
-        const bool bad = !(fabs(rowk[k]) > tiny);
-        flagged = flagged || bad;
-        const double inv = bad ? 0.0 : rcpd(rowk[k]);
-        inv_piv[k] = inv;
-#pragma unroll
-        for (int m = 0; m < ROWS; ++m) {
-          if (kQuad * m + 3 <= k) continue;  // no lane has a row i = sub + 4m > k in this block
-          const int i = sub + kQuad * m;
-          const double l = (i > k) ? A[m][k] * inv : 0.0;
-          lmax = fmax(lmax, fabs(l));
-#pragma unroll
-          for (int j = k + 1; j < N; ++j) A[m][j] = fma(-l, rowk[j], A[m][j]);
-          fv[m] = fma(-l, bk, fv[m]);
-        }
-      }
+      };
+      eliminate(std::integral_constant<bool, SYM>{});
       lmax = fmax(lmax, dppd<kXor1>(lmax));
       lmax = fmax(lmax, dppd<kXor2>(lmax));
       flagged = flagged || !(lmax <= 1e4);
@@ -1237,6 +1264,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       if (!__any(flagged && live)) break;
     } else if (flagged) {
       // ---- rare path: gather the whole system into every lane of the quad, careful solve -------
+      if (sym) mirror();  // (the fast path of a symmetric set keeps the block-upper part only)
       double W[N * (N + 1)], T[N * (N + 1)], xp[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) {
