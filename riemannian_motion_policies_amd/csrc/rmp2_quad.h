@@ -654,7 +654,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // registers in the 256-register build; in the 128-register build the walk's state otherwise lives in scratch)
     QuadState cur = {};
     QuadState slot[SLOTS > 0 ? SLOTS : 1] = {};
-    const float4* rec4n = reinterpret_cast<const float4*>(loc);
+    // loop-local copies of the long-lived LDS addresses: their own short live ranges -- the 128-register build otherwise
+    // reloads the spilled originals inside the loop (4 scratch loads per frame on the kernel's one serial chain)
+    float* wloc = loc;
+    const float* wqd = my_qd;
+    if (MINW >= 3) asm volatile("" : "+v"(wloc), "+v"(wqd));  // (the builds with registers to spare lose 3 % to it)
+    const float4* rec4n = reinterpret_cast<const float4*>(wloc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2];
     // {axis, ctl} of the frame: wave-uniform, one 16-byte fetch per frame (scalar cache, or the staged copy), one ahead
     float4 nac = *reinterpret_cast<const float4*>(ops[0].axis);
@@ -665,12 +670,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       const int qi = ((ctl >> 6) & 31) - 1;
       // branch-free joint handling (a taken scalar branch costs a two-wave SIMD the work of ~5 instructions): the joint
       // velocity is read unconditionally and the joint type enters as two wave-uniform 0 / 1 factors
-      const float qdv = my_qd[max(qi, 0)];
+      const float qdv = wqd[max(qi, 0)];
       const float f_rev = (c_jtype == RMP2_JOINT_REVOLUTE && qi >= 0) ? 1.0f : 0.0f;
       const float f_pri = (c_jtype == RMP2_JOINT_PRISMATIC && qi >= 0) ? 1.0f : 0.0f;
       {  // next frame's record: issued now, consumed one iteration later
         const int kn = min(k + 1, n_ops - 1);
-        rec4n = reinterpret_cast<const float4*>(loc + kSlot * kn);
+        rec4n = reinterpret_cast<const float4*>(wloc + kSlot * kn);
         n0 = rec4n[0];
         n1 = rec4n[1];
         n2 = rec4n[2];
@@ -720,7 +725,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       cur.v = vn;
       cur.a = an;
       if (sub < 3) {  // the frame's world record [p, v, a, z] replaces its local transform (consumed by every lane of
-        float* fr = loc + kSlot * k;  // the quad one iteration ago)
+        float* fr = wloc + kSlot * k;  // the quad one iteration ago)
         fr[sub] = pn;
         fr[3 + sub] = vn;
         fr[6 + sub] = an;
@@ -772,6 +777,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
     // (scalar-cache walk: the frame's flattened record is fetched one frame ahead -- a dependent scalar fetch costs
     // ~200 cycles and the old chain leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id] had four of them per frame)
+    const float* floc = loc;  // (loop-local copy, as in the walk)
+    if (MINW >= 3) asm volatile("" : "+v"(floc));
     int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
       if (2 * t == hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
@@ -793,7 +800,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
       RMP2_SEG_BEGIN();
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
-      const float4* fr4 = reinterpret_cast<const float4*>(loc + kSlot * k);
+      const float4* fr4 = reinterpret_cast<const float4*>(floc + kSlot * k);
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
       const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
       // Jacobian columns of the frame: formed AFTER the first leaf's (S, h) -- the pair loop is where the time goes and
