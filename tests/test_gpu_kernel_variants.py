@@ -254,3 +254,64 @@ def test_quad_register_caps_agree_bitwise_at_fleet_sizes(torch_mod):
         res.append((q.clone(), qd.clone(), qdd.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_symmetric_form_against_the_general_form_and_its_careful_path(torch_mod):
+    """The quad kernel's symmetric form (template flag SYM, sets without a JointLimitAvoidance leaf: the system stays
+    block-upper through the identity leaves and the elimination) against the general form (RMP2_QUAD_SYM=0) of the same
+    kernel: same arithmetic up to the order of the fp64 eliminations, so the fp32 results agree far inside the parity
+    tolerance.  Then the one place where the symmetric form needs the FULL matrix on a rare path -- the careful solver of a
+    flagged robot, fed by the mirror step: a Panda with a lone target attractor (rank <= 3 of 9: every robot is flagged)
+    stepped through the fused-rollout entry (which keeps such sets on the elimination mappings), against the general
+    form bit for bit."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    from riemannian_motion_policies_amd.urdf import panda_table
+    _, desc = Cf.config3()
+    R = 12288                                   # quad by default dispatch, latency build
+    s = Cf.sample_panda_states(np.random.default_rng(3), R)
+    sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng(7))).cuda()
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    outs = []
+    for symenv in ("1", "0"):
+        eng = _engine_env(desc, RMP2_KERNEL="quad", RMP2_QUAD_SYM=symenv)
+        M = torch.zeros((R, 9, 9), dtype=torch.float64, device="cuda")
+        outs.append((eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=sph), M=M).clone(), M.clone()))
+    torch.cuda.synchronize()
+    a, b = outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy()
+    scale = np.maximum(1.0, np.abs(b).max(axis=1))
+    diff = np.abs(a - b).max(axis=1)
+    # unrestricted states: ~2 % of the robots touch or penetrate a sphere (|qdd| ~ 1e3, metric entries spanning ten orders
+    # of magnitude); there the ORDER of the fp64 eliminations shows at 1e-5 relative in either form (measured: both forms
+    # sit equally far from the oracle, 1e-5 .. 1e-4).  Everywhere else the two forms agree to fp32 rounding.
+    calm = scale <= 50.0
+    assert calm.mean() > 0.9 and (diff[calm] <= 2e-6 * scale[calm]).all(), diff[calm].max()
+    assert (diff <= 1e-3 * scale).all(), (diff / scale).max()
+    assert torch.equal(outs[0][1], outs[1][1]), "the exported metric (mirrored for the output in the symmetric form) differs"
+    # (inside the diagonal 4 x 4 blocks M[i][j] and M[j][i] are formed by different lanes, (S c_i) . c_j and (S c_j) . c_i in
+    # fp32: symmetric to rounding; the off-diagonal blocks are copies)
+    Ms = outs[0][1]
+    asym = (Ms - Ms.transpose(1, 2)).abs().amax(dim=(1, 2)) / Ms.abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    assert float(asym.max()) < 1e-6, float(asym.max())
+    # careful path of the symmetric form
+    t = panda_table()
+    lone = D.build_desc(t, [D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                                       Cf.TARGET_ATTRACTOR_PARAMS, goal_len=3, name="attractor")])
+    R2 = 8704                                   # beyond the hex cut: the rollout entry launches the quad kernel
+    s2 = Cf.sample_panda_states(np.random.default_rng(4), R2)
+    q2, qd2, g2 = (torch.from_numpy(s2[k]).cuda() for k in ("q", "qd", "goal"))
+    res = []
+    for symenv in ("1", "0"):
+        eng = _engine_env(lone, RMP2_KERNEL="quad", RMP2_QUAD_SYM=symenv)
+        st = torch.zeros(R2, dtype=torch.int32, device="cuda")
+        qdd = eng.rollout(q2.clone(), qd2.clone(), g2, n_control_steps=1, substeps=1, dt=0.0, status=st)   # dt = 0: q, qd unchanged
+        torch.cuda.synchronize()
+        assert "quad" in eng.last_kernel()
+        res.append((qdd.clone(), st.clone()))
+    # a rank-3 system: WHAT the pseudo-inverse returns is pinned elsewhere (golden config 1, exp-04 sets, the strict-pinv
+    # tests); here the point is that the careful solver of the symmetric form is fed the same full matrix as the general
+    # form's -- its input is the mirrored block-upper system -- so the two must agree bit for bit
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.isfinite(res[0][0]).all()
+    assert (res[0][1].cpu().numpy() != 0).all(), "every robot of a rank-deficient set must report the pseudo-inverse path"
