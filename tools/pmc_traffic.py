@@ -21,5 +21,9 @@ out = {"workload": sys.argv[3], "robots": robots, "launches": min(nf, nw),
        "algorithmic_bytes_per_launch": 120 * robots,
        "note": "FETCH_SIZE/WRITE_SIZE from separate --pmc passes, gfx950 correction FETCH x2 (calibrated on this access "
                "pattern); memory-side (fabric) requests, Infinity-Cache hits included"}
+if out["hbm_bytes_per_launch"] > 2 * out["algorithmic_bytes_per_launch"]:
+    # the 128-register (four waves per SIMD) build of the quad kernel spills: its private-segment traffic is what shows here
+    out["note"] += ("; above the algorithmic bytes: register-spill (scratch) traffic of the register-capped kernel build that "
+                    "ran -- DESIGN.md section 5 gives the per-wave figure and the time it buys")
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
