@@ -686,8 +686,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       if (c_restore != -1) {  // (one test for the common case: the frame continues from its predecessor)
         if (c_restore == -2) {
           // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
+          int sb = sub;  // (opaque copy: the three 0 / 1 values are not worth a register across the whole step)
+          asm volatile("" : "+v"(sb));
 #pragma unroll
-          for (int m = 0; m < 3; ++m) cur.R[m] = (m == sub) ? 1.0f : 0.0f;
+          for (int m = 0; m < 3; ++m) cur.R[m] = (m == sb) ? 1.0f : 0.0f;
           cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
         } else if (SLOTS > 0) {
 #pragma unroll
@@ -1127,9 +1129,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         }
         const float omb = 1.0f - beta;
         const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
+        int sd = sub;  // (opaque copy, as for the walk's base row)
+        asm volatile("" : "+v"(sd));
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
-          const int i = sub + kQuad * m;
+          const int i = sd + kQuad * m;
           const bool row_ok = i < n_dof;
           // zeta_i of MY row: select from the statically indexed vector
           float zi = 0.f;
@@ -1156,7 +1160,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
     if (sym && out.M && pass == 0) mirror();  // (wave-uniform; the lower blocks it fills are not read by the sym resolve)
-    if (pass == 0 && live) {
+    if (pass == 0 && live && (out.M || out.f)) {
+      // (the 64-bit row addresses are formed HERE, from an opaque copy of the robot index: hoisted to the prologue -- where
+      // the compiler otherwise puts them -- they are spilled by every wave of the register-capped builds and read back
+      // only when the debug outputs are asked for)
+      int rb = robot;
+      asm volatile("" : "+v"(rb));
 #pragma unroll
       for (int m = 0; m < ROWS; ++m) {
         const int i = sub + kQuad * m;
@@ -1164,9 +1173,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           if (out.M) {
 #pragma unroll
             for (int j = 0; j < N; ++j)
-              if (j < n_dof) out.M[((size_t)robot * n_dof + i) * n_dof + j] = A[m][j];
+              if (j < n_dof) out.M[((size_t)rb * n_dof + i) * n_dof + j] = A[m][j];
           }
-          if (out.f) out.f[(size_t)robot * n_dof + i] = fv[m];
+          if (out.f) out.f[(size_t)rb * n_dof + i] = fv[m];
         }
       }
     }
@@ -1294,17 +1303,21 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }
       bool finite = true;
+      float* co = my_out;
+      asm volatile("" : "+v"(co));
       for (int i = 0; i < n_dof; ++i) {
         finite = finite && (fabs(xp[i]) < 1.7e308);
-        if (sub == 0) my_out[i] = (float)xp[i];
+        if (sub == 0) co[i] = (float)xp[i];
       }
       if (!finite) status |= RMP2_STATUS_NONFINITE;
     }
   }
   if (ro.substeps > 0) {
     // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd); every lane advances ITS dofs
-    float* qw = &lds[QuadLds<N>::kQ + gi * N];
-    float* qdw = &lds[QuadLds<N>::kQd + gi * N];
+    int gio = gi;
+    asm volatile("" : "+v"(gio));
+    float* qw = &lds[QuadLds<N>::kQ + gio * N];
+    float* qdw = &lds[QuadLds<N>::kQd + gio * N];
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
       const int i = sub + kQuad * m;
@@ -1324,9 +1337,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
   // ---- coalesced store of the qdd tile (and of the advanced state after a rollout) ---------------------
   __syncthreads();
+  int lane_o = lane;  // (opaque copy: keeps the store addresses from being formed in the prologue and spilled)
+  asm volatile("" : "+v"(lane_o));
   if (ro.q_out) {
     const int count = n_live * n_dof;
-    for (int i = lane; i < count; i += kWave) {
+    for (int i = lane_o; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
       ro.q_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQ + rr * N + jj];
       ro.qd_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQd + rr * N + jj];
@@ -1336,7 +1351,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     const float* tile = &lds[QuadLds<N>::kLoc];
     const int count = min(kRobotsPerWave, R - r0) * n_dof;
     float* go = out.qdd + (size_t)r0 * n_dof;
-    for (int i = lane; i < count; i += kWave) {
+    for (int i = lane_o; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
       go[i] = tile[rr * out_stride + jj];
     }
