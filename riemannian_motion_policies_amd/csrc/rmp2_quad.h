@@ -687,7 +687,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (c_restore == -2) {
           // base: identity rotation row, zero vectors.  (e_sub @ Rl == row sub of Rl exactly.)
           int sb = sub;  // (opaque copy: the three 0 / 1 values are not worth a register across the whole step)
-          asm volatile("" : "+v"(sb));
+          if (MINW >= 3) asm volatile("" : "+v"(sb));
 #pragma unroll
           for (int m = 0; m < 3; ++m) cur.R[m] = (m == sb) ? 1.0f : 0.0f;
           cur.p = cur.w = cur.al = cur.v = cur.a = 0.f;
@@ -864,8 +864,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             pair_loop<kPairsExplicit, false>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3,
                                       A3, lh.P, IP, S, h);
           } else {
-            const int b0 = obs.csr_offset[live ? robot : 0];
-            const int count = live ? obs.csr_offset[robot + 1] - b0 : 0;
+            int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
+            if (MINW >= 3) asm volatile("" : "+v"(rr_));
+            const int b0 = obs.csr_offset[rr_];
+            const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
             int max_count = count;
 #pragma unroll
             for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
@@ -1130,7 +1132,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         const float omb = 1.0f - beta;
         const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
         int sd = sub;  // (opaque copy, as for the walk's base row)
-        asm volatile("" : "+v"(sd));
+        if (MINW >= 3) asm volatile("" : "+v"(sd));
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
           const int i = sd + kQuad * m;
@@ -1165,7 +1167,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       // the compiler otherwise puts them -- they are spilled by every wave of the register-capped builds and read back
       // only when the debug outputs are asked for)
       int rb = robot;
-      asm volatile("" : "+v"(rb));
+      if (MINW >= 3) asm volatile("" : "+v"(rb));
 #pragma unroll
       for (int m = 0; m < ROWS; ++m) {
         const int i = sub + kQuad * m;
@@ -1304,7 +1306,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
       bool finite = true;
       float* co = my_out;
-      asm volatile("" : "+v"(co));
+      if (MINW >= 3) asm volatile("" : "+v"(co));
       for (int i = 0; i < n_dof; ++i) {
         finite = finite && (fabs(xp[i]) < 1.7e308);
         if (sub == 0) co[i] = (float)xp[i];
@@ -1315,7 +1317,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   if (ro.substeps > 0) {
     // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd); every lane advances ITS dofs
     int gio = gi;
-    asm volatile("" : "+v"(gio));
+    if (MINW >= 3) asm volatile("" : "+v"(gio));
     float* qw = &lds[QuadLds<N>::kQ + gio * N];
     float* qdw = &lds[QuadLds<N>::kQd + gio * N];
 #pragma unroll
@@ -1338,7 +1340,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // ---- coalesced store of the qdd tile (and of the advanced state after a rollout) ---------------------
   __syncthreads();
   int lane_o = lane;  // (opaque copy: keeps the store addresses from being formed in the prologue and spilled)
-  asm volatile("" : "+v"(lane_o));
+  if (MINW >= 3) asm volatile("" : "+v"(lane_o));
   if (ro.q_out) {
     const int count = n_live * n_dof;
     for (int i = lane_o; i < count; i += kWave) {
