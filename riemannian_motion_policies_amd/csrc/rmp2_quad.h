@@ -1151,7 +1151,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
             float a = is_jla ? cw[j] * Hij : wsc * Hij;
             a = row_ok ? a : 0.f;
-            A[m][j] += (double)a;
+            if (!SYM || j >= kQuad * m) A[m][j] += (double)a;  // (sym: the blocks below the diagonal are not kept)
             fi += a * xdd[j];
           }
           fv[m] += (double)fi;
@@ -1161,13 +1161,15 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
-    if (sym && out.M && pass == 0) mirror();  // (wave-uniform; the lower blocks it fills are not read by the sym resolve)
     if (pass == 0 && live && (out.M || out.f)) {
       // (the 64-bit row addresses are formed HERE, from an opaque copy of the robot index: hoisted to the prologue -- where
       // the compiler otherwise puts them -- they are spilled by every wave of the register-capped builds and read back
       // only when the debug outputs are asked for)
       int rb = robot;
       if (MINW >= 3) asm volatile("" : "+v"(rb));
+      // (sym: the full rows exist only here -- the mirror sits in the block that reads them, so that the lower blocks are
+      // dead everywhere else; `live` is the same for the four lanes of a quad, which is all its quad permutes need)
+      if (sym && out.M) mirror();
 #pragma unroll
       for (int m = 0; m < ROWS; ++m) {
         const int i = sub + kQuad * m;
