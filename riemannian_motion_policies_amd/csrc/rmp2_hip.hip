@@ -884,7 +884,7 @@ struct rmp2_handle {
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
   int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
-  int quad_minw = 0;  // register cap of the throughput quad build: 0 = by fleet size (2 or 3 waves per SIMD, launch_quad);
+  int quad_minw = 0;  // register cap of the throughput quad build: 0 = by fleet size (2, 3 or 4 waves per SIMD, launch_quad);
                       // env RMP2_QUAD_MINW=2|3|4 pins it (A/B only)
   int n_simd = 1024;  // SIMDs of the device (4 per CU)
   void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
@@ -1235,13 +1235,16 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                     blocks > 4 * h->n_simd ? 2 : 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
-  // or four waves per SIMD).  More waves retire the leaf phases faster per robot (1.10 vs 0.99 G steps/s at 262 144
-  // robots with three instead of two), but a SIMD's share of the fleet has to divide into rounds.  With b = waves owed
-  // per SIMD (profiles/r02_quad_minw_ab.txt): two waves for b <= 2, three for b <= 3 and wherever four do not divide b;
-  // the 128-register build pays ~150 scratch accesses per wave and only wins in the symmetric form of the kernel (its
-  // elimination keeps 15 instead of 27 doubles per lane) where b is a multiple of four -- the 65 536-robot fleet: 63.9 us
-  // against 66.0 with two waves and 76.8 with three.  Sets with a JointLimitAvoidance leaf (general form): two waves for
-  // 3 < b <= 4, three otherwise.
+  // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
+  // divide into rounds.  With b = waves owed per SIMD (profiles/r02_quad_minw_ab.txt, us per step at the end of round 2):
+  //       b     1.5    2    2.5    3    3.5    4     5     6     8     12     16
+  //   2 waves  34.4  34.3  58.8  59.0  64.8  64.9  87.5  98.4  129.8  192.7  257.1
+  //   3 waves  35.9  36.2  41.5  42.2  65.0  65.3  71.8  82.7  108.0  157.0  205.6
+  //   4 waves  39.2  40.2  45.5  47.2  53.2  54.9  76.9  83.9  105.4  151.9  197.7   (symmetric form)
+  // two waves for ceil(b) <= 2, three for 3 and wherever four do not divide ceil(b), four where they do.  The 128-register
+  // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
+  // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
+  // ceil(b) == 4 and three otherwise.
   const bool latency = blocks <= 1024 && h->goal_floats <= 16;
   const bool symk = h->symmetric && N == 9 && !o.capsule;
   int minw = h->quad_minw;
