@@ -307,7 +307,9 @@ __device__ __forceinline__ int select_bit(uint32_t m, int r) {
 }
 
 // RAGGED: positions index the robot's CSR list ci[0 .. count); otherwise positions ARE sphere indices
-template <bool RAGGED, int W>
+// SKIP: leave out the test slots no robot of the wave fills (a wave-uniform branch per slot: pays where waves share a SIMD,
+// costs where a lone wave pays ~28 cycles per branch)
+template <bool RAGGED, int W, bool SKIP = false>
 __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, const int32_t* ci, int count, int max_count,
                                                  int sub, const float P3[3], const float V3[3], const float A3[3],
                                                  const float* P, const float* IP, float S[6], float h[3],
@@ -323,6 +325,7 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
     uint32_t m = 0u;
 #pragma unroll
     for (int i = 0; i < kTests; ++i) {
+      if (SKIP && base + W * i >= max_count) continue;  // wave-uniform: no robot of the wave has a sphere in this slot
       const int pos = base + sub + W * i;
       const bool valid = pos < count;
       int sidx = valid ? pos : 0;
@@ -844,10 +847,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds && !CAP)
 #ifdef RMP2_STAMPS
-              pair_loop_culled<false, kQuad>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
+              pair_loop_culled<false, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
                                              IP, S, h, &seg_[5]);
 #else
-              pair_loop_culled<false, kQuad>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
+              pair_loop_culled<false, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
                                              IP, S, h);
 #endif
             else if (spheres_in_lds)
@@ -872,7 +875,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #pragma unroll
             for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
             if (spheres_in_lds && !CAP)
-              pair_loop_culled<true, kQuad>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3, V3, A3, lh.P,
+              pair_loop_culled<true, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3, V3, A3, lh.P,
                                             IP, S, h);
             else if (spheres_in_lds)
               pair_loop<kPairsRaggedLds, CAP>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3,
