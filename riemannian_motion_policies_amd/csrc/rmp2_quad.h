@@ -896,6 +896,10 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           // whose dof does not move the frame get a zero column, so everything below is branch-free
 #pragma unroll
           for (int m = 0; m < ROWS; ++m) {
+            if (MINW >= 2 && ((op.anc_mask >> (kQuad * m)) & 0xfu) == 0u) {  // wave-uniform: no dof of this row block moves
+              mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;                 // the frame (nor is its record read)
+              continue;
+            }
             const bool act = (op.anc_mask >> (sub + kQuad * m)) & 1u;  // (bits >= n_dof are never set)
             if (!kRowRecsInRegs) {
               const float4 j0 = rjs[m][0], j2 = rjs[m][2];
