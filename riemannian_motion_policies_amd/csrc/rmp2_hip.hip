@@ -889,6 +889,7 @@ struct rmp2_handle {
   int n_simd = 1024;  // SIMDs of the device (4 per CU)
   void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
   bool symmetric = false;      // no leaf with a non-symmetric metric (JointLimitAvoidance, quirk Q2) in the set
+  int prio_tail = -1;          // env RMP2_PRIO_TAIL=0..3 pins the priority of the phases after the frame loop (A/B only)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1232,7 +1233,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
-                    blocks > 4 * h->n_simd ? 2 : 0};
+                    h->prio_tail >= 0 ? h->prio_tail : 0};
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
   // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
   // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
@@ -1540,6 +1541,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->symmetric = true;  // every kind but JointLimitAvoidance (A = w * H scales COLUMNS, quirk Q2) has a symmetric metric
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) h->symmetric = false;
+  if (const char* we = std::getenv("RMP2_PRIO_TAIL")) h->prio_tail = std::atoi(we) & 3;
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // A/B: 0 = general form
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;

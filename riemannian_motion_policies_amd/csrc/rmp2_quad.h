@@ -446,8 +446,9 @@ struct QuadHdr {
   uint32_t dof_ops[3];  // op that owns dof j, 5 bits each, 6 dofs per word (rmp2_quad.h only)
   float cull_c0;        // max over the distance leaves of (metric_modulation_radius + margin): cull threshold
   int32_t strict;       // 1: solve = PINV, the pseudo-inverse on every robot (rmp2_hex.h only; the quad kernel is AUTO)
-  int32_t prio_tail;    // wave priority of the phases after the FK leaves (rmp2_quad.h only): 0 when a SIMD's share of the
-                        // fleet is at most a round or two, 2 when waves keep arriving (see the s_setprio note in the kernel)
+  int32_t prio_tail;    // wave priority of the phases after the frame loop (rmp2_quad.h only): 0; RMP2_PRIO_TAIL pins another
+                        // value for A/B runs (with the kernels of the middle of round 2 a fleet of many rounds preferred 2,
+                        // with the final ones 0 wins at every size: tools/gpu_calls_r02/r02_run33_prio_tail.sh)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -500,13 +501,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #define RMP2_SEG(i) do {} while (0)
 #endif
   RMP2_STAMP();
-  // Wave priority falls as the step progresses (s_setprio 3 through the walk and the first third of the leaf frames, 2 in the
-  // second third, 1 in the last, then 0/2; thirds instead of halves: 52.5 -> 51.5 us at 65 536 robots).  The SIMD's arbiter otherwise serves its
-  // oldest wave first: waves that started together finish staggered and the last one runs alone, at a fraction of the
-  // issue rate.  With the lagging wave preferred they finish together: 68.5 -> 66.9 us at 65 536 robots (two rounds of
-  // two waves), 51.5 -> 49.1 at 49 152 (one round of three), 73.0 -> 68.5 for the 128-register build.  When a SIMD owes
-  // many rounds the serial tail (identity leaves, resolve) goes back to priority 2 instead of 0, so that a wave about to
-  // free its slot is not starved by the newcomers: 237.2 -> 234.4 us at 262 144 (0 there costs +1.4 %).
+  // Wave priority falls as the step progresses: s_setprio 3 through the walk and the first third of the leaf frames, 2 in
+  // the second third, 1 in the last, 0 after the frame loop (hdr.prio_tail).  The SIMD's arbiter otherwise serves its oldest
+  // wave first: waves that started together finish staggered and the last one runs alone, at a fraction of the issue
+  // rate.  With the lagging wave preferred they finish together (measured when it was introduced: 68.5 -> 66.9 us at
+  // 65 536 robots with two rounds of two waves, 51.5 -> 49.1 at 49 152 with one round of three, 73.0 -> 68.5 for the
+  // 128-register build; thirds instead of halves of the frame loop: another 52.5 -> 51.5).
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int sub = lane & 3;
@@ -974,7 +974,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     constexpr bool sym = SYM;
     if (!sym) mirror();
 
-    if (hdr.prio_tail) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    switch (hdr.prio_tail) {  // (s_setprio takes an immediate)
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
     RMP2_STAMP();  // 3: FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
     for (int li = 0; li < n_id; ++li) {
