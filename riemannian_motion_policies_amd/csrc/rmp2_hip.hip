@@ -1239,9 +1239,9 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
   // divide into rounds.  With b = waves owed per SIMD (profiles/r02_quad_minw_ab.txt, us per step at the end of round 2):
   //       b     1.5    2    2.5    3    3.5    4     5     6     8     12     16
-  //   2 waves  34.4  34.3  58.8  59.0  64.8  64.9  87.5  98.4  129.8  192.7  257.1
-  //   3 waves  35.9  36.2  41.5  42.2  65.0  65.3  71.8  82.7  108.0  157.0  205.6
-  //   4 waves  39.2  40.2  45.5  47.2  53.2  54.9  76.9  83.9  105.4  151.9  197.7   (symmetric form)
+  //   2 waves  35.3  35.1  61.7  61.9  66.7  66.9  92.2  98.2  129.7  193.6  259.3
+  //   3 waves  36.2  36.3  40.5  40.9  66.0  66.0  71.7  77.7  107.8  151.6  214.6
+  //   4 waves  38.7  39.4  43.6  45.2  50.2  51.5  79.5  83.6   94.9  139.3  182.4   (symmetric form)
   // two waves for ceil(b) <= 2, three for 3 and wherever four do not divide ceil(b), four where they do.  The 128-register
   // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
   // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
