@@ -358,9 +358,13 @@ def worker(args) -> int:
                 exch.start(local, produced=local_ready)
 
                 def one_step():
-                    bound[exch.finish().data_ptr()]()
-                    exch.consumed(attached=True)
+                    # the gather of the NEXT step's table is issued before this step's kernel: it gets its few workgroups
+                    # while the GPU is between two steps, instead of queueing behind a kernel that fills every SIMD and
+                    # all of LDS (the orderings are unchanged: it waits for the reader fence of the buffer it overwrites)
+                    launch = bound[exch.finish().data_ptr()]
                     exch.start(local, produced=local_ready)
+                    launch()
+                    exch.consumed(attached=True)
         kern = timer.run(one_step, args.steps, args.warmup)
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
