@@ -786,8 +786,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     if (MINW >= 3) asm volatile("" : "+v"(floc));
     int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
-      if (3 * t >= hdr.n_leaf_ops && 3 * (t - 1) < hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(2);
-      if (3 * t >= 2 * hdr.n_leaf_ops && 3 * (t - 1) < 2 * hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
+      if (MINW >= 3) {  // thirds of the frame loop at 3 / 2 / 1
+        if (3 * t >= hdr.n_leaf_ops && 3 * (t - 1) < hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(2);
+        if (3 * t >= 2 * hdr.n_leaf_ops && 3 * (t - 1) < 2 * hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
+      } else {          // two waves per SIMD (and the lone wave of the latency build): halves at 2 / 1 measured better
+        if (t == 0) __builtin_amdgcn_s_setprio(2);
+        if (2 * t == hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
+      }
       int k;
       OpCtl op;
       if (STAGE) {
