@@ -890,6 +890,7 @@ struct rmp2_handle {
   void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
   bool symmetric = false;      // no leaf with a non-symmetric metric (JointLimitAvoidance, quirk Q2) in the set
   int prio_tail = -1;          // env RMP2_PRIO_TAIL=0..3 pins the priority of the phases after the frame loop (A/B only)
+  int quad_latency_blocks = 1024;  // grids up to this many waves take the latency build (env RMP2_QUAD_LATENCY_BLOCKS, A/B only)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
@@ -1246,7 +1247,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
   // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
   // ceil(b) == 4 and three otherwise.
-  const bool latency = blocks <= 1024 && h->goal_floats <= 16;
+  const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
   const bool symk = h->symmetric && N == 9 && !o.capsule;
   int minw = h->quad_minw;
   if (minw == 0) {
@@ -1542,6 +1543,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) h->symmetric = false;
   if (const char* we = std::getenv("RMP2_PRIO_TAIL")) h->prio_tail = std::atoi(we) & 3;
+  if (const char* we = std::getenv("RMP2_QUAD_LATENCY_BLOCKS")) h->quad_latency_blocks = std::atoi(we);
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // A/B: 0 = general form
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
