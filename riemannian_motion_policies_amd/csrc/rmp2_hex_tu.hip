@@ -1,0 +1,83 @@
+// rmp2_hex_tu.hip -- instantiations of the hex mapping (rmp2_hex.h) for ONE template size: compiled once per RMP2_TU_N
+// (2, 9, 16) by __graft_entry__.build_hip.
+#include "rmp2_host.h"
+
+namespace rmp2 {
+namespace {
+
+constexpr size_t kLdsDefault = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
+
+template <int N, int WAVES, bool ROLL>
+void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                  const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  const int per_block = kHexRobots * WAVES;
+  const int blocks = (R + per_block - 1) / per_block;
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds),
+                                        h->has_point);
+  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0,
+                    h->strict ? 1 : 0};
+  const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
+  h->last_kernel = h->strict ? "rmp2_step_hex_kernel (16 lanes per robot, strict pseudo-inverse)"
+                             : "rmp2_step_hex_kernel (16 lanes per robot)";
+#define RMP2_HEX_LAUNCH(CAP, PT)                                                                                          \
+  do {                                                                                                                    \
+    auto kern = rmp2_step_hex_kernel<N, CAP, WAVES, ROLL, PT>;                                                            \
+    if (bytes > kLdsDefault)                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+    RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
+                     ro, R);                                                                                              \
+  } while (0)
+  if (!ROLL && h->has_point)  // attached-point leaves (rollouts refuse them upstream; capsule tables: sphere modes only)
+    RMP2_HEX_LAUNCH(false, true);
+  else if (o.capsule)
+    RMP2_HEX_LAUNCH(true, false);
+  else
+    RMP2_HEX_LAUNCH(false, false);
+#undef RMP2_HEX_LAUNCH
+}
+
+// A launch may ask for up to 64 KiB of dynamic LDS as it is; beyond that (up to the CU's 160 KiB) the function attribute is
+// raised first (launch_hex_w).
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <int N>
+size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds), h->has_point);
+}
+
+// big programs (many frames / leaves) do not fit four waves' working sets into one block's LDS: one wave per
+// block then; if even that does not fit the caller falls back to the quad kernel
+template <int N>
+bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
+  // four-wave blocks while at least two of them fit a CU (the block shares one staged program); one-wave blocks beyond
+  if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit / 2) {
+    if (rollout)
+      launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
+    else
+      launch_hex_w<N, 4, false>(h, q, qd, goal, gs, o, out, ro, R, s);
+    return true;
+  }
+  if (!rollout && hex_bytes<N>(h, o, 1) <= kLdsLimit) {  // (the rollout build exists for four-wave blocks only)
+    launch_hex_w<N, 1, false>(h, q, qd, goal, gs, o, out, ro, R, s);
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+#define RMP2_CAT_(a, b) a##b
+#define RMP2_CAT(a, b) RMP2_CAT_(a, b)
+bool RMP2_CAT(launch_hex_n, RMP2_TU_N)(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                                       const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  return launch_hex<RMP2_TU_N>(h, q, qd, goal, gs, o, out, ro, R, s);
+}
+
+}  // namespace rmp2

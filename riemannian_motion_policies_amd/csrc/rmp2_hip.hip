@@ -18,10 +18,7 @@
 #include <string>
 #include <vector>
 
-#include "rmp2_device.h"
-#include "rmp2_solve.h"
-#include "rmp2_quad.h"
-#include "rmp2_hex.h"
+#include "rmp2_host.h"
 
 using namespace rmp2;
 
@@ -865,46 +862,6 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
-struct rmp2_handle {
-  int device = 0;
-  int n_dof = 0, n_frames = 0, n_slots = 0, n_leaves = 0, goal_floats = 0;
-  int n_slots_full = 0;  // slots of the unpruned program (FK / differentiate entry points)
-  int n_ops_step = 0;    // frames the control-step kernels visit (pruned + folded program)
-  DevProgram* d_prog_full = nullptr;
-  int n_template = 0;  // N of the kernel instantiation
-  bool has_distance = false;
-  bool has_point = false;  // attached-point leaves (CollisionAvoidance): hex and lane-per-robot kernels
-  int n_id_leaves = 0;
-  int n_leaf_ops = 0;
-  uint32_t rev_mask = 0;
-  float cull_c0 = 0.f;  // max over the distance leaves of (metric_modulation_radius + margin): beyond it a pair is culled
-  uint32_t dof_ops[3] = {0u, 0u, 0u};  // op that owns each dof (quad kernel: Jacobian columns come from the frame slots)
-  bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
-  bool likely_singular = false;  // no positive-definite identity leaf in the set
-  int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
-  int hex_levels = 0;
-  int hex_waves = 4;  // waves per block of the hex kernel (env RMP2_HEX_WAVES=1|4, A/B only)
-  int quad_minw = 0;  // register cap of the throughput quad build: 0 = by fleet size (2, 3 or 4 waves per SIMD, launch_quad);
-                      // env RMP2_QUAD_MINW=2|3|4 pins it (A/B only)
-  int n_simd = 1024;  // SIMDs of the device (4 per CU)
-  void* step_fence = nullptr;  // rmp2_set_step_fence: completion fence of the step launches (nullptr: none)
-  bool symmetric = false;      // no leaf with a non-symmetric metric (JointLimitAvoidance, quirk Q2) in the set
-  int prio_tail = -1;          // env RMP2_PRIO_TAIL=0..3 pins the priority of the phases after the frame loop (A/B only)
-  int quad_latency_blocks = 1024;  // grids up to this many waves take the latency build (env RMP2_QUAD_LATENCY_BLOCKS, A/B only)
-  int n_fk_leaves = 0;
-  int hex_is_chain = 0;
-  void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS
-  int hex_blob16 = 0;          // its size in 16-byte units
-  std::vector<int> distance_leaves;
-  DevProgram* d_prog = nullptr;
-  int32_t* d_pair_begin = nullptr;
-  int32_t h_pair_begin[RMP2_MAX_LEAVES + 1];
-  bool pair_begin_valid = false;
-  float* d_scratch = nullptr;  // rmp2_differentiate scratch
-  size_t scratch_robots = 0;
-  mutable const char* last_kernel = "none";  // mapping the last control step / rollout was launched with (rmp2_last_kernel)
-  std::string error;
-};
 
 namespace {
 
@@ -1186,16 +1143,6 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   return RMP2_OK;
 }
 
-// A step launch: plain, or -- when a completion fence is attached to the handle (rmp2_set_step_fence) -- with the
-// fence as the dispatch's own completion signal (hipExtLaunchKernelGGL stop event): no separate packet behind the kernel.
-#define RMP2_STEP_LAUNCH(h_, kern_, grid_, block_, bytes_, stream_, ...)                                            \
-  do {                                                                                                              \
-    if ((h_)->step_fence)                                                                                           \
-      hipExtLaunchKernelGGL(kern_, grid_, block_, bytes_, stream_, nullptr, static_cast<hipEvent_t>((h_)->step_fence), 0, \
-                            __VA_ARGS__);                                                                           \
-    else                                                                                                            \
-      hipLaunchKernelGGL(kern_, grid_, block_, bytes_, stream_, __VA_ARGS__);                                       \
-  } while (0)
 
 template <int N, int SLOTS, bool STRICT>
 void launch_step(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
@@ -1220,128 +1167,6 @@ int dispatch_slots(const rmp2_handle* h, const float* q, const float* qd, const 
     case 2: launch_step<N, 2, STRICT>(h, q, qd, goal, gs, o, out, R, s); return RMP2_OK;
     default: return RMP2_ERR_UNSUPPORTED;
   }
-}
-
-template <int N, int SLOTS>
-void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                 const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
-  const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
-  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
-                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
-                                            sphere_lds_floats(o.capsule, n_sph_lds));
-  const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
-                             sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
-  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
-                    h->prio_tail >= 0 ? h->prio_tail : 0};
-  // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
-  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
-  // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
-  // divide into rounds.  With b = waves owed per SIMD (profiles/r02_quad_minw_ab.txt, us per step at the end of round 2):
-  //       b     1.5    2    2.5    3    3.5    4     5     6     8     12     16
-  //   2 waves  35.3  35.1  61.7  61.9  66.7  66.9  92.2  98.2  129.7  193.6  259.3
-  //   3 waves  36.2  36.3  40.5  40.9  66.0  66.0  71.7  77.7  107.8  151.6  214.6
-  //   4 waves  38.7  39.4  43.6  45.2  50.2  51.5  79.5  83.6   94.9  139.3  182.4   (symmetric form)
-  // two waves for ceil(b) <= 2, three for 3 and wherever four do not divide ceil(b), four where they do.  The 128-register
-  // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
-  // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
-  // ceil(b) == 4 and three otherwise.
-  const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
-  const bool symk = h->symmetric && N == 9 && !o.capsule;
-  int minw = h->quad_minw;
-  if (minw == 0) {
-    const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
-    if (bc <= 2) minw = 2;
-    else if (bc == 3) minw = 3;
-    else if (bc % 4 == 0) minw = symk ? 4 : (bc == 4 ? 2 : 3);
-    else minw = 3;
-  }
-  const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
-  h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
-#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM)                                                                         \
-  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM>), dim3(blocks), dim3(kWave), bytes, s,    \
-                   h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
-  // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
-  // template with sphere tables (symk above); everything else takes the general form
-#define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \
-  do {                                                                                                                  \
-    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false);                                                          \
-    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9));                                                      \
-    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false);                                                                   \
-  } while (0)
-  if (latency) RMP2_QUAD_BY_CAP(1, true);
-  else if (minw == 4) RMP2_QUAD_BY_CAP(4, false);  // 128 registers, four waves per SIMD
-  else if (minw == 3) RMP2_QUAD_BY_CAP(3, false);  // 168 registers, three waves per SIMD
-  else RMP2_QUAD_BY_CAP(2, false);
-#undef RMP2_QUAD_BY_CAP
-#undef RMP2_QUAD_LAUNCH
-}
-
-constexpr size_t kLdsDefault = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
-
-template <int N, int WAVES, bool ROLL>
-void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                  const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
-  const int per_block = kHexRobots * WAVES;
-  const int blocks = (R + per_block - 1) / per_block;
-  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
-                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  const size_t bytes = hex_lds_bytes<N>(WAVES, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds),
-                                        h->has_point);
-  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0,
-                    h->strict ? 1 : 0};
-  const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
-  h->last_kernel = h->strict ? "rmp2_step_hex_kernel (16 lanes per robot, strict pseudo-inverse)"
-                             : "rmp2_step_hex_kernel (16 lanes per robot)";
-#define RMP2_HEX_LAUNCH(CAP, PT)                                                                                          \
-  do {                                                                                                                    \
-    auto kern = rmp2_step_hex_kernel<N, CAP, WAVES, ROLL, PT>;                                                            \
-    if (bytes > kLdsDefault)                                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-    RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
-                     ro, R);                                                                                              \
-  } while (0)
-  if (!ROLL && h->has_point)  // attached-point leaves (rollouts refuse them upstream; capsule tables: sphere modes only)
-    RMP2_HEX_LAUNCH(false, true);
-  else if (o.capsule)
-    RMP2_HEX_LAUNCH(true, false);
-  else
-    RMP2_HEX_LAUNCH(false, false);
-#undef RMP2_HEX_LAUNCH
-}
-
-// A launch may ask for up to 64 KiB of dynamic LDS as it is; beyond that (up to the CU's 160 KiB) the function attribute is
-// raised first (launch_hex_w).
-constexpr size_t kLdsLimit = 160 * 1024;
-
-template <int N>
-size_t hex_bytes(const rmp2_handle* h, const ObsArgs& o, int waves) {
-  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
-                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
-  return hex_lds_bytes<N>(waves, h->n_ops_step, h->hex_blob16, sphere_lds_floats(o.capsule, n_sph_lds), h->has_point);
-}
-
-// big programs (many frames / leaves) do not fit four waves' working sets into one block's LDS: one wave per
-// block then; if even that does not fit the caller falls back to the quad kernel
-template <int N>
-bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
-                const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
-  const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
-  // four-wave blocks while at least two of them fit a CU (the block shares one staged program); one-wave blocks beyond
-  if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit / 2) {
-    if (rollout)
-      launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
-    else
-      launch_hex_w<N, 4, false>(h, q, qd, goal, gs, o, out, ro, R, s);
-    return true;
-  }
-  if (!rollout && hex_bytes<N>(h, o, 1) <= kLdsLimit) {  // (the rollout build exists for four-wave blocks only)
-    launch_hex_w<N, 1, false>(h, q, qd, goal, gs, o, out, ro, R, s);
-    return true;
-  }
-  return false;
 }
 
 template <int N>
@@ -1383,15 +1208,15 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // sphere lists: hex 16.9 us, quad 36.5).
   const int hex_max = (h->has_point || N == 2) ? 20480 : 8192;
   if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= hex_max)) &&
-      launch_hex<N>(h, q, qd, goal, gs, o, out, ro, R, s))
+      (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && R > 32768));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
-    case 0: launch_quad<N, 0>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
-    case 1: launch_quad<N, 1>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
-    case 2: launch_quad<N, 2>(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
+    case 0: (N == 2 ? launch_quad_n2_s0 : launch_quad_n9_s0)(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
+    case 1: (N == 2 ? launch_quad_n2_s1 : launch_quad_n9_s1)(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
+    case 2: (N == 2 ? launch_quad_n2_s2 : launch_quad_n9_s2)(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;
     default: return RMP2_ERR_UNSUPPORTED;
   }
 }
@@ -1705,7 +1530,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   else if (h->n_template == 9)
     rc = dispatch_solve<9>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
   else  // 10 .. 16 dofs: hex mapping at every fleet size
-    rc = launch_hex<16>(h, q, qd, goal, goal_stride, o, oa, ro, R, s) ? RMP2_OK : RMP2_ERR_UNSUPPORTED;
+    rc = launch_hex_n16(h, q, qd, goal, goal_stride, o, oa, ro, R, s) ? RMP2_OK : RMP2_ERR_UNSUPPORTED;
   if (rc != RMP2_OK) return fail(h, rc, "no kernel instantiation for this robot");
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;

@@ -1,0 +1,74 @@
+// rmp2_quad_tu.hip -- instantiations of the quad mapping (rmp2_quad.h) for ONE template size and slot count:
+// compiled once per (RMP2_TU_N, RMP2_TU_SLOTS) pair by __graft_entry__.build_hip, e.g. -DRMP2_TU_N=9 -DRMP2_TU_SLOTS=1.
+#include "rmp2_host.h"
+
+namespace rmp2 {
+namespace {
+
+template <int N, int SLOTS>
+void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+                 const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  const int blocks = (R + kRobotsPerWave - 1) / kRobotsPerWave;
+  const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
+                            ? std::min(o.n_spheres, kLdsSpheres) : 0;
+  const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
+                                            sphere_lds_floats(o.capsule, n_sph_lds));
+  const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
+                             sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
+  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
+                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
+                    h->prio_tail >= 0 ? h->prio_tail : 0};
+  // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
+  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
+  // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
+  // divide into rounds.  With b = waves owed per SIMD (profiles/r02_quad_minw_ab.txt, us per step at the end of round 2):
+  //       b     1.5    2    2.5    3    3.5    4     5     6     8     12     16
+  //   2 waves  35.3  35.1  61.7  61.9  66.7  66.9  92.2  98.2  129.7  193.6  259.3
+  //   3 waves  36.2  36.3  40.5  40.9  66.0  66.0  71.7  77.7  107.8  151.6  214.6
+  //   4 waves  38.7  39.4  43.6  45.2  50.2  51.5  79.5  83.6   94.9  139.3  182.4   (symmetric form)
+  // two waves for ceil(b) <= 2, three for 3 and wherever four do not divide ceil(b), four where they do.  The 128-register
+  // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
+  // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
+  // ceil(b) == 4 and three otherwise.
+  const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
+  const bool symk = h->symmetric && N == 9 && !o.capsule;
+  int minw = h->quad_minw;
+  if (minw == 0) {
+    const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
+    if (bc <= 2) minw = 2;
+    else if (bc == 3) minw = 3;
+    else if (bc % 4 == 0) minw = symk ? 4 : (bc == 4 ? 2 : 3);
+    else minw = 3;
+  }
+  const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
+  h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
+#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM)                                                                         \
+  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM>), dim3(blocks), dim3(kWave), bytes, s,    \
+                   h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
+  // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
+  // template with sphere tables (symk above); everything else takes the general form
+#define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \
+  do {                                                                                                                  \
+    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false);                                                          \
+    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9));                                                      \
+    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false);                                                                   \
+  } while (0)
+  if (latency) RMP2_QUAD_BY_CAP(1, true);
+  else if (minw == 4) RMP2_QUAD_BY_CAP(4, false);  // 128 registers, four waves per SIMD
+  else if (minw == 3) RMP2_QUAD_BY_CAP(3, false);  // 168 registers, three waves per SIMD
+  else RMP2_QUAD_BY_CAP(2, false);
+#undef RMP2_QUAD_BY_CAP
+#undef RMP2_QUAD_LAUNCH
+}
+
+}  // namespace
+
+#define RMP2_CAT_(a, b, c, d) a##b##c##d
+#define RMP2_CAT(a, b, c, d) RMP2_CAT_(a, b, c, d)
+bool RMP2_CAT(launch_quad_n, RMP2_TU_N, _s, RMP2_TU_SLOTS)(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs,
+                                                            const ObsArgs& o, const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
+  launch_quad<RMP2_TU_N, RMP2_TU_SLOTS>(h, q, qd, goal, gs, o, out, ro, R, s);
+  return true;
+}
+
+}  // namespace rmp2

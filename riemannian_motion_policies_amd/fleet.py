@@ -62,6 +62,22 @@ class _Fence:
             pass
 
 
+class _SystemFence:
+    """Stream fence WITH the system-scope release / acquire of a default HIP event (torch.cuda.Event), same interface as
+    _Fence.  What the consumer of an all-gathered table needs at world > 1: the table is written by PEER GPUs over xGMI,
+    past this GPU's L2, and a device-scope fence would let the next kernel read lines its L2 still holds from two steps
+    ago (round-2 advisor finding)."""
+
+    def __init__(self, device: torch.device):
+        self._ev = torch.cuda.Event()
+
+    def record(self, stream: "torch.cuda.Stream") -> None:
+        self._ev.record(stream)
+
+    def wait(self, stream: "torch.cuda.Stream") -> None:
+        stream.wait_event(self._ev)
+
+
 class ObstacleExchange:
     """All-gather of the per-rank slices of the shared sphere table [K, 4] (RCCL, side stream).
 
@@ -86,7 +102,11 @@ class ObstacleExchange:
         self.side = torch.cuda.Stream(self.device) if cuda else None
         # (fences, not torch events: a default event between two step kernels costs ~7 us of the step, see _Fence)
         fences = cuda and self.collective
-        self.ready = [_Fence(self.device) for _ in range(2)] if fences else None
+        # ready[b]: "table b has been gathered".  At world 1 the gather is a local copy and a device-scope fence orders it;
+        # at world > 1 peers wrote the table over xGMI, so the consumer needs the system-scope release / acquire of a
+        # default event (the write-after-read side below, reader_done, orders work of THIS GPU only and keeps the cheap fence)
+        ready_cls = _Fence if self.world == 1 else _SystemFence
+        self.ready = [ready_cls(self.device) for _ in range(2)] if fences else None
         self.reader_done = [None, None]   # fence after the last kernel that read buffer b
         self._reader_events = [_Fence(self.device) for _ in range(2)] if fences else None
         self._next, self._pending, self._last = 0, [], None
@@ -101,11 +121,11 @@ class ObstacleExchange:
         is valid (default: everything issued so far on the current stream).  With a process group the collective
         is issued even for one rank (the RCCL path is then the one exercised on a one-GPU box); without one the
         slice is the table."""
+        if len(self._pending) >= 2:   # (checked before anything is mutated: a caller may catch this and finish())
+            raise RuntimeError("ObstacleExchange has two table buffers: finish() a gather before starting a third")
         b = self._next
         self._next ^= 1
         self._pending.append(b)
-        if len(self._pending) > 2:
-            raise RuntimeError("ObstacleExchange has two table buffers: finish() a gather before starting a third")
         if not self.collective:
             self.tables[b].copy_(local)
             return
@@ -201,26 +221,72 @@ class MixedFleet:
 
 class MixedFleetShard:
     """One rank's shard of BASELINE config 5 across `world` GPUs: the fleet is stably partitioned by robot
-    TYPE (wavefronts stay type-homogeneous), then cut into `world` contiguous shards so that the estimated WORK -- the
-    per-robot flops of SURVEY 8(d): a base term per type plus 240 flops per (control point, obstacle) pair -- is
-    balanced, not the robot count.  A shard therefore holds robots of one type or, where a cut falls inside a type's
-    range, of two; it drives one engine per type present.  Robots are independent: no data-path collective."""
+    TYPE (wavefronts stay type-homogeneous), then cut into `world` contiguous shards so that the estimated COST is
+    balanced, not the robot count.  The cost of a robot is `per_robot[type] + per_pair[type] x pairs` in NANOSECONDS OF
+    KERNEL TIME, calibrated from short timed launches of each type's engine (calibrate_costs below; round 2 weighed by
+    the flop model of SURVEY 8(d), 1 : 2.9 TwoJoint : Panda, where the measured per-robot times are 1 : 1.7 -- the
+    TwoJoint ranks would have been the stragglers).  A shard holds robots of one type or, where a cut falls inside a
+    type's range, of two; it drives one engine per type present.  Robots are independent: no data-path collective."""
 
-    BASE_FLOPS = {"two_joint": 0.5e3, "panda": 4.0e3}      # BASELINE.md section 3, config 5
+    BASE_FLOPS = {"two_joint": 0.5e3, "panda": 4.0e3}      # BASELINE.md section 3, config 5 (roofline accounting only)
     CONTROL_POINTS = {"two_joint": 3, "panda": 8}
     BYTES = {"two_joint": 36, "panda": 120}
+    # ns of kernel time per robot and per (control point, obstacle) pair at throughput fleet sizes on one MI355X
+    # (profiles/r03_cost_calibration.json, tools/calibrate_costs.py).  Every rank must cut with the SAME numbers: a
+    # caller that re-calibrates at run time measures on rank 0 and broadcasts (bench.py does).
+    DEFAULT_COST = {"two_joint": (0.55, 0.0160), "panda": (0.95, 0.0098)}
 
     @staticmethod
-    def plan(total: int, world: int, counts):
-        """counts[r] = obstacles robot r sees, in TYPE-SORTED order (first total // 2 robots: TwoJoint, rest: Panda).
-        Returns (cuts, ranges): cuts = world + 1 indices into the sorted fleet; ranges[rank] = {type: (lo, hi)} in
-        per-type robot numbering."""
+    def calibrate_costs(device: int, robots: int = 16384, seed: int = 5, steps: int = 200):
+        """Measure {type: (ns per robot, ns per pair)} on `device`: each type's engine at `robots` robots with every robot
+        seeing 0 obstacles and all K of them (two timed launches per type; the kernel's time is linear in the pair count
+        between those, and near-linear in the robot count at throughput sizes)."""
         import numpy as np
+        from . import configs as Cf
+        from .engine import Engine
+        dev = torch.device("cuda", device)
+        K = Cf.N_SPHERES
+        out = {}
+        for key, builder, sampler in (("two_joint", Cf.config5_two_joint, Cf.sample_two_joint_states),
+                                      ("panda", Cf.config3, Cf.sample_panda_states)):
+            _, desc = builder("auto")
+            eng = Engine(desc, device)
+            st = sampler(np.random.default_rng([seed, 99]), robots)
+            q, qd, goal = (torch.from_numpy(st[x]).to(dev) for x in ("q", "qd", "goal"))
+            sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng([seed, 0 if key == "two_joint" else robots]))).to(dev)
+            times = []
+            for k in (0, K):
+                off = torch.arange(robots + 1, dtype=torch.int32) * k
+                idx = torch.arange(K, dtype=torch.int32).repeat(robots)[: robots * k] if k else torch.zeros(1, dtype=torch.int32)
+                obs = eng.obstacles(spheres=sph, csr_offset=off, csr_index=idx)
+                launch, _ = eng.bind(q, qd, goal, obstacles=obs)
+                for _ in range(20):
+                    launch()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(steps):
+                    launch()
+                b.record()
+                torch.cuda.synchronize(dev)
+                times.append(a.elapsed_time(b) * 1e6 / steps)   # ns per launch
+            per_robot = times[0] / robots
+            per_pair = max(times[1] - times[0], 0.0) / (robots * K * MixedFleetShard.CONTROL_POINTS[key])
+            out[key] = (per_robot, per_pair)
+        return out
+
+    @staticmethod
+    def plan(total: int, world: int, counts, cost=None):
+        """counts[r] = obstacles robot r sees, in TYPE-SORTED order (first total // 2 robots: TwoJoint, rest: Panda).
+        cost = {type: (ns per robot, ns per pair)} (default: DEFAULT_COST).
+        Returns (cuts, ranges, work): cuts = world + 1 indices into the sorted fleet; ranges[rank] = {type: (lo, hi)} in
+        per-type robot numbering; work[r] = estimated ns of robot r."""
+        import numpy as np
+        cost = cost or MixedFleetShard.DEFAULT_COST
         counts = np.asarray(counts)
         n_tj = total // 2
         is_tj = np.arange(total) < n_tj
-        work = np.where(is_tj, MixedFleetShard.BASE_FLOPS["two_joint"], MixedFleetShard.BASE_FLOPS["panda"]) + \
-            240.0 * np.where(is_tj, 3, 8) * counts
+        (a_tj, b_tj), (a_pd, b_pd) = cost["two_joint"], cost["panda"]
+        work = np.where(is_tj, a_tj, a_pd) + np.where(is_tj, 3 * b_tj, 8 * b_pd) * counts
         cuts = balanced_bounds(work, world)
         ranges = []
         for r in range(world):
@@ -230,15 +296,15 @@ class MixedFleetShard:
         return cuts, ranges, work
 
     @classmethod
-    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto"):
+    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None):
         """Synthetic config-5 fleet of `total` robots (k_r ~ U{0..32} as CSR lists into the type's
-        shared sphere table); builds only this rank's shard."""
+        shared sphere table); builds only this rank's shard.  `cost`: see plan()."""
         import numpy as np
         from . import configs as Cf
         from .engine import Engine
         rng = np.random.default_rng(seed)
         counts = rng.integers(0, Cf.N_SPHERES + 1, size=total)
-        _, ranges, work = cls.plan(total, world, counts)
+        _, ranges, work = cls.plan(total, world, counts, cost)
         n_tj = total // 2
         self = cls()
         self.parts = {}
