@@ -46,6 +46,9 @@ WORKLOADS = {
                     name="Franka Panda, target + joint-limit + damping, 4096 robots/GPU (BASELINE configs[1])"),
     "config3": dict(robots=65536, bytes=120, flops=66.0e3,
                     name="Franka Panda cluttered: 8 control points x 32 shared spheres, 65536 robots/GPU (BASELINE configs[2])"),
+    "config3b": dict(robots=65536, bytes=6264, flops=66.0e3, bound="hbm",
+                     name="Franka Panda cluttered, interface B: 256 explicit closest-point pairs per robot (p_link, p_obs "
+                          "[R, 256, 3], the reference's Datamanager layout), 65536 robots/GPU (BASELINE.md section 3 row 3-B)"),
     "config4": dict(robots=65536, bytes=120, flops=66.0e3,
                     name="Franka Panda cluttered, 65536 robots/GPU, sphere table sharded over the ranks and "
                          "all-gathered over RCCL every step (BASELINE configs[3])"),
@@ -152,10 +155,45 @@ def cpu_baseline(workload: str, desc, table, s, spheres):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def _visible_filter(n: int) -> int:
+    """Apply HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (comma lists; an empty value hides all)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+def count_gpus_without_hip() -> int:
+    """GPUs of this node WITHOUT initialising HIP in this process: the KFD topology in sysfs (nodes with simd_count > 0 are
+    GPUs; CPUs have 0), filtered by the *_VISIBLE_DEVICES variables.  torch.cuda.device_count() is NOT used here: it only
+    stays clear of the runtime while amdsmi initialises; otherwise it falls back to hipGetDeviceCount, and a process that
+    holds a HIP context must not fork + exec children on this pool.  If sysfs is unreadable a throw-away child counts."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        for path in nodes:
+            try:
+                props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except Exception:
+                pass
+        return _visible_filter(n)
+    try:   # a fresh child may initialise whatever it likes; this process stays clean
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+        return int(out[-1]) if out else 0
+    except Exception:
+        return 0
+
+
 def spawn_ranks(args) -> int:
-    """--gpus N without a launcher: start N fresh ranks (this process has not touched a GPU and never will)."""
-    import torch  # device_count() does not initialise the GPU runtime
-    have = torch.cuda.device_count()
+    """--gpus N without a launcher: start N fresh ranks.  This process never initialises HIP (see count_gpus_without_hip):
+    it only counts devices through sysfs, builds the library with hipcc and waits for its children."""
+    have = count_gpus_without_hip()
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} HIP device(s); "
               f"not silently running on fewer", file=sys.stderr)
@@ -238,27 +276,251 @@ class Timed:
                     host_issue_ms_per_step=t_host / steps * 1e3)
 
 
-def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs, traffic):
+def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs, workload, R, bound="valu"):
+    """Top level = the BINDING roof of the dominant kernel (`bound`); the other roof is nested.  `achieved` is ALGORITHMIC
+    work per second of kernel time: for the flop count that is the UN-CULLED count of SURVEY 8(d)
+    (all 256 pairs of a robot), which the culling kernel does not execute -- `executed` says what the silicon did."""
     ach_bw = per_launch_bytes / (kern["kernel_ms"] * 1e-3)
     ach_fl = per_launch_flops / (kern["kernel_ms"] * 1e-3)
-    return {"bound": "hbm", "achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": ach_bw / HBM_PEAK, "traffic": traffic,
-            "kernel": kernel, "kernel_ms": kern["kernel_ms"],
-            "event_group_launches": kern["grp"], "event_group_ms_raw": kern["raw_ms"], "event_pair_ms_empty": kern["floor_ms"],
-            "setup_launches_before_warmup": kern.get("settle", 0),
-            "algorithmic_bytes_per_robot_step": bytes_rs,
-            "valu": {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": ach_fl / VALU_PEAK, "algorithmic_flops_per_robot_step": flops_rs},
-            "binding": "fp32 VALU issue (see DESIGN.md: 120 B per robot-step cannot load HBM; `valu` is the binding roof)"}
+    hbm = {"achieved": ach_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach_bw / HBM_PEAK,
+           "algorithmic_bytes_per_robot_step": bytes_rs}
+    valu = {"achieved": ach_fl / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach_fl / VALU_PEAK,
+            "algorithmic_flops_per_robot_step": flops_rs}
+    traffic, traffic_source = traffic_of(workload, R)
+    top = dict(valu if bound == "valu" else hbm)
+    out = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+           "traffic": traffic, "traffic_source": traffic_source,
+           "kernel": kernel, "kernel_ms": kern["kernel_ms"],
+           "event_group_launches": kern["grp"], "event_group_ms_raw": kern["raw_ms"], "event_pair_ms_empty": kern["floor_ms"],
+           "setup_launches_before_warmup": kern.get("settle", 0),
+           "algorithmic_bytes_per_robot_step": bytes_rs, "algorithmic_flops_per_robot_step": flops_rs,
+           "flops_note": "un-culled algorithmic count (SURVEY 8(d): every (control point, obstacle) pair at 240 flops); the "
+                         "kernel culls out-of-range pairs, whose metric the reference computes as exactly 0 -- see `executed`",
+           "hbm" if bound == "valu" else "valu": hbm if bound == "valu" else valu,
+           "binding": ("fp32 VALU issue: 120 B per robot-step cannot load HBM (DESIGN.md section 5)" if bound == "valu" else
+                       "HBM: the explicit closest-point pairs are 24 B each, read once per step")}
+    ex = executed_of(workload, R)
+    if ex is not None:
+        out["executed"] = ex
+    return out
+
+
+def _stored(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def _current_kernel_hash():
+    try:
+        import __graft_entry__ as ge
+        return ge.kernel_src_hash()
+    except Exception:
+        return None
 
 
 def traffic_of(workload, R):
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
-    try:
-        tj = json.load(open(tpath))
-        return tj.get("hbm_bytes_per_launch") if tj.get("robots") == R else None
-    except Exception:
+    """HBM bytes per launch from the PMC passes (tools/pmc_traffic.py -> profiles/traffic_<workload>.json).  A stored figure
+    is quoted only for the kernels it was measured on: the file records the hash of the kernel sources, and a mismatch (or a
+    different fleet size) prints null together with the reason."""
+    name = f"traffic_{workload}.json"
+    tj = _stored(name)
+    if tj is None:
+        return None, {"file": None, "note": "no PMC measurement stored for this workload"}
+    src = {"file": "profiles/" + name, "measured_at_commit": tj.get("commit"), "kernel_src_hash": tj.get("kernel_src_hash"),
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes around this command, gfx950 correction applied; "
+                  "read from the stored file, not measured in this run"}
+    if tj.get("robots") != R:
+        src["note"] = f"stored measurement is for {tj.get('robots')} robots, this run has {R}: not quoted"
+        return None, src
+    cur = _current_kernel_hash()
+    if tj.get("kernel_src_hash") is None or cur is None or tj["kernel_src_hash"] != cur:
+        src["note"] = "kernel sources changed since the counters were collected (hash mismatch): not quoted"
+        src["current_kernel_src_hash"] = cur
+        return None, src
+    return tj.get("hbm_bytes_per_launch"), src
+
+
+def executed_of(workload, R):
+    """What the kernel executed, from tracked counter / stamp runs (profiles/executed_<workload>.json): the share of the
+    pairs that are in range, VALU instructions per wave, issue-slot occupancy."""
+    ej = _stored(f"executed_{workload}.json")
+    if ej is None or ej.get("robots") != R:
         return None
+    cur = _current_kernel_hash()
+    ej = dict(ej)
+    ej["stale"] = not (ej.get("kernel_src_hash") is not None and ej.get("kernel_src_hash") == cur)
+    return ej
+
+
+def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=None, exch=None):
+    """Engine + bound launch of configs 2 / 3 / 3b / 4 on this rank's shard.  Returns (one_step, eng, desc, table, s, spheres_np,
+    keep): `one_step` issues one control step on the current stream."""
+    import numpy as np
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    from riemannian_motion_policies_amd.fleet import ObstacleExchange
+    table, desc = (Cf.config2 if workload == "config2" else Cf.config3)(args.solve)
+    eng = Engine(desc, local_rank)
+    # synthetic inputs, SURVEY 8(d): seed 1 -> performance inputs (rank-offset so shards differ)
+    sr = rank if seed_rank is None else seed_rank
+    s = Cf.sample_panda_states(np.random.default_rng(1 + 1000 * sr), R)
+    q, qd, goal = (torch.from_numpy(s[k]).to(dev) for k in ("q", "qd", "goal"))
+    out = torch.empty_like(q)
+    keep = [q, qd, goal, out]
+    spheres_np = None
+    if workload == "config2":
+        launch, _ = eng.bind(q, qd, goal, out=out)   # bare C-ABI call on fixed buffers
+        return launch, eng, desc, table, s, None, keep
+    K = Cf.N_SPHERES
+    spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
+    if workload == "config3":
+        obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
+        launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
+        return launch, eng, desc, table, s, spheres_np, keep
+    if workload == "config3b":
+        # interface B (reference-faithful, data_management.py:8-37): explicit closest-point pairs per robot, produced on
+        # the GPU by the closest-point stage from the same sphere table, then read back by the step as [R, 256, 3] arrays
+        tbl = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
+        p_link, p_obs = eng.closest_points(q, tbl)
+        obstacles = eng.obstacles(p_link=p_link, p_obs=p_obs)
+        launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
+        keep += [p_link, p_obs]
+        return launch, eng, desc, table, s, spheres_np, keep
+    # config4
+    if K % world:
+        raise SystemExit("sphere count must divide by the world size")
+    exch = exch or ObstacleExchange(K // world, dev)
+    local = torch.from_numpy(spheres_np[rank * (K // world):(rank + 1) * (K // world)]).to(dev)
+    # all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered (into
+    # the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
+    local_ready = torch.cuda.Event()
+    local_ready.record(torch.cuda.current_stream(dev))
+    # one pre-marshalled launch per table buffer (the exchange alternates between two fixed buffers); each
+    # launch signals "this table has been read" through its own completion (no event packet between steps)
+    bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out,
+                                    done_fence=exch.reader_fence(t))[0]
+             for t in exch.tables}
+    exch.start(local, produced=local_ready)
+
+    def one_step():
+        # the gather of the NEXT step's table is issued before this step's kernel: it gets its few workgroups
+        # while the GPU is between two steps, instead of queueing behind a kernel that fills every SIMD and
+        # all of LDS (the orderings are unchanged: it waits for the reader fence of the buffer it overwrites)
+        launch = bound[exch.finish().data_ptr()]
+        exch.start(local, produced=local_ready)
+        launch()
+        exch.consumed(attached=True)
+    keep += [exch, local, bound]
+    return one_step, eng, desc, table, s, spheres_np, keep
+
+
+def check_against_oracle(desc, s, spheres_np, out, n=256, what="", pairs=None):
+    """Result check of a bench workload (outside every timed region): the first n robots against the CPU oracle.
+    pairs = (p_link, p_obs) device tensors: the oracle reads the same explicit pairs (interface B)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    kw = dict(spheres=spheres_np) if spheres_np is not None else {}
+    if pairs is not None:
+        kw = dict(p_link=pairs[0][:n].cpu().numpy(), p_obs=pairs[1][:n].cpu().numpy())
+    ref = O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], **kw)["qdd64"]
+    got = out[:n].cpu().numpy()
+    err = np.abs(got - ref).max(axis=1)
+    # perf inputs are unrestricted (SURVEY 8(d)): near-contact robots carry |qdd| of 1e2..1e3, where the relative bound applies
+    ok = (err <= 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))) | (err <= 1e-3 * np.abs(ref).max(axis=1))
+    if not (np.isfinite(got).all() and ok.mean() >= 0.97):
+        raise SystemExit(f"bench.py: {what} result check FAILED against the oracle: worst {err.max():.3e}, {(~ok).sum()} of {n} out")
+    return {"robots_checked": int(n), "max_abs_err": float(err.max()), "within_tolerance": int(ok.sum())}
+
+
+def emulate_world(args, workload, dev, local_rank, use_dist):
+    """Single-GPU EMULATION of an N-rank run: build each of the N rank shards one after the other on THIS GPU, time each
+    on its own, and report per-rank time, the maximum, and the throughput N GPUs would reach if each ran its shard at the
+    speed measured here.  Config 5 has no data-path collective, so the slowest shard IS the N-GPU step; config 4's
+    per-rank step carries the RCCL all-gather at world 1 (a lower bound on its latency at world N)."""
+    import gc
+    import numpy as np
+    import torch
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    W = args.emulate_world
+    wl = WORKLOADS[workload]
+    R = args.robots or wl["robots"]
+    steps, warmup = min(args.steps, 500), min(args.warmup, 50)
+    rows, extra = [], {}
+    if workload == "config5":
+        cost = None
+        if args.calibrate:
+            cost = MixedFleetShard.calibrate_costs(local_rank, robots=args.calibrate_robots)
+        extra["cost_model_ns"] = {k: {"per_robot": v[0], "per_pair": v[1]} for k, v in (cost or MixedFleetShard.DEFAULT_COST).items()}
+        extra["cost_model_source"] = "measured in this run (--calibrate)" if cost else "fleet.MixedFleetShard.DEFAULT_COST"
+        plans = {"calibrated": cost or MixedFleetShard.DEFAULT_COST}
+        if args.compare_flop_model:   # the round-2 weights (SURVEY 8(d) flops), for the before / after of the imbalance
+            plans = {"flop_model_round2": {"two_joint": (0.5e3, 240.0), "panda": (4.0e3, 240.0)}, **plans}
+        for pname, c in plans.items():
+            prow = []
+            for r in range(W):
+                shard = MixedFleetShard.synthetic(R * W, W, r, local_rank, seed=5, solve=args.solve, cost=c)
+                k = Timed(dev, False).run(shard.step, steps, warmup)
+                prow.append({"rank": r, "two_joint": shard.n_two_joint, "panda": shard.n_panda,
+                             "us_per_step": k["dt"] / steps * 1e6, "est_cost_us": shard.work / 1e3 if pname == "calibrated" else None,
+                             "kernels": {key: p["engine"].last_kernel() for key, p in shard.parts.items()}})
+                del shard
+                gc.collect()
+                torch.cuda.synchronize(dev)
+            extra.setdefault("plans", {})[pname] = prow
+        rows = extra["plans"]["calibrated"]
+    else:
+        # ONE exchange (one side stream) for all emulated ranks: HIP maps streams onto hardware queues in creation order,
+        # and a fresh side stream per rank lands on the compute stream's queue every few ranks (measured: 156 us steps)
+        from riemannian_motion_policies_amd import configs as Cf
+        from riemannian_motion_policies_amd.fleet import ObstacleExchange
+        exch = ObstacleExchange(Cf.N_SPHERES, dev)
+        for r in range(W):
+            while exch._pending:   # drain the previous rank's outstanding gather
+                exch.finish()
+            one_step, eng, desc, table, s, spheres_np, keep = build_config34(
+                workload, args, dev, local_rank, 0, 1, R, seed_rank=r, exch=exch)
+            k = Timed(dev, use_dist).run(one_step, steps, warmup)
+            chk = check_against_oracle(desc, s, spheres_np, keep[3], what=f"{workload} rank {r}")
+            rows.append({"rank": r, "robots": R, "us_per_step": k["dt"] / steps * 1e6, "kernel_us": k["kernel_ms"] * 1e3,
+                         "kernel": eng.last_kernel(), "result_check": chk})
+            del one_step, eng, keep
+            gc.collect()
+            torch.cuda.synchronize(dev)
+    t = np.array([x["us_per_step"] for x in rows])
+    total = R * W
+    line = {
+        "metric": "RMP2 control steps/sec (batched robots)",
+        "value": total / (t.sum() * 1e-6),
+        "unit": "robot control steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": float(t.sum()) * 1e-3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (leaves, Jacobians, pull-back) + f64 (sum over leaves, resolve)", "data": "synthetic",
+        "config": {"workload": wl["name"], "workload_key": workload, "robots_per_gpu": R, "solve": args.solve,
+                   "parallelism": f"EMULATION on one GPU of a {W}-rank job: the {W} rank shards run one after the other"},
+        "value_note": f"measured: all {W} shards of the {total}-robot fleet on ONE GPU, sequentially",
+        "emulated_scaling": {
+            "label": "PREDICTED from a single-GPU emulation -- not a multi-GPU measurement",
+            "world": W, "total_robots": total, "per_rank": rows,
+            "max_us": float(t.max()), "min_us": float(t.min()), "mean_us": float(t.mean()),
+            "imbalance_max_over_mean": float(t.max() / t.mean()),
+            f"predicted_{W}gpu_steps_per_s": total / (t.max() * 1e-6),
+            "assumes": ("no data-path collective (config 5): the slowest shard is the step" if workload == "config5" else
+                        "per-rank step = kernel + RCCL all-gather measured at world 1: a LOWER bound on the exchange latency "
+                        "at world N (the gather then crosses xGMI)"),
+        },
+    }
+    line["emulated_scaling"].update({k: v for k, v in extra.items() if k != "plans"})
+    if "plans" in extra and len(extra["plans"]) > 1:
+        line["emulated_scaling"]["plans"] = {
+            k: {"per_rank_us": [x["us_per_step"] for x in v], "shards": [[x["two_joint"], x["panda"]] for x in v],
+                "max_us": max(x["us_per_step"] for x in v),
+                "imbalance_max_over_mean": max(x["us_per_step"] for x in v) / (sum(x["us_per_step"] for x in v) / len(v))}
+            for k, v in extra["plans"].items()}
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 def worker(args) -> int:
@@ -286,6 +548,8 @@ def worker(args) -> int:
     workload = args.workload
     if workload == "auto":
         workload = "config3" if world == 1 else "config4"
+    if args.emulate_world and (world != 1 or workload not in ("config4", "config5")):
+        raise SystemExit("--emulate-world N: one GPU (--gpus 1), --workload config4 or config5")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # the process group exists whenever a launcher set RANK (even for one rank: RCCL init, barriers and the MAX-reduce
@@ -315,7 +579,14 @@ def worker(args) -> int:
     if use_dist:
         dist.barrier()
     from riemannian_motion_policies_amd.engine import Engine
-    from riemannian_motion_policies_amd.fleet import MixedFleetShard, ObstacleExchange
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+
+    if args.emulate_world:
+        rc = emulate_world(args, workload, dev, local_rank, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return rc
 
     timer = Timed(dev, use_dist)
     wl = WORKLOADS[workload]
@@ -323,58 +594,35 @@ def worker(args) -> int:
     line_extra = {}
     spheres_np = None
     desc = table = s = None
+    bound = "valu"
 
-    if workload in ("config2", "config3", "config4"):
-        table, desc = (Cf.config2 if workload == "config2" else Cf.config3)(args.solve)
-        eng = Engine(desc, local_rank)
-        # synthetic inputs, SURVEY 8(d): seed 1 -> performance inputs (rank-offset so shards differ)
-        s = Cf.sample_panda_states(np.random.default_rng(1 + 1000 * rank), R)
-        q, qd, goal = (torch.from_numpy(s[k]).to(dev) for k in ("q", "qd", "goal"))
-        out = torch.empty_like(q)
-        if workload == "config2":
-            launch, _ = eng.bind(q, qd, goal, out=out)   # bare C-ABI call on fixed buffers
-            one_step = launch
-        else:
-            K = Cf.N_SPHERES
-            spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
-            if workload == "config3":
-                obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
-                launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
-                one_step = launch
-            else:
-                if K % world:
-                    raise SystemExit("sphere count must divide by the world size")
-                exch = ObstacleExchange(K // world, dev)
-                local = torch.from_numpy(spheres_np[rank * (K // world):(rank + 1) * (K // world)]).to(dev)
-                # all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered (into
-                # the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
-                local_ready = torch.cuda.Event()
-                local_ready.record(torch.cuda.current_stream(dev))
-                # one pre-marshalled launch per table buffer (the exchange alternates between two fixed buffers); each
-                # launch signals "this table has been read" through its own completion (no event packet between steps)
-                bound = {t.data_ptr(): eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=t), out=out,
-                                                done_fence=exch.reader_fence(t))[0]
-                         for t in exch.tables}
-                exch.start(local, produced=local_ready)
-
-                def one_step():
-                    # the gather of the NEXT step's table is issued before this step's kernel: it gets its few workgroups
-                    # while the GPU is between two steps, instead of queueing behind a kernel that fills every SIMD and
-                    # all of LDS (the orderings are unchanged: it waits for the reader fence of the buffer it overwrites)
-                    launch = bound[exch.finish().data_ptr()]
-                    exch.start(local, produced=local_ready)
-                    launch()
-                    exch.consumed(attached=True)
+    if workload in ("config2", "config3", "config3b", "config4"):
+        one_step, eng, desc, table, s, spheres_np, keep = build_config34(workload, args, dev, local_rank, rank, world, R)
         kern = timer.run(one_step, args.steps, args.warmup)
+        # result check, outside the timed region: the buffers the timed steps wrote, against the oracle
+        line_extra["result_check"] = check_against_oracle(desc, s, spheres_np, keep[3], what=workload,
+                                                          pairs=(keep[4], keep[5]) if workload == "config3b" else None)
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
         kernel_name = eng.last_kernel() + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)"
         total_robots = R * world
+        bound = wl.get("bound", "valu")
         parallelism = f"robot-batch split x{world}" + (
             ", RCCL all-gather of the sphere table per step (side stream, double-buffered)" if workload == "config4" else "")
     else:
-        # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, work-balanced cut across the ranks ----
-        shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve)
+        # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, cost-balanced cut across the ranks ----
+        cost = None
+        if args.calibrate:   # rank 0 measures, every rank cuts with the same numbers
+            c = torch.zeros(4, dtype=torch.float64, device=dev)
+            if rank == 0:
+                m = MixedFleetShard.calibrate_costs(local_rank, robots=args.calibrate_robots)
+                c = torch.tensor([*m["two_joint"], *m["panda"]], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.broadcast(c, 0)
+            c = c.tolist()
+            cost = {"two_joint": (c[0], c[1]), "panda": (c[2], c[3])}
+            line_extra["cost_model_ns"] = cost
+        shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve, cost=cost)
         one_step = shard.step
         kern = timer.run(one_step, args.steps, args.warmup)
         # the dominant kernel (the Panda engine's) timed on its own right after the timed region, same buffers
@@ -385,7 +633,7 @@ def worker(args) -> int:
         flops_rs = per_launch_flops / max(shard.dominant_robots, 1)
         kernel_name = shard.dominant_kernel() + " (Panda engine of this rank's shard; timed on its own after the timed region)"
         total_robots = R * world
-        parallelism = (f"type-sorted fleet cut x{world} by estimated work (fleet.balanced_bounds); "
+        parallelism = (f"type-sorted fleet cut x{world} by calibrated per-robot cost (fleet.MixedFleetShard.plan); "
                        "one engine per robot type per rank; no data-path collective")
         counts = torch.tensor([float(shard.n_two_joint), float(shard.n_panda), float(shard.work)], dtype=torch.float64, device=dev)
         if use_dist:
@@ -393,7 +641,7 @@ def worker(args) -> int:
             dist.all_gather(allc, counts)
         else:
             allc = [counts]
-        line_extra["shards"] = [{"two_joint": int(c[0]), "panda": int(c[1]), "est_work_Mflop": float(c[2]) / 1e6} for c in allc]
+        line_extra["shards"] = [{"two_joint": int(c[0]), "panda": int(c[1]), "est_cost_us": float(c[2]) / 1e3} for c in allc]
 
     value = total_robots * args.steps / kern["dt"]
     rc = 0
@@ -415,7 +663,7 @@ def worker(args) -> int:
             "config": {"workload": wl["name"], "workload_key": workload, "robots_per_gpu": R, "solve": args.solve,
                        "parallelism": parallelism},
             "roofline": roofline_obj(kernel_name, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs,
-                                     traffic_of("config3" if workload == "config4" else workload, R)),
+                                     "config3" if workload == "config4" else workload, R, bound),
         }
         line.update(line_extra)
         if workload in ("config3", "config4") and not args.no_secondary:
@@ -432,7 +680,7 @@ def worker(args) -> int:
                 "workload": w2["name"], "robots": 4096, "value": 4096 * 2000 / k2["dt"], "unit": "robot control steps/s",
                 "steps": 2000, "warmup": 200, "ms_per_step": k2["dt"] / 2000 * 1e3, "n_gpus": 1,
                 "roofline": roofline_obj(eng2.last_kernel(), k2, w2["bytes"] * 4096, w2["flops"] * 4096, w2["bytes"], w2["flops"],
-                                         traffic_of("config2", 4096)),
+                                         "config2", 4096, "valu"),
                 "note": "latency regime: 1024 waves on 1024 SIMDs, ~3 us of the launch is dispatch floor (DESIGN.md section 5)"}
         if not args.no_cpu_baseline and world == 1 and desc is not None:
             line["cpu_baseline"] = cpu_baseline(workload, desc, table, s, spheres_np)
@@ -451,6 +699,14 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--robots", type=int, default=0, help="robots per GPU (default: the workload's)")
     ap.add_argument("--solve", default="auto", choices=["auto", "pinv"])
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="config4 / config5 on ONE GPU: build and time each of the N rank shards in turn, report per-rank "
+                         "times and the predicted N-GPU throughput (clearly labelled as an emulation)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="config5: measure the per-type cost model (ns per robot, ns per pair) on rank 0 before cutting the fleet")
+    ap.add_argument("--calibrate-robots", type=int, default=16384)
+    ap.add_argument("--compare-flop-model", action="store_true",
+                    help="--emulate-world with config5: also time the shards the round-2 flop-model weights would cut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()

@@ -476,11 +476,19 @@ __device__ __forceinline__ int uni(int v) {
 
 // SYM = every leaf of the set has a symmetric metric (no JointLimitAvoidance, quirk Q2; decided at rmp2_create): the
 // system stays in block-upper form through the identity leaves and the elimination.
-template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false>
+// OBS = the obstacle mode the instantiation is compiled for (kObsAny: resolved at run time); PLAIN = a single control step
+// without the debug outputs (M, f) and without the rollout loop.  The specialised throughput builds carry none of the
+// other modes' code: no per-lane 64-bit addresses of pair arrays, CSR lists, debug rows or rollout outputs for the
+// compiler to hoist into the prologue and park in scratch (what the 128-register build spilled in round 2).
+constexpr int kObsAny = -1;
+template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, bool PLAIN = false>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
-                      OutArgs out, RolloutArgs ro, int R) {
+                      OutArgs out, RolloutArgs ro_arg, int R) {
+  const int obs_mode = OBS == kObsAny ? obs.mode : OBS;
+  const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr} : ro_arg;
+  if (PLAIN) out.M = nullptr, out.f = nullptr;
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
   // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
@@ -518,7 +526,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
   // ---- stage the q / qd tile (coalesced) and the sphere table in LDS --------------------------
   const int n_ops = hdr.n_ops, n_id = hdr.n_id;
-  const int n_sph_lds = (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES)
+  const int n_sph_lds = (obs_mode == RMP2_OBS_SHARED_SPHERES || obs_mode == RMP2_OBS_RAGGED_SPHERES)
                             ? min(obs.n_spheres, kLdsSpheres) : 0;
   float* const sph_lds_base = lds + QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(n_ops);  // 16-byte aligned
   const uint32_t rev_mask = hdr.rev_mask;
@@ -553,7 +561,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         lds[QuadLds<N>::kQd + rr * N + jj] = 0.f;
       }
     }
-    if (obs.mode == RMP2_OBS_SHARED_SPHERES || obs.mode == RMP2_OBS_RAGGED_SPHERES) {
+    if (obs_mode == RMP2_OBS_SHARED_SPHERES || obs_mode == RMP2_OBS_RAGGED_SPHERES) {
       if (CAP) {
         for (int i = lane; i < 8 * n_sph_lds; i += kWave) sph_lds_base[i] = obs.spheres[i];
       } else {  // image for the culled pair loop: {-2c, |c|^2 - thr^2} records, then the radii
@@ -850,7 +858,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           h[0] = h[1] = h[2] = 0.f;
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
-          if (obs.mode == RMP2_OBS_SHARED_SPHERES) {
+          if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds && !CAP)
 #ifdef RMP2_STAMPS
               pair_loop_culled<false, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
@@ -865,7 +873,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             else
               pair_loop<kPairsSharedGlobal, CAP>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
                                             P3, V3, A3, lh.P, IP, S, h);
-          } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
+          } else if (obs_mode == RMP2_OBS_EXPLICIT_PAIRS) {
             const int lidx = uni<STAGE>(lf.index);
             const int pb = obs.pair_begin[lidx];
             const int count = obs.pair_begin[lidx + 1] - pb;
@@ -1210,7 +1218,31 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (i >= n_dof && j == i) A[m][j] = 1.0;
     }
 
-    if (pass == 0) {
+    if constexpr (N == 2) {
+      // ---- 2-dof robots: the closed-form pseudo-inverse for every robot (rmp2_solve.h) ----------------------------
+      // No elimination and no careful second pass: sets without an inertia leaf (the TwoJoint half of the mixed fleet)
+      // put a few robots per ten thousand on the rank-deficient path, and ONE such robot used to cost its wave a second
+      // trip through the frame loop plus a Jacobi iteration in scratch memory -- the launch waits for its slowest wave
+      // (measured: 13.7 us for a 32 400-robot shard without such a robot, 24 .. 41 us with two or three).
+      double x0, x1;
+      if (n_dof == 2) {
+        status |= pinv_solve_2x2(bcastd<0>(A[0][0]), bcastd<0>(A[0][1]), bcastd<1>(A[0][0]), bcastd<1>(A[0][1]),
+                                 bcastd<0>(fv[0]), bcastd<1>(fv[0]), x0, x1);
+      } else {  // one dof on the 2-dof template: 1 x 1
+        const double a = bcastd<0>(A[0][0]), f0 = bcastd<0>(fv[0]);
+        const bool fin = fabs(a) < 1.7e308 && fabs(f0) < 1.7e308;
+        x0 = !fin ? __builtin_nan("") : (a != 0.0 ? f0 / a : 0.0);
+        x1 = 0.0;
+        if (fin && a == 0.0) status |= RMP2_STATUS_RANK_DROP | RMP2_STATUS_PINV_PATH;
+      }
+      if (!(fabs(x0) < 1.7e308) || !(fabs(x1) < 1.7e308)) status |= RMP2_STATUS_NONFINITE;
+      if (sub == 0) {
+        my_out[0] = (float)x0;
+        if (n_dof > 1) my_out[1] = (float)x1;
+      }
+      flagged = false;
+      break;
+    } else if (pass == 0) {
       // ---- resolve: row-distributed fp64 elimination without row exchanges -------------------
       // (certification and fall-through exactly as lu_solve<N>, rmp2_solve.h)
       double lmax = 0.0;

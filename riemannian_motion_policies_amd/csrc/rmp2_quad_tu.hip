@@ -42,21 +42,43 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
-#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM)                                                                         \
-  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM>), dim3(blocks), dim3(kWave), bytes, s,    \
+#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, PLAIN)                                                             \
+  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, PLAIN>), dim3(blocks), dim3(kWave), bytes, s, \
                    h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
   // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
   // template with sphere tables (symk above); everything else takes the general form
 #define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \
   do {                                                                                                                  \
-    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false);                                                          \
-    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9));                                                      \
-    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false);                                                                   \
+    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false, kObsAny, false);                                          \
+    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9), kObsAny, false);                                      \
+    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false, kObsAny, false);                                                   \
   } while (0)
+  // plain control steps of the throughput builds (no debug outputs, no rollout, sphere primitives): one instantiation per
+  // obstacle mode
+#define RMP2_QUAD_PLAIN_SYM(MINW, SYM)                                                                                  \
+  do {                                                                                                                  \
+    switch (o.mode) {                                                                                                   \
+      case RMP2_OBS_SHARED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_SHARED_SPHERES, true); break;    \
+      case RMP2_OBS_RAGGED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_RAGGED_SPHERES, true); break;    \
+      case RMP2_OBS_EXPLICIT_PAIRS: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_EXPLICIT_PAIRS, true); break;    \
+      default: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_NONE, true); break;                                   \
+    }                                                                                                                   \
+  } while (0)
+#define RMP2_QUAD_PLAIN(MINW)                                                                                           \
+  do {                                                                                                                  \
+    if (symk) RMP2_QUAD_PLAIN_SYM(MINW, (N == 9));                                                                      \
+    else RMP2_QUAD_PLAIN_SYM(MINW, false);                                                                              \
+  } while (0)
+  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !out.f && !o.capsule;
   if (latency) RMP2_QUAD_BY_CAP(1, true);
+  else if (plain && minw == 4) RMP2_QUAD_PLAIN(4);
+  else if (plain && minw == 3) RMP2_QUAD_PLAIN(3);
+  else if (plain) RMP2_QUAD_PLAIN(2);
   else if (minw == 4) RMP2_QUAD_BY_CAP(4, false);  // 128 registers, four waves per SIMD
   else if (minw == 3) RMP2_QUAD_BY_CAP(3, false);  // 168 registers, three waves per SIMD
   else RMP2_QUAD_BY_CAP(2, false);
+#undef RMP2_QUAD_PLAIN
+#undef RMP2_QUAD_PLAIN_SYM
 #undef RMP2_QUAD_BY_CAP
 #undef RMP2_QUAD_LAUNCH
 }

@@ -123,6 +123,48 @@ __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int
   return dropped;
 }
 
+// 2 x 2 systems: x = pinv(M) f in closed form (rmp.py:153-154 with TensorFlow's cutoff 10 * n * eps * sigma_max), for EVERY
+// robot -- no elimination, no flag, no second pass.  sigma_1^2 = (|M|_F^2 + sqrt(|M|_F^4 - 4 det^2)) / 2 and
+// sigma_2 = |det| / sigma_1 (no cancellation); both singular values kept: x = adj(M) f / det (differences formed with
+// Kahan's fma trick); sigma_2 dropped: pinv(M) = M^T / sigma_1^2 up to a relative sigma_2 / sigma_1 <= 4.4e-15.
+// Returns RMP2_STATUS_* bits.
+__device__ __forceinline__ uint32_t pinv_solve_2x2(double a, double b, double c, double d, double f0, double f1,
+                                                   double& x0, double& x1) {
+  auto diff = [](double p, double q, double r, double s) {  // p q - r s, ~1.5 ulp
+    const double w = r * s;
+    const double e = fma(-r, s, w);
+    return fma(p, q, -w) + e;
+  };
+  const double scale = fmax(fmax(fabs(a), fabs(b)), fmax(fabs(c), fabs(d)));
+  if (!(scale < 1.7e308) || !(fabs(f0) < 1.7e308) || !(fabs(f1) < 1.7e308)) {  // NaN / Inf in: NaN out, as the reference's pinv
+    x0 = x1 = __builtin_nan("");
+    return RMP2_STATUS_NONFINITE | RMP2_STATUS_PINV_PATH;
+  }
+  if (!(scale > 0.0)) {
+    x0 = x1 = 0.0;
+    return RMP2_STATUS_RANK_DROP | RMP2_STATUS_PINV_PATH;
+  }
+  const double is = 1.0 / scale;
+  a *= is, b *= is, c *= is, d *= is;  // entries in [-1, 1]: nothing below can overflow; x = pinv(M / s) f / s
+  const double fro2 = fma(a, a, fma(b, b, fma(c, c, d * d)));
+  const double det = diff(a, d, b, c);
+  const double disc = sqrt(fmax(fma(fro2, fro2, -4.0 * det * det), 0.0));
+  const double s1sq = 0.5 * (fro2 + disc);
+  const double s1 = sqrt(s1sq);
+  const double s2 = fabs(det) / s1;
+  const double cutoff = 10.0 * 2.0 * 2.220446049250313e-16 * s1;
+  if (s2 > cutoff) {
+    const double id = is / det;
+    x0 = diff(d, f0, b, f1) * id;
+    x1 = diff(a, f1, c, f0) * id;
+    return 0u;
+  }
+  const double iw = is / s1sq;
+  x0 = fma(a, f0, c * f1) * iw;
+  x1 = fma(b, f0, d * f1) * iw;
+  return RMP2_STATUS_RANK_DROP | RMP2_STATUS_PINV_PATH;
+}
+
 // ---- rare path of the AUTO build (run-time indices, scratch memory, loops not unrolled) ----
 // Gaussian elimination with partial pivoting on a COPY; returns false (x untouched) when a
 // pivot column is below 1e-11 * max|M| -> the caller then takes the pseudo-inverse.

@@ -1,7 +1,11 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) around bench.py into
 profiles/traffic_<workload>.json (HBM bytes per launch of the control-step kernel).
-usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> <robots> <out.json>"""
-import csv, glob, json, statistics, sys
+usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> <robots> <out.json> [commit]
+(the GPU box has no .git: pass the commit the snapshot was taken at, or fill it in afterwards)"""
+import csv, glob, json, os, statistics, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
 def per_launch(d, counter):
     path = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
@@ -18,7 +22,10 @@ out = {"workload": sys.argv[3], "robots": robots, "launches": min(nf, nw),
        "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
        "hbm_bytes_per_launch": (2 * f + w) * 1024.0,
        "hbm_bytes_per_launch_uncorrected": (f + w) * 1024.0,
-       "algorithmic_bytes_per_launch": 120 * robots,
+       "algorithmic_bytes_per_launch": (6264 if sys.argv[3] == "config3b" else 120) * robots,
+       "kernel_src_hash": ge.kernel_src_hash(),
+       "commit": (sys.argv[6] if len(sys.argv) > 6 else
+                  subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None),
        "note": "FETCH_SIZE/WRITE_SIZE from separate --pmc passes, gfx950 correction FETCH x2 (calibrated on this access "
                "pattern); memory-side (fabric) requests, Infinity-Cache hits included"}
 if out["hbm_bytes_per_launch"] > 2 * out["algorithmic_bytes_per_launch"]:
