@@ -463,6 +463,8 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
             prow = []
             for r in range(W):
                 shard = MixedFleetShard.synthetic(R * W, W, r, local_rank, seed=5, solve=args.solve, cost=c)
+                if args.graph:
+                    shard.capture()
                 k = Timed(dev, False).run(shard.step, steps, warmup)
                 prow.append({"rank": r, "two_joint": shard.n_two_joint, "panda": shard.n_panda,
                              "us_per_step": k["dt"] / steps * 1e6, "est_cost_us": shard.work / 1e3 if pname == "calibrated" else None,
@@ -623,6 +625,9 @@ def worker(args) -> int:
             cost = {"two_joint": (c[0], c[1]), "panda": (c[2], c[3])}
             line_extra["cost_model_ns"] = cost
         shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve, cost=cost)
+        # (a HIP graph of the two-stream step replays SLOWER than the eager sequence on this runtime -- 62.1 against 40.3 us per
+        # step, profiles/r03_config5_graph_ab.txt: its cross-stream edges become full barriers -- so eager is the default)
+        line_extra["step_issue"] = "hip graph replay" if (args.graph and shard.capture()) else "eager (<= 6 host calls)"
         one_step = shard.step
         kern = timer.run(one_step, args.steps, args.warmup)
         # the dominant kernel (the Panda engine's) timed on its own right after the timed region, same buffers
@@ -707,6 +712,7 @@ def main():
     ap.add_argument("--calibrate-robots", type=int, default=16384)
     ap.add_argument("--compare-flop-model", action="store_true",
                     help="--emulate-world with config5: also time the shards the round-2 flop-model weights would cut")
+    ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()

@@ -210,6 +210,15 @@ int rmp2_leaf_evaluate(int device, const rmp2_leaf *leaf, int32_t k, const float
  * (and the sanitizer build, tools/asan_compile_program.sh) can exercise without a GPU. */
 int rmp2_validate(const rmp2_desc *desc);
 
+/* Environment variables read by rmp2_create (and by nothing else).  They are DIAGNOSTIC overrides of the per-call kernel
+ * dispatch, used by the parity tests and the profiling tools to force every mapping over the same inputs; all choices
+ * produce the same numbers to fp32 rounding, none is needed for correctness, and an unset variable means "by fleet size":
+ *   RMP2_KERNEL     = hex | quad | lane   mapping of robots to lanes (16 / 4 / 1 lanes per robot)
+ *   RMP2_QUAD_MINW  = 2 | 3 | 4           register cap of the quad mapping's throughput build (waves per SIMD it leaves room for)
+ *   RMP2_QUAD_SYM   = 0                   general (full-matrix) form of the quad mapping for sets that qualify for the symmetric one
+ * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with
+ * -DRMP2_TUNING (tools/); the shipped library ignores them.  A deployment should leave all of them unset. */
+
 /* Build an engine for one robot type + one RMP set on HIP device `device`.
  * Replaces: UrdfForwardKinematic.__init__ tables (kinematics.py:157-209) + the RmpCore
  * registry contents (rmp.py:114-131) as a flat, immutable "program".               */
@@ -237,7 +246,10 @@ int rmp2_fence_wait(void *fence, void *stream);            /* later work on `str
 int rmp2_fence_destroy(void *fence);
 /* Attach `fence` to the handle: every later rmp2_step / rmp2_rollout on `h` signals it when its kernel completes -- the
  * effect of rmp2_fence_record right behind the launch, but carried by the dispatch itself (no extra packet between two
- * steps; ~3 us per step in the exchange loop).  NULL detaches.  A launch with a fence attached is not stream-capturable. */
+ * steps; ~3 us per step in the exchange loop).  NULL detaches.  A launch with a fence attached is not stream-capturable.
+ * While a fence is attached, rmp2_step / rmp2_rollout on that handle carry per-handle state (the attachment): they must
+ * then be issued from ONE thread at a time (handles stay independent of each other).  rmp2_fence_destroy refuses a fence
+ * that is still attached (RMP2_ERR_INVALID_ARGUMENT); rmp2_destroy detaches. */
 int rmp2_set_step_fence(rmp2_handle *h, void *fence);
 
 /* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
@@ -288,7 +300,10 @@ int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R,
  *   x[R][16] = vec(T), xd[R][16] = J qd, J[R][16][n_dof], c[R][16] = Jdot qd.
  * The two differentiate entry points are debug / test entries: they use a per-robot scratch buffer owned by the handle
  * (grown, with a device synchronisation, on the first call at a larger R), so calls on ONE handle must be issued on one
- * stream at a time; rmp2_step / rmp2_rollout / rmp2_forward_kinematics have no such state. */
+ * stream at a time; rmp2_step / rmp2_rollout / rmp2_forward_kinematics have no such state -- except while a step fence is
+ * attached (rmp2_set_step_fence: one issuing thread per handle) and for the cached pair_begin table of EXPLICIT_PAIRS,
+ * which is refreshed on the call's stream when the caller's pair layout changes (keep one layout per handle, or one
+ * stream). */
 int rmp2_differentiate(rmp2_handle *h, const float *q, const float *qd, int32_t frame, float *x, float *xd,
                        float *J, float *c, int32_t R, void *stream);
 

@@ -581,6 +581,37 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   const int n_iters = n_live <= 0 ? 0 : (ROLL ? ro.n_iters : 1);
   // (the plain step's condition below is visibly "at most once": the compiler emits a branch, not a loop -- a run-time
   // trip count costs the step ~3 k cycles of loop-carried state)
+  // ragged lists over a table of at most 64 spheres: the robot's list as a membership mask, built once by its 16 lanes
+  // (rmp2_quad.h, pair_loop_culled<MEMBER>); a list with a repeated or out-of-range index keeps the list walk
+  uint32_t member_lo = 0u, member_hi = 0u;
+  bool use_member = false;
+  if (obs.mode == RMP2_OBS_RAGGED_SPHERES && !CAP && obs.n_spheres <= 64 && n_live > 0) {
+    const int rr_ = live ? robot : 0;
+    const int b0 = obs.csr_offset[rr_];
+    const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
+    int max_count = count;
+#pragma unroll
+    for (int o = 32; o >= kHex; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+    bool bad = false;
+    for (int t = s; t - s < max_count; t += kHex) {  // (wave-uniform trip count)
+      if (t < count) {
+        const int idx = obs.csr_index[b0 + t];
+        bad = bad || idx < 0 || idx >= obs.n_spheres;
+        if (idx >= 0 && idx < 32) member_lo |= 1u << idx;
+        if (idx >= 32 && idx < 64) member_hi |= 1u << (idx - 32);
+      }
+    }
+    member_lo |= dppu<kXor1>(member_lo);
+    member_lo |= dppu<kXor2>(member_lo);
+    member_lo |= dppu<0x141>(member_lo);  // row_half_mirror
+    member_lo |= dppu<0x140>(member_lo);  // row_mirror
+    member_hi |= dppu<kXor1>(member_hi);
+    member_hi |= dppu<kXor2>(member_hi);
+    member_hi |= dppu<0x141>(member_hi);
+    member_hi |= dppu<0x140>(member_hi);
+    bad = bad || (__builtin_popcount(member_lo) + __builtin_popcount(member_hi) != count);
+    use_member = !__any(bad);
+  }
 #pragma nounroll
   for (int it = 0; ROLL ? (it < n_iters) : (it == 0 && n_live > 0); ++it) {
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
@@ -732,6 +763,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
           const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
           pair_loop<kPairsExplicit, false, kHex>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, s, P3,
                                                  V3, A3, lh.P, IP, S, h);
+        } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
+          pair_loop_culled<false, kHex, false, true>(sph_lds_base, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, s, P3, V3, A3,
+                                                     lh.P, IP, S, h, nullptr, member_lo, member_hi);
         } else {
           const int b0 = obs.csr_offset[live ? robot : 0];
           const int count = live ? obs.csr_offset[robot + 1] - b0 : 0;

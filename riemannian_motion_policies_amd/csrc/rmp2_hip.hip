@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -859,6 +861,8 @@ rmp2_leaf_kernel(rmp2_leaf lf, int k, const float* __restrict__ x, const float* 
 // host: handle, program compiler, launches
 // =========================================================================================
 thread_local std::string g_create_error;
+std::mutex g_fence_mutex;                   // guards g_attached_fences
+std::map<void*, int> g_attached_fences;     // fence -> number of handles it is attached to (rmp2_set_step_fence)
 
 }  // namespace
 
@@ -1136,9 +1140,19 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   }
   // the op that owns each dof (its frame's origin is the joint origin o_j, its world axis z_j): 5 bits per dof
   for (int w = 0; w < 3; ++w) P.dof_ops[w] = 0u;
-  for (int k = 0; k < F; ++k)
-    if (P.ops[k].qidx >= 0 && P.ops[k].jtype != RMP2_JOINT_FIXED)
-      P.dof_ops[P.ops[k].qidx / 6] |= (uint32_t)k << (5 * (P.ops[k].qidx % 6));
+  // (one owner per dof: two movable frames on one q_index -- a mimic-style table -- would OR two op indices into the field
+  // and the quad kernel would read the joint record of a third frame; the Jacobian columns assume a single owner anyway)
+  {
+    uint32_t owned = 0u;
+    for (int k = 0; k < F; ++k)
+      if (P.ops[k].qidx >= 0 && P.ops[k].jtype != RMP2_JOINT_FIXED) {
+        if ((owned >> P.ops[k].qidx) & 1u)
+          return err = "q_index " + std::to_string(P.ops[k].qidx) + " is driven by more than one movable joint (mimic joints are not supported)",
+                 RMP2_ERR_UNSUPPORTED;
+        owned |= 1u << P.ops[k].qidx;
+        P.dof_ops[P.ops[k].qidx / 6] |= (uint32_t)k << (5 * (P.ops[k].qidx % 6));
+      }
+  }
   P.n_id_leaves = nid;
   return RMP2_OK;
 }
@@ -1203,10 +1217,13 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //     quad                        13.0   13.6   14.0   13.9   16.8   25.7   31.0   68.5
   //     lane                        19.4   19.4   19.5   19.5   20.3   20.3   21.5   39.4
   // (hex holds two waves per SIMD: beyond 8 192 robots it runs a second round.)  Attached-point leaves exist in the hex
-  // and lane mappings only: those sets keep the older hex / lane cut at 20 480 robots.  So do 2-dof robots, whose hex
-  // step is short enough for the second round not to matter (TwoJoint half of config 5, 16 384 robots with ragged
-  // sphere lists: hex 16.9 us, quad 36.5).
-  const int hex_max = (h->has_point || N == 2) ? 20480 : 8192;
+  // and lane mappings only: those sets keep the older hex / lane cut at 20 480 robots.  2-dof robots used to as well; with
+  // the quad mapping's closed-form 2 x 2 resolve and 80-register builds the cut is the same 8 192 (round 3,
+  // profiles/r03_dispatch_sweep.txt, TwoJoint half of config 5 with ragged lists, us per step):
+  //     R:    4096   8192  12288  16384  20480  32768  65536
+  //     hex    9.0   10.1   12.0   17.1   18.9   27.7   52.5
+  //     quad  11.3   11.9   11.9   12.3   12.2   12.4   15.5
+  const int hex_max = h->has_point ? 20480 : 8192;
   if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= hex_max)) &&
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
@@ -1262,11 +1279,23 @@ int rmp2_fence_wait(void* fence, void* stream) {
 }
 int rmp2_set_step_fence(rmp2_handle* h, void* fence) {
   if (!h) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null handle");
+  std::lock_guard<std::mutex> lock(g_fence_mutex);
+  if (h->step_fence) {
+    auto it = g_attached_fences.find(h->step_fence);
+    if (it != g_attached_fences.end() && --it->second == 0) g_attached_fences.erase(it);
+  }
   h->step_fence = fence;
+  if (fence) ++g_attached_fences[fence];
   return RMP2_OK;
 }
 int rmp2_fence_destroy(void* fence) {
   if (!fence) return RMP2_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_fence_mutex);
+    if (g_attached_fences.count(fence))
+      return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT,
+                  "fence is still attached to a handle (rmp2_set_step_fence): detach it (NULL) or destroy the handle first");
+  }
   return hipEventDestroy(static_cast<hipEvent_t>(fence)) == hipSuccess ? RMP2_OK : fail(nullptr, RMP2_ERR_HIP, "hipEventDestroy failed");
 }
 
@@ -1367,15 +1396,20 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   h->symmetric = true;  // every kind but JointLimitAvoidance (A = w * H scales COLUMNS, quirk Q2) has a symmetric metric
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) h->symmetric = false;
+#ifdef RMP2_TUNING  // A/B knobs of the tuning builds only (tools/): a stray variable must not change a deployment's dispatch
   if (const char* we = std::getenv("RMP2_PRIO_TAIL")) h->prio_tail = std::atoi(we) & 3;
-  if (const char* we = std::getenv("RMP2_QUAD_LATENCY_BLOCKS")) h->quad_latency_blocks = std::atoi(we);
-  if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // A/B: 0 = general form
+  if (const char* we = std::getenv("RMP2_QUAD_LATENCY_BLOCKS")) h->quad_latency_blocks = std::atoi(we), h->quad_latency_set = true;
+#endif
+  if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // 0 = general form (include/rmp2.h)
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
+  h->hex_waves = 4;
+#ifdef RMP2_TUNING
   {
     const char* we = std::getenv("RMP2_HEX_WAVES");
     h->hex_waves = (we && std::atoi(we) == 1) ? 1 : 4;
   }
+#endif
   {
     const char* we = std::getenv("RMP2_QUAD_MINW");
     const int wv = we ? std::atoi(we) : 0;
@@ -1383,6 +1417,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       h->n_simd = 4 * prop.multiProcessorCount;
+    if (!h->quad_latency_set) h->quad_latency_blocks = h->n_simd;  // the latency build serves grids of at most one wave per SIMD
   }
   h->n_fk_leaves = P.n_fk_leaves;
   h->hex_is_chain = P.hex.is_chain;
@@ -1450,6 +1485,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
 
 int rmp2_destroy(rmp2_handle* h) {
   if (!h) return RMP2_OK;
+  rmp2_set_step_fence(h, nullptr);  // (a fence attached to a destroyed handle is free to be destroyed)
   int prev = -1;  // the caller's current device is left as it was
   if (hipGetDevice(&prev) != hipSuccess) prev = -1;
   (void)hipSetDevice(h->device);

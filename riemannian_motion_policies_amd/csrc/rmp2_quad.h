@@ -309,11 +309,16 @@ __device__ __forceinline__ int select_bit(uint32_t m, int r) {
 // RAGGED: positions index the robot's CSR list ci[0 .. count); otherwise positions ARE sphere indices
 // SKIP: leave out the test slots no robot of the wave fills (a wave-uniform branch per slot: pays where waves share a SIMD,
 // costs where a lone wave pays ~28 cycles per branch)
-template <bool RAGGED, int W, bool SKIP = false>
+// MEMBER: the robot sees only the spheres whose bit is set in (member_lo, member_hi) -- a ragged list over a table of at
+// most 64 spheres IS a membership mask: the loop then runs in the dense form (positions are sphere indices read from
+// LDS) and the in-range mask is ANDed with it; no dependent global load of a list entry per test slot and per trip.
+template <bool RAGGED, int W, bool SKIP = false, bool MEMBER = false>
 __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, const int32_t* ci, int count, int max_count,
                                                  int sub, const float P3[3], const float V3[3], const float A3[3],
                                                  const float* P, const float* IP, float S[6], float h[3],
-                                                 unsigned long long* dbg = nullptr) {
+                                                 unsigned long long* dbg = nullptr, uint32_t member_lo = 0u,
+                                                 uint32_t member_hi = 0u) {
+  static_assert(!(RAGGED && MEMBER), "a membership mask replaces the list");
   static_assert(W == 4 || W == 16, "quad or hex");
   const float4* aux = reinterpret_cast<const float4*>(tab);
   const float* rad = tab + 4 * n_tab;
@@ -342,6 +347,7 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       m |= dppu<0x141>(m);  // row_half_mirror
       m |= dppu<0x140>(m);  // row_mirror
     }
+    if (MEMBER) m &= (base == 0 ? member_lo : member_hi);
     // ---- pass 2: lane `sub` evaluates the set bits of rank sub, sub + W, ... ----
     uint32_t rem = m;
     int rank = sub;                      // W == 16: rank of the bit this lane takes next
@@ -606,6 +612,36 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const float* my_goal = !goal ? nullptr : (STAGE ? s_goal + gi * 16 : goal + (size_t)(live ? robot : 0) * goal_stride);
   uint32_t status = 0u;
   bool flagged = false;
+
+  // ---- ragged lists over a small table: the robot's list as a membership mask (built once, by its quad) -----------------
+  // Each lane reads every fourth entry of the robot's list (the wave's 16 lists are contiguous in the CSR array), sets the
+  // bits and the quad ORs them.  A list with a repeated index cannot be a mask (the reference would count that obstacle
+  // twice): such a wave keeps the list walk.
+  uint32_t member_lo = 0u, member_hi = 0u;
+  bool use_member = false;
+  if (obs_mode == RMP2_OBS_RAGGED_SPHERES && !CAP && obs.n_spheres <= 64) {
+    const int rr_ = live ? robot : 0;
+    const int b0 = obs.csr_offset[rr_];
+    const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
+    int max_count = count;
+#pragma unroll
+    for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+    bool bad = false;
+    for (int t = sub; t - sub < max_count; t += kQuad) {  // (wave-uniform trip count)
+      if (t < count) {
+        const int idx = obs.csr_index[b0 + t];
+        bad = bad || idx < 0 || idx >= obs.n_spheres;
+        if (idx >= 0 && idx < 32) member_lo |= 1u << idx;
+        if (idx >= 32 && idx < 64) member_hi |= 1u << (idx - 32);
+      }
+    }
+    member_lo |= dppu<kXor1>(member_lo);
+    member_lo |= dppu<kXor2>(member_lo);
+    member_hi |= dppu<kXor1>(member_hi);
+    member_hi |= dppu<kXor2>(member_hi);
+    bad = bad || (__builtin_popcount(member_lo) + __builtin_popcount(member_hi) != count);
+    use_member = !__any(bad);
+  }
 
 #pragma nounroll
   for (int it = 0; it < ro.n_iters; ++it) {
@@ -880,6 +916,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
             pair_loop<kPairsExplicit, false>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3,
                                       A3, lh.P, IP, S, h);
+          } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
+            pair_loop_culled<false, kQuad, (MINW >= 2), true>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
+                                                             A3, lh.P, IP, S, h, nullptr, member_lo, member_hi);
           } else {
             int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
             if (MINW >= 3) asm volatile("" : "+v"(rr_));

@@ -18,27 +18,24 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
                     h->prio_tail >= 0 ? h->prio_tail : 0};
-  // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all
-  // 512 registers; throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three
-  // or four waves per SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to
-  // divide into rounds.  With b = waves owed per SIMD (profiles/r02_quad_minw_ab.txt, us per step at the end of round 2):
-  //       b     1.5    2    2.5    3    3.5    4     5     6     8     12     16
-  //   2 waves  35.3  35.1  61.7  61.9  66.7  66.9  92.2  98.2  129.7  193.6  259.3
-  //   3 waves  36.2  36.3  40.5  40.9  66.0  66.0  71.7  77.7  107.8  151.6  214.6
-  //   4 waves  38.7  39.4  43.6  45.2  50.2  51.5  79.5  83.6   94.9  139.3  182.4   (symmetric form)
-  // two waves for ceil(b) <= 2, three for 3 and wherever four do not divide ceil(b), four where they do.  The 128-register
-  // build only pays in the symmetric form of the kernel (its elimination keeps 15 instead of 27 doubles per lane: 50 VGPR
-  // spills, none in the hot loops); sets with a JointLimitAvoidance leaf (general form: 118 spills) stay on two waves for
-  // ceil(b) == 4 and three otherwise.
+  // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all 512 registers;
+  // throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three or four waves per
+  // SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to divide into rounds.
+  // With the per-mode plain builds of round 3 (no spills at two and three waves, 16 spilled dwords at four in the
+  // symmetric form) the three-wave build no longer wins anywhere; config 3, us per step (profiles/r03_quad_minw_ab.txt),
+  // b = waves a SIMD owes to the fleet:
+  //       b      1     1.5    2    2.5    3    3.5    4     5     6     8     12     16
+  //   2 waves  30.2  33.6  33.5  37.7  38.1  59.4  60.6  65.9  73.3   99.3  140.2  190.1
+  //   3 waves  30.3  34.6  34.4  38.9  39.2  62.2  63.6  67.9  74.5  102.2  142.7  200.4
+  //   4 waves  30.5  36.2  36.7  40.7  41.5  46.5  50.1  73.3  76.6   90.5  130.3  170.6
+  // two waves up to ceil(b) = 3 and for 5 and 6, four for 4 and from 7 on.  Sets with a JointLimitAvoidance leaf (general
+  // form, 48-56 spilled dwords at 128 registers) keep two waves.
   const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
   const bool symk = h->symmetric && N == 9 && !o.capsule;
   int minw = h->quad_minw;
   if (minw == 0) {
     const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
-    if (bc <= 2) minw = 2;
-    else if (bc == 3) minw = 3;
-    else if (bc % 4 == 0) minw = symk ? 4 : (bc == 4 ? 2 : 3);
-    else minw = 3;
+    minw = (symk && (bc == 4 || bc >= 7)) ? 4 : 2;
   }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";

@@ -355,9 +355,56 @@ class MixedFleetShard:
         return self
 
     _side = None
+    _graph = None
+
+    def capture(self) -> bool:
+        """Record the shard's step (fork, two launches, join) ONCE as a HIP graph; step() then replays it with a single
+        host call.  MEASURED SLOWER on ROCm 7.2 / MI355X than the eager sequence (config 5 at world 1: 62.1 us per step against
+        40.3 eager; host issue time 19.7 against 28.1 us -- the graph's cross-stream edges are executed as full barriers), so
+        nothing calls this by default; kept for A/B runs (bench.py --graph).  Returns False (and keeps the eager step) if the
+        capture fails."""
+        if self._graph is not None:
+            return True
+        try:
+            torch.cuda.synchronize(self._device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                # (the pre-bound launches target the streams they were bound on; the recording issues the same steps on the
+                # capture stream -- and on the side stream forked from it -- through Engine.step)
+                cur = torch.cuda.current_stream(self._device)
+
+                def issue(key, stream):
+                    p = self.parts[key]
+                    q, qd, goal, obs = p["keep"]
+                    p["engine"].step(q, qd, goal, obstacles=obs, out=p["out"], stream=stream.cuda_stream)
+
+                if self._side is None:
+                    for key in self.parts:
+                        issue(key, cur)
+                else:
+                    other = [k for k in self.parts if k != self._dom][0]
+                    self._fork.record(cur)
+                    self._fork.wait(self._side)
+                    issue(other, self._side)
+                    self._join.record(self._side)
+                    issue(self._dom, cur)
+                    self._join.wait(cur)
+            torch.cuda.synchronize(self._device)
+            self._graph = g
+            return True
+        except Exception:
+            self._graph = None
+            return False
 
     def step(self):
-        """One control step of the shard.  With both types present the two kernels overlap: the side stream forks off the
+        """One control step of the shard (graph replay after capture(), else the eager sequence)."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._step_eager()
+
+    def _step_eager(self):
+        """With both types present the two kernels overlap: the side stream forks off the
         current stream (it sees everything enqueued so far, e.g. the simulator's state update) and joins it again."""
         if self._side is None:
             for launch in self._launches:

@@ -315,3 +315,68 @@ def test_symmetric_form_against_the_general_form_and_its_careful_path(torch_mod)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.isfinite(res[0][0]).all()
     assert (res[0][1].cpu().numpy() != 0).all(), "every robot of a rank-deficient set must report the pseudo-inverse path"
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad"])
+@pytest.mark.parametrize("K", [32, 48, 64, 80])
+def test_ragged_lists_as_membership_masks_and_their_fallback(torch_mod, golden_dir, kernel, K):
+    """Ragged obstacle lists over a table of K <= 64 spheres run as a 32/64-bit membership mask (pair_loop_culled<MEMBER>,
+    no list walk in the frame loop); K > 64 keeps the CSR walk; a list that repeats an index cannot be a mask -- the
+    reference would count that obstacle twice -- and must take the list walk too.  All against the oracle's list walk."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    _, desc = Cf.config3()
+    eng = _engine(desc, kernel)
+    R = g["q"].shape[0]
+    rng = np.random.default_rng(100 + K)
+    sph = np.concatenate([g["spheres"], Cf.sample_spheres(rng, 64)])[:K]
+    sph[32:, :2] *= np.float32(1.6)    # the extra spheres stand further out
+    # parity is stated for states with >= 0.05 m of clearance (DESIGN.md section 2): robots an extra sphere comes closer to
+    # carry |qdd| of 1e2 and more, where fp32 rounding alone exceeds the bound
+    d = np.linalg.norm(g["origins"][:, :, None, :] - sph[None, None, :, :3], axis=-1) - sph[None, None, :, 3]
+    clear = d.min(axis=(1, 2)) >= 0.05
+    assert clear.sum() >= R // 2
+    off, idx = Cf.sample_ragged(rng, R, K)
+    q, qd, goal = (torch.from_numpy(g[k]) for k in ("q", "qd", "goal"))
+    for dup in (False, True):
+        idx2 = idx.copy()
+        if dup:   # robot 5 lists its first obstacle twice (same list length: the last entry is overwritten)
+            a, b = off[5], off[6]
+            if b - a >= 2:
+                idx2[b - 1] = idx2[a]
+        obs = eng.obstacles(spheres=torch.from_numpy(sph), csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx2))
+        ref = O.step(desc, g["q"], g["qd"], g["goal"], spheres=sph, csr_offset=off, csr_index=idx2)["qdd64"]
+        qdd = eng.step(q, qd, goal, obstacles=obs)
+        torch.cuda.synchronize()
+        _check(qdd.cpu().numpy(), ref, f"ragged K={K} {kernel} dup={dup}", mask=clear)
+
+
+def test_two_by_two_closed_form_pseudo_inverse(torch_mod, golden_dir):
+    """The quad mapping resolves 2-dof robots by the closed-form 2 x 2 pseudo-inverse (rmp2_solve.h pinv_solve_2x2): full
+    rank, exactly rank one (the TwoJoint start pose q = [0, 0], quirk Q3: J = [[0,0],[2,1],[0,0]]) and a NaN state,
+    against the oracle's SVD-style pseudo-inverse, with the status bits."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    _, desc = Cf.config1()
+    eng = _engine(desc, "quad")
+    s = Cf.sample_two_joint_states(np.random.default_rng(21), 300)
+    s["q"][0] = 0.0                      # rank-1 metric
+    s["q"][1] = [0.3, np.pi]             # folded arm: singular Jacobian again
+    s["q"][2, 0] = np.nan
+    st = torch.zeros(300, dtype=torch.int32, device="cuda")
+    qdd = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), status=st)
+    torch.cuda.synchronize()
+    assert "quad" in eng.last_kernel()
+    got, stc = qdd.cpu().numpy(), st.cpu().numpy()
+    ref = O.step(desc, s["q"], s["qd"], s["goal"])
+    cond = np.linalg.cond(ref["M"][3:])
+    # (a set without an inertia leaf: fp32 rounding of the leaves is amplified by cond(M), so the 1e-5 bound is stated for
+    # cond(M) <= 100 as everywhere else -- DESIGN.md section 2; robot 0: exact rank 1, the pseudo-inverse is well defined)
+    ok = np.concatenate([[True, False, False], cond < 100])
+    _check(got, ref["qdd64"], "2x2 closed form", mask=ok)
+    assert stc[0] & 2 and stc[0] & 4, "rank drop of the start pose must be reported"
+    assert stc[2] & 1 and not np.isfinite(got[2]).all()
+    assert (stc[3:][cond < 1e4] == 0).all() and (cond < 100).sum() > 100
