@@ -405,6 +405,131 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
   }
 }
 
+// ---- explicit closest-point pairs (the reference's Datamanager layout, data_management.py:8-37), culled ---------------
+// Interface B is the HBM-bound variant of the step (24 B per pair: 6 264 B per robot-step against 120 B with a shared
+// table), so what the lanes do per byte decides whether the loads or the ALUs set the time.  ObstacleAvoidance's metric is
+// exactly 0 beyond `thr` = margin + metric_modulation_radius (rmp2.py:191-195), as in the sphere modes:
+//   pass 1  every lane loads ITS share of the leaf's pairs (pair sub, sub + 4, ...: a quad reads 48 contiguous bytes of
+//           each array per slot, twelve bytes per lane) and tests |crit - p_obs|^2 against thr^2 (with slack; pairs inside
+//           the slack band run the exact formula, NaNs count as in range); the quad ORs the bits into one mask per chunk of
+//           32 pairs;
+//   pass 2  the set bits are dealt round-robin to the quad's lanes, which fetch their pair again (an L1 / L2 hit: the
+//           lines were read a few hundred cycles ago) and run the transcendental chain on it.
+struct F3 { float x, y, z; };
+// One leaf's first 32 pairs as this lane holds them between the loads and the range test: pairs sub, sub + 4, ... of both
+// arrays.  PairRegs travels from one leaf to the next: the loads of the NEXT leaf's chunk are issued as soon as this leaf's
+// tests have freed the registers, and land while this leaf's in-range pairs are evaluated and pulled back (the step is
+// bound by memory latency otherwise: one round trip per leaf on every wave's critical path).
+struct PairRegs {
+  F3 a[8], o[8];
+  const float* tag;  // p_link base the registers were loaded from (nullptr: nothing prefetched)
+};
+__device__ __forceinline__ void pair_regs_load(PairRegs& r, const float* pl, const float* po, int sub) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pos = sub + kQuad * i;
+    r.a[i] = *reinterpret_cast<const F3*>(pl + 3 * pos);
+    r.o[i] = *reinterpret_cast<const F3*>(po + 3 * pos);
+  }
+  r.tag = pl;
+}
+// next_pl / next_po: first pair of the leaf that follows in execution order when that leaf has a full chunk (>= 32
+// pairs), else nullptr
+template <bool PREFETCH>
+__device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const float* po, int count, int sub,
+                                                          const float P3[3], const float V3[3], const float A3[3],
+                                                          const float* P, const float* IP, float thr2, float S[6], float h[3],
+                                                          PairRegs* pf = nullptr, const float* next_pl = nullptr,
+                                                          const float* next_po = nullptr) {
+  const float vv = dot3(V3, V3);
+  auto diff_of = [&](int b, float diff[3]) {
+    const F3 a = *reinterpret_cast<const F3*>(pl + 3 * b);
+    const F3 o = *reinterpret_cast<const F3*>(po + 3 * b);
+    // taskmap.py:124-129: rel = stop_gradient(p_link - p_joint); crit = p_joint + rel
+    diff[0] = (P3[0] + (a.x - P3[0])) - o.x;
+    diff[1] = (P3[1] + (a.y - P3[1])) - o.y;
+    diff[2] = (P3[2] + (a.z - P3[2])) - o.z;
+  };
+  for (int base = 0; base < count; base += 32) {  // wave-uniform (the pair layout is shared by the fleet)
+    uint32_t m = 0u;
+    if (base + 32 <= count) {
+      // full chunk (the usual case: 32 pairs per leaf): all sixteen loads are issued before the first test -- a guarded
+      // loop pays one memory round trip per slot (measured: 163 us per step at 65 536 robots, latency bound)
+      PairRegs loc;
+      PairRegs& r = PREFETCH ? *pf : loc;
+      // (wave-uniform: the tag is the robot's own row address, but every lane of the wave prefetched the same leaf)
+      if (!PREFETCH || base != 0 || !__all(r.tag == pl)) pair_regs_load(r, pl + 3 * base, po + 3 * base, sub);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dx = (P3[0] + (r.a[i].x - P3[0])) - r.o[i].x;
+        const float dy = (P3[1] + (r.a[i].y - P3[1])) - r.o[i].y;
+        const float dz = (P3[2] + (r.a[i].z - P3[2])) - r.o[i].z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        m |= !(d2 > thr2) ? (1u << (kQuad * i)) : 0u;
+      }
+      if (PREFETCH && base + 32 >= count) {  // last chunk of this leaf tested: the registers are free for the next leaf
+        if (next_pl) pair_regs_load(r, next_pl, next_po, sub);
+        else r.tag = nullptr;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (base + kQuad * i >= count) continue;  // wave-uniform
+        const int pos = base + sub + kQuad * i;
+        const bool valid = pos < count;
+        float diff[3];
+        diff_of(valid ? pos : 0, diff);
+        const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+        m |= (valid && !(d2 > thr2)) ? (1u << (kQuad * i)) : 0u;
+      }
+    }
+    m <<= sub;
+    m |= dppu<kXor1>(m);
+    m |= dppu<kXor2>(m);
+    uint32_t rem = m;
+    rem = sub > 0 ? (rem & (rem - 1u)) : rem;
+    rem = sub > 1 ? (rem & (rem - 1u)) : rem;
+    rem = sub > 2 ? (rem & (rem - 1u)) : rem;
+    // (the pair of the NEXT trip is fetched while the current one is evaluated: the re-fetch is an L2 hit at best)
+    auto take = [&](bool& on_, float diff_[3]) {
+      on_ = rem != 0u;
+      const int j = on_ ? (__builtin_ffs((int)rem) - 1) : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rem &= rem - 1u;
+      diff_of(base + j, diff_);
+    };
+    bool on_next;
+    float diff_next[3];
+    take(on_next, diff_next);
+    while (true) {
+      const bool on = on_next;
+      if (!__any(on)) break;
+      const float diff[3] = {diff_next[0], diff_next[1], diff_next[2]};
+      take(on_next, diff_next);
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const float inv = rsq0(d2);
+      const float d = d2 * inv;
+      const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+      const float xdot = dot3(nh, V3);
+      const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+      float acc, met;
+      obstacle_pair(P, IP, d, xdot, acc, met);
+      if (!on) met = 0.f;
+      const float wgt = met * (acc - cd);
+      const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+      S[0] = fmaf(mn[0], nh[0], S[0]);
+      S[1] = fmaf(mn[0], nh[1], S[1]);
+      S[2] = fmaf(mn[0], nh[2], S[2]);
+      S[3] = fmaf(mn[1], nh[1], S[3]);
+      S[4] = fmaf(mn[1], nh[2], S[4]);
+      S[5] = fmaf(mn[2], nh[2], S[5]);
+      h[0] = fmaf(wgt, nh[0], h[0]);
+      h[1] = fmaf(wgt, nh[1], h[1]);
+      h[2] = fmaf(wgt, nh[2], h[2]);
+    }
+  }
+}
+
 // v[4 m + sub] of a wave-uniform per-dof vector of the program (leaf va / vb): four scalar-cache words and three
 // selects instead of a lane-indexed vector load from global memory (a full memory latency in the middle of a leaf)
 __device__ __forceinline__ float pick4(const float* v, int m, int sub) {
@@ -494,7 +619,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
                       OutArgs out, RolloutArgs ro_arg, int R) {
   const int obs_mode = OBS == kObsAny ? obs.mode : OBS;
   const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr} : ro_arg;
+#ifdef RMP2_STAMPS
+  if (PLAIN) out.M = nullptr;  // (diagnostic build: the stamps travel behind the f rows, so the plain build keeps that pointer)
+#else
   if (PLAIN) out.M = nullptr, out.f = nullptr;
+#endif
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
   // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
@@ -828,6 +957,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // ~200 cycles and the old chain leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id] had four of them per frame)
     const float* floc = loc;  // (loop-local copy, as in the walk)
     if (MINW >= 3) asm volatile("" : "+v"(floc));
+    // explicit-pair plain builds with registers to spare (two waves per SIMD): the next leaf's pairs are prefetched
+    // (MEASURED SLOWER and therefore off: holding the next leaf's 48 registers through the pull-back makes the 256-register
+    // build spill 40 dwords in the frame loop -- 184.1 us per step at 65 536 robots against 123.7 without the prefetch)
+    constexpr bool kPrefetchPairs = false && OBS == RMP2_OBS_EXPLICIT_PAIRS && PLAIN && !STAGE && MINW <= 2;
+    PairRegs pair_regs;
+    pair_regs.tag = nullptr;
     int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
       if (MINW >= 3) {  // thirds of the frame loop at 3 / 2 / 1
@@ -914,8 +1049,31 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const int pb = obs.pair_begin[lidx];
             const int count = obs.pair_begin[lidx + 1] - pb;
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
-            pair_loop<kPairsExplicit, false>(nullptr, obs.p_link + base, obs.p_obs + base, nullptr, count, count, sub, P3, V3,
-                                      A3, lh.P, IP, S, h);
+            // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
+            const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
+            if constexpr (kPrefetchPairs) {
+              // the leaf that follows in execution order (exec_leaves[] holds the FK leaves in that order): when it is a
+              // distance leaf with a full chunk its first 32 pairs are prefetched by this leaf's loop
+              const float* npl = nullptr;
+              const float* npo = nullptr;
+              const int e = op.leaf_begin + li;
+              if (e + 1 < hdr.n_fk) {
+                const DevLeaf& nx = prog->exec_leaves[e + 1];
+                if (nx.taskmap == RMP2_TASKMAP_FK_DISTANCE) {
+                  const int npb = obs.pair_begin[nx.index];
+                  if (obs.pair_begin[nx.index + 1] - npb >= 32) {
+                    const size_t nb = ((size_t)(live ? robot : 0) * obs.n_pairs + npb) * 3;
+                    npl = obs.p_link + nb;
+                    npo = obs.p_obs + nb;
+                  }
+                }
+              }
+              pair_loop_explicit_culled<true>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
+                                              thr * thr * kCullSlack, S, h, &pair_regs, npl, npo);
+            } else {
+              pair_loop_explicit_culled<false>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
+                                               thr * thr * kCullSlack, S, h);
+            }
           } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
             pair_loop_culled<false, kQuad, (MINW >= 2), true>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
                                                              A3, lh.P, IP, S, h, nullptr, member_lo, member_hi);
@@ -1226,7 +1384,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
-    if (pass == 0 && live && (out.M || out.f)) {
+    if (!PLAIN && pass == 0 && live && (out.M || out.f)) {
       // (the 64-bit row addresses are formed HERE, from an opaque copy of the robot index: hoisted to the prologue -- where
       // the compiler otherwise puts them -- they are spilled by every wave of the register-capped builds and read back
       // only when the debug outputs are asked for)

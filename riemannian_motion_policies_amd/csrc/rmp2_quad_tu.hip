@@ -36,6 +36,9 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   if (minw == 0) {
     const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
     minw = (symk && (bc == 4 || bc >= 7)) ? 4 : 2;
+    // explicit pairs (interface B) are bound by memory latency, not by issue slots: the two-wave build keeps a whole leaf's
+    // loads (and the next leaf's prefetch) in flight per wave -- 123.7 us per step at 65 536 robots against 148.7 with four
+    if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
   }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
@@ -66,7 +69,11 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     if (symk) RMP2_QUAD_PLAIN_SYM(MINW, (N == 9));                                                                      \
     else RMP2_QUAD_PLAIN_SYM(MINW, false);                                                                              \
   } while (0)
+#ifdef RMP2_STAMPS
+  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !o.capsule;  // (stamps ride behind out.f)
+#else
   const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !out.f && !o.capsule;
+#endif
   if (latency) RMP2_QUAD_BY_CAP(1, true);
   else if (plain && minw == 4) RMP2_QUAD_PLAIN(4);
   else if (plain && minw == 3) RMP2_QUAD_PLAIN(3);
