@@ -392,8 +392,20 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
     # config4
     if K % world:
         raise SystemExit("sphere count must divide by the world size")
-    exch = exch or ObstacleExchange(K // world, dev)
     local = torch.from_numpy(spheres_np[rank * (K // world):(rank + 1) * (K // world)]).to(dev)
+    if args.exchange == "native":
+        # gather + stream orderings + launch inside librmp2_hip.so: one C-ABI call per control step (the torch.distributed
+        # loop below costs ~50 us of host time per step -- more than the step kernel takes)
+        from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
+        exch = exch if isinstance(exch, NativeObstacleExchange) else NativeObstacleExchange(K // world, dev)
+        if exch.pending == 0:   # (a reused exchange -- the emulation -- still holds the previous user's last gather)
+            exch.start(local)
+        # (the rank's slice is static in this benchmark -- as the fixed `local_ready` event of the torch-driven loop below --
+        # so no producer event is put between two step kernels; a moving slice orders itself with next_local_is_ready=False)
+        one_step = exch.bind(eng, q, qd, goal, out, next_local=local, next_local_is_ready=True)
+        keep += [exch, local]
+        return one_step, eng, desc, table, s, spheres_np, keep
+    exch = exch or ObstacleExchange(K // world, dev)
     # all-gather on a side stream, pipelined one step ahead: the table of step k + 1 is gathered (into
     # the second buffer) while the kernel of step k runs; every step consumes a freshly gathered table
     local_ready = torch.cuda.Event()
@@ -478,10 +490,13 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
         # ONE exchange (one side stream) for all emulated ranks: HIP maps streams onto hardware queues in creation order,
         # and a fresh side stream per rank lands on the compute stream's queue every few ranks (measured: 156 us steps)
         from riemannian_motion_policies_amd import configs as Cf
-        from riemannian_motion_policies_amd.fleet import ObstacleExchange
-        exch = ObstacleExchange(Cf.N_SPHERES, dev)
+        from riemannian_motion_policies_amd.fleet import NativeObstacleExchange, ObstacleExchange
+        native = args.exchange == "native"
+        exch = NativeObstacleExchange(Cf.N_SPHERES, dev) if native else ObstacleExchange(Cf.N_SPHERES, dev)
+        if native:
+            exch.set_peer_wait(True)   # (time the orderings an N-rank exchange needs, not the one-rank shortcut)
         for r in range(W):
-            while exch._pending:   # drain the previous rank's outstanding gather
+            while not native and exch._pending:   # drain the previous rank's outstanding gather
                 exch.finish()
             one_step, eng, desc, table, s, spheres_np, keep = build_config34(
                 workload, args, dev, local_rank, 0, 1, R, seed_rank=r, exch=exch)
@@ -610,7 +625,7 @@ def worker(args) -> int:
         total_robots = R * world
         bound = wl.get("bound", "valu")
         parallelism = f"robot-batch split x{world}" + (
-            ", RCCL all-gather of the sphere table per step (side stream, double-buffered)" if workload == "config4" else "")
+            f", RCCL all-gather of the sphere table per step (side stream, double-buffered; exchange = {args.exchange})" if workload == "config4" else "")
     else:
         # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, cost-balanced cut across the ranks ----
         cost = None
@@ -712,6 +727,9 @@ def main():
     ap.add_argument("--calibrate-robots", type=int, default=16384)
     ap.add_argument("--compare-flop-model", action="store_true",
                     help="--emulate-world with config5: also time the shards the round-2 flop-model weights would cut")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="config4: obstacle exchange inside librmp2_hip.so (one C-ABI call per step) or driven from Python "
+                         "through torch.distributed (A/B)")
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")

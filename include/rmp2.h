@@ -216,6 +216,7 @@ int rmp2_validate(const rmp2_desc *desc);
  *   RMP2_KERNEL     = hex | quad | lane   mapping of robots to lanes (16 / 4 / 1 lanes per robot)
  *   RMP2_QUAD_MINW  = 2 | 3 | 4           register cap of the quad mapping's throughput build (waves per SIMD it leaves room for)
  *   RMP2_QUAD_SYM   = 0                   general (full-matrix) form of the quad mapping for sets that qualify for the symmetric one
+ *   RMP2_EXCHANGE_THROTTLE_US = n         (rmp2_exchange_create) bound of the host throttle of rmp2_exchange_step, 0 = free-running
  * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with
  * -DRMP2_TUNING (tools/); the shipped library ignores them.  A deployment should leave all of them unset. */
 
@@ -251,6 +252,39 @@ int rmp2_fence_destroy(void *fence);
  * then be issued from ONE thread at a time (handles stay independent of each other).  rmp2_fence_destroy refuses a fence
  * that is still attached (RMP2_ERR_INVALID_ARGUMENT); rmp2_destroy detaches. */
 int rmp2_set_step_fence(rmp2_handle *h, void *fence);
+
+/* Native obstacle exchange for a fleet sharded over the GPUs of a node (the `rmp2_comm_init` of SURVEY 8(b)):
+ * every rank owns `spheres_per_rank` rows of the shared sphere table, the table [nranks * spheres_per_rank][4] is
+ * all-gathered once per control step with RCCL on the exchange's own stream, double-buffered and one step ahead of the
+ * kernel that consumes it; gather, stream orderings and the step launch are ONE call per control step (the same loop
+ * driven from Python through torch.distributed costs ~50 us of host time per step, more than the step kernel takes).
+ * RCCL is bound at run time: `rccl_library` is the path of the librccl.so the process uses (e.g. PyTorch's own copy), so
+ * this library has no link-time dependency on it.  Rank 0 calls rmp2_exchange_unique_id and ships the 128 bytes to the
+ * other ranks by any means (bench.py: torch.distributed broadcast); every rank then calls rmp2_exchange_create
+ * (collective: it returns when all `nranks` ranks have joined).  One issuing thread per exchange. */
+typedef struct rmp2_rccl_uid { char bytes[128]; } rmp2_rccl_uid;  /* ncclUniqueId */
+typedef struct rmp2_exchange rmp2_exchange;
+int rmp2_exchange_unique_id(const char *rccl_library, rmp2_rccl_uid *uid);
+int rmp2_exchange_create(const char *rccl_library, const rmp2_rccl_uid *uid, int rank, int nranks, int device,
+                         int spheres_per_rank, rmp2_exchange **out);
+int rmp2_exchange_destroy(rmp2_exchange *x);
+const char *rmp2_exchange_last_error(const rmp2_exchange *x);
+int rmp2_exchange_pending(const rmp2_exchange *x);   /* gathers started and not yet consumed by a step (0 .. 2) */
+/* on != 0: a one-rank exchange orders its steps as an N-rank one does (GPU-side wait on the gathered table kept): what a
+ * single-GPU EMULATION of an N-rank run must time.  No effect at nranks > 1 (the wait is always kept there). */
+int rmp2_exchange_set_peer_wait(rmp2_exchange *x, int32_t on);
+/* Issue the all-gather of `local` (device [spheres_per_rank][4]) into the free table buffer; it waits for the last step
+ * that read the buffer it overwrites and -- local_is_ready == 0 -- for everything enqueued on `stream` so far (the producer
+ * of `local`).  local_is_ready != 0: the caller guarantees that `local` is complete when this call is made (produced by an
+ * earlier, already synchronised step of its pipeline, or static): no event is put on `stream`.  At most two gathers may be
+ * outstanding. */
+int rmp2_exchange_start(rmp2_exchange *x, const float *local, int32_t local_is_ready, void *stream);
+/* One control step (as rmp2_step with SHARED_SPHERES) on the OLDEST outstanding table.  next_local != NULL: the gather of
+ * the next table is issued before the launch (same as rmp2_exchange_start(x, next_local, next_local_is_ready, stream)).
+ * table_out (optional): device pointer of the table this step reads. */
+int rmp2_exchange_step(rmp2_exchange *x, rmp2_handle *h, const float *q, const float *qd, const float *goal,
+                       int32_t goal_stride, const float *next_local, int32_t next_local_is_ready, const rmp2_outputs *out,
+                       int32_t R, void *stream, const float **table_out);
 
 /* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
  *   q, qd       device [R][n_dof] fp32

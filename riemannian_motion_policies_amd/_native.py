@@ -57,6 +57,16 @@ def lib():
     l.rmp2_differentiate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     l.rmp2_differentiate_euler.argtypes = l.rmp2_differentiate.argtypes
+    l.rmp2_exchange_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+    l.rmp2_exchange_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    l.rmp2_exchange_destroy.argtypes = [C.c_void_p]
+    l.rmp2_exchange_last_error.restype = C.c_char_p
+    l.rmp2_exchange_last_error.argtypes = [C.c_void_p]
+    l.rmp2_exchange_pending.argtypes = [C.c_void_p]
+    l.rmp2_exchange_set_peer_wait.argtypes = [C.c_void_p, C.c_int32]
+    l.rmp2_exchange_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    l.rmp2_exchange_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.POINTER(D.Outputs), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     if l.rmp2_abi_version() != D.ABI_VERSION:
         raise Rmp2Error(f"ABI mismatch: library {l.rmp2_abi_version()} vs bindings {D.ABI_VERSION}")
     if l.rmp2_sizeof_desc() != C.sizeof(D.Desc) or l.rmp2_sizeof_obstacles() != C.sizeof(D.Obstacles):

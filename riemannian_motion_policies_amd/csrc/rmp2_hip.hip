@@ -14,6 +14,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+
+#include <chrono>
+
 #include <map>
 #include <mutex>
 #include <new>
@@ -1576,6 +1580,208 @@ int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal
               const rmp2_obstacles* obs, const rmp2_outputs* out, int32_t R, void* stream) {
   const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr};
   return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
+}
+
+// ---- native obstacle exchange (include/rmp2.h): RCCL all-gather of the sphere table + step, one call per control step ----
+// RCCL is bound at run time (dlopen of the library the caller names -- the copy the process already uses, e.g. PyTorch's --
+// so that librmp2_hip.so itself has no link-time dependency on it and a fleet without a distributed table never loads it).
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, rmp2_rccl_uid, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
+
+int load_rccl(const char* path, RcclApi& api, std::string& err) {
+  if (!path || !*path) return err = "path of the RCCL library is required", RMP2_ERR_INVALID_ARGUMENT;
+  api.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!api.lib) return err = std::string("dlopen(") + path + "): " + dlerror(), RMP2_ERR_HIP;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy)
+    return err = std::string(path) + " does not export the RCCL entry points", RMP2_ERR_HIP;
+  return RMP2_OK;
+}
+}  // namespace
+
+struct rmp2_exchange {
+  RcclApi api;
+  void* comm = nullptr;
+  int device = 0, rank = 0, world = 1, per_rank = 0;
+  float* table[2] = {nullptr, nullptr};    // [world * per_rank][4]
+  hipStream_t side = nullptr;              // the gathers' stream
+  hipEvent_t ready[2] = {nullptr, nullptr};        // gather into table b complete
+  hipEvent_t reader_done[2] = {nullptr, nullptr};  // last kernel that read table b complete (the launch's own stop event)
+  hipEvent_t produced = nullptr;                   // "everything enqueued on the caller's stream so far"
+  bool reader_valid[2] = {false, false};
+  int pending[2] = {0, 0}, n_pending = 0, next = 0;
+  bool peer_wait = false;  // keep the GPU-side wait at world 1 too (the single-GPU emulation of an N-rank run: rmp2_exchange_set_peer_wait)
+  int throttle_us = 500;  // bound of the host throttle in rmp2_exchange_step (0: free-running; RMP2_EXCHANGE_THROTTLE_US in tuning builds)
+  std::string error;
+};
+
+int rmp2_exchange_unique_id(const char* rccl_library, rmp2_rccl_uid* uid) {
+  if (!uid) return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "null argument");
+  RcclApi api;
+  std::string err;
+  if (int rc = load_rccl(rccl_library, api, err)) return fail(nullptr, rc, err);
+  const int r = api.GetUniqueId(uid);
+  return r == 0 ? RMP2_OK : fail(nullptr, RMP2_ERR_HIP, std::string("ncclGetUniqueId: ") + (api.GetErrorString ? api.GetErrorString(r) : "?"));
+}
+
+int rmp2_exchange_create(const char* rccl_library, const rmp2_rccl_uid* uid, int rank, int nranks, int device,
+                         int spheres_per_rank, rmp2_exchange** out) {
+  if (!out || !uid || nranks < 1 || rank < 0 || rank >= nranks || spheres_per_rank < 1)
+    return fail(nullptr, RMP2_ERR_INVALID_ARGUMENT, "rmp2_exchange_create: bad arguments");
+  *out = nullptr;
+  rmp2_exchange* x = new (std::nothrow) rmp2_exchange();
+  if (!x) return fail(nullptr, RMP2_ERR_HIP, "out of host memory");
+  x->device = device, x->rank = rank, x->world = nranks, x->per_rank = spheres_per_rank;
+  if (const char* te = std::getenv("RMP2_EXCHANGE_THROTTLE_US")) x->throttle_us = std::max(0, std::atoi(te));
+  std::string err;
+  int rc = load_rccl(rccl_library, x->api, err);
+  hipError_t e = hipSuccess;
+  if (rc == RMP2_OK) {
+    e = hipSetDevice(device);
+    // ready[]: a default event (system-scope release) when peers write the table over xGMI, a device-scope one for one rank;
+    // reader_done[] / produced order work of THIS GPU only (rmp2_fence_* rules)
+    const unsigned ready_flags = hipEventDisableTiming | (nranks == 1 ? hipEventDisableSystemFence : 0u);
+    const unsigned local_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+      e = hipMalloc(&x->table[b], sizeof(float) * 4 * nranks * spheres_per_rank);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ready[b], ready_flags);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&x->reader_done[b], local_flags);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->produced, local_flags);
+    if (e == hipSuccess) {
+      // highest priority: at the boundary between two step kernels the gather's few workgroups are dispatched BEFORE the next
+      // step's 4 096 (which fill every SIMD and all of LDS; behind them the gather would only run at that step's tail)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      e = hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, hi);
+    }
+    if (e != hipSuccess) rc = RMP2_ERR_HIP, err = std::string("rmp2_exchange_create: ") + hipGetErrorString(e);
+  }
+  if (rc == RMP2_OK) {
+    const int r = x->api.CommInitRank(&x->comm, nranks, *uid, rank);
+    if (r != 0) rc = RMP2_ERR_HIP, err = std::string("ncclCommInitRank: ") + (x->api.GetErrorString ? x->api.GetErrorString(r) : "?");
+  }
+  if (rc != RMP2_OK) {
+    rmp2_exchange_destroy(x);
+    return fail(nullptr, rc, err);
+  }
+  *out = x;
+  return RMP2_OK;
+}
+
+int rmp2_exchange_destroy(rmp2_exchange* x) {
+  if (!x) return RMP2_OK;
+  (void)hipSetDevice(x->device);
+  if (x->side) (void)hipStreamSynchronize(x->side);
+  if (x->comm && x->api.CommDestroy) x->api.CommDestroy(x->comm);
+  for (int b = 0; b < 2; ++b) {
+    if (x->table[b]) (void)hipFree(x->table[b]);
+    if (x->ready[b]) (void)hipEventDestroy(x->ready[b]);
+    if (x->reader_done[b]) (void)hipEventDestroy(x->reader_done[b]);
+  }
+  if (x->produced) (void)hipEventDestroy(x->produced);
+  if (x->side) (void)hipStreamDestroy(x->side);
+  delete x;
+  return RMP2_OK;
+}
+
+int rmp2_exchange_set_peer_wait(rmp2_exchange* x, int32_t on) {
+  if (!x) return RMP2_ERR_INVALID_ARGUMENT;
+  x->peer_wait = on != 0;
+  return RMP2_OK;
+}
+
+int rmp2_exchange_pending(const rmp2_exchange* x) { return x ? x->n_pending : 0; }
+
+const char* rmp2_exchange_last_error(const rmp2_exchange* x) { return x ? x->error.c_str() : g_create_error.c_str(); }
+
+#define XCH_TRY(x, expr)                                                                                   \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) return (x)->error = std::string(#expr) + ": " + hipGetErrorString(e_), RMP2_ERR_HIP; \
+  } while (0)
+
+// Issue the all-gather of `local` ([spheres_per_rank][4], device) into the free table buffer, on the exchange's side
+// stream.  It waits for everything enqueued on `stream` so far (the producer of `local`) and for the last kernel that read
+// the buffer it overwrites.
+int rmp2_exchange_start(rmp2_exchange* x, const float* local, int32_t local_is_ready, void* stream) {
+  if (!x || !local) return RMP2_ERR_INVALID_ARGUMENT;
+  if (x->n_pending >= 2) return x->error = "two gathers are outstanding: step before starting a third", RMP2_ERR_INVALID_ARGUMENT;
+  const int b = x->next;
+  if (!local_is_ready) {  // order the gather behind the producer of `local` on the caller's stream (an event packet between
+    XCH_TRY(x, hipEventRecord(x->produced, static_cast<hipStream_t>(stream)));  // two step kernels: ~4 us of the step)
+    XCH_TRY(x, hipStreamWaitEvent(x->side, x->produced, 0));
+  }
+  if (x->reader_valid[b]) XCH_TRY(x, hipStreamWaitEvent(x->side, x->reader_done[b], 0));
+  const int r = x->api.AllGather(local, x->table[b], (size_t)4 * x->per_rank, kNcclFloat, x->comm, x->side);
+  if (r != 0) return x->error = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(r) : "?"), RMP2_ERR_HIP;
+  XCH_TRY(x, hipEventRecord(x->ready[b], x->side));
+  x->pending[x->n_pending++] = b;
+  x->next ^= 1;
+  return RMP2_OK;
+}
+
+// One control step on the oldest outstanding table: `stream` waits for its gather; if `next_local` is given, the gather of
+// the NEXT table is issued first (it then takes its few workgroups while the GPU is between two steps, instead of queueing
+// behind a kernel that fills every SIMD); then the step kernel is launched with the "table has been read" fence as its own
+// completion signal.  `table_out` (optional) receives the device pointer of the table this step reads.
+int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const float* qd, const float* goal,
+                       int32_t goal_stride, const float* next_local, int32_t next_local_is_ready, const rmp2_outputs* out,
+                       int32_t R, void* stream, const float** table_out) {
+  if (!x || !h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (x->n_pending < 1) return x->error = "no gathered table outstanding: rmp2_exchange_start first", RMP2_ERR_INVALID_ARGUMENT;
+  const int b = x->pending[0];
+  x->pending[0] = x->pending[1];
+  --x->n_pending;
+  // Host throttle: wait (bounded) until the gather of THIS step's table has completed -- it was issued one call ago and runs
+  // as soon as step k - 2 has finished, so the host stays at most ~1.5 steps ahead of the GPU, which is all the launch
+  // latency needs.  The point: a stream-wait on an event that has ALREADY completed is dropped by the runtime at enqueue
+  // time, while a host that runs many steps ahead turns every one of them into a barrier packet between two step kernels
+  // (measured at 65 536 robots: 53.1 us per step free-running, see profiles/r03_exchange_timing.txt).
+  bool seen_complete = false;
+  if (x->throttle_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t qe;
+    while ((qe = hipEventQuery(x->ready[b])) == hipErrorNotReady) {
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > x->throttle_us) break;
+    }
+    seen_complete = qe == hipSuccess;
+  }
+  // One rank: the gather is a copy on THIS GPU; once the host has seen it complete the step needs no GPU-side wait at all
+  // (even a satisfied stream-wait is a barrier packet between two step kernels: 4.7 us of the period,
+  // profiles/r03_exchange_timing.txt).  Several ranks: peers wrote the table over xGMI, past this GPU's L2 -- the step
+  // keeps the stream-wait on the system-scope event, whose acquire is what makes those writes visible.
+  if (!(seen_complete && x->world == 1 && !x->peer_wait))
+    XCH_TRY(x, hipStreamWaitEvent(static_cast<hipStream_t>(stream), x->ready[b], 0));
+  if (next_local)
+    if (int rc = rmp2_exchange_start(x, next_local, next_local_is_ready, stream)) return rc;
+  rmp2_obstacles o;
+  std::memset(&o, 0, sizeof(o));
+  o.mode = RMP2_OBS_SHARED_SPHERES;
+  o.primitive = RMP2_PRIM_SPHERE;
+  o.n_spheres = x->world * x->per_rank;
+  o.spheres = x->table[b];
+  void* const saved = h->step_fence;
+  h->step_fence = x->reader_done[b];
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr};
+  const int rc = step_impl(h, q, qd, goal, goal_stride, &o, out, ro, R, stream);
+  h->step_fence = saved;
+  if (rc != RMP2_OK) return x->error = h->error, rc;
+  x->reader_valid[b] = true;
+  if (table_out) *table_out = x->table[b];
+  return RMP2_OK;
 }
 
 int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t goal_stride,

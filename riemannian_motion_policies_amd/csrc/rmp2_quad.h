@@ -29,6 +29,10 @@
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
 
+#ifndef RMP2_IDENT_FIRST
+#define RMP2_IDENT_FIRST 0  // measured: no gain (43.7 vs 43.6 us at 65 536 robots, 163.1 vs 160.2 at 262 144; tools/experiments/README.md)
+#endif
+
 namespace rmp2 {
 
 constexpr int kQuad = 4;
@@ -625,6 +629,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   if (PLAIN) out.M = nullptr, out.f = nullptr;
 #endif
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
+  constexpr bool kIdentFirst = SYM && PLAIN && MINW >= 3 && RMP2_IDENT_FIRST;  // (see "Phase order per wave" below)
   // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
   //               STAGE only: ops[n_ops] | leaves[n_leaves] | fk list | id list | goal tile 16 x 16 floats]
@@ -821,6 +826,222 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   }
   __syncthreads();
 
+  // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
+  double A[ROWS][N];
+  double fv[ROWS];
+  auto zero_system = [&]() {
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      fv[m] = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[m][j] = 0.0;
+    }
+  };
+  constexpr bool sym = SYM;
+  // ---- identity-task-map leaves (row layout): they need q and qd only, not the kinematics ------------------------
+  auto identity_leaves = [&]() {
+      for (int li = 0; li < n_id; ++li) {
+        // (scalar-cache walk: the identity leaves follow the FK leaves in exec_leaves[], in execution order -- no index fetch)
+        const DevLeaf& lfr = STAGE ? leaves[uni<STAGE>(id_list[li])] : prog->exec_leaves[hdr.n_fk + li];
+        const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte load
+        struct {
+          int kind, goal_offset;
+          const float* va;
+          const float* vb;
+        } lf = {uni<STAGE>(lh.kind), uni<STAGE>(lh.goal_offset), lfr.va, lfr.vb};
+        const float* P = lh.P;
+        if (lf.kind == RMP2_LEAF_JOINT_DAMPING || lf.kind == RMP2_LEAF_CSPACE_BIASING ||
+            lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {
+          // diagonal metrics m * I:  A_ii += m, f_i += m * xdd_i
+          float mdiag, nrm = 0.f;
+          if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {  // rmp2.py:127-137
+            float s2 = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) s2 += my_qd[j] * my_qd[j];
+            nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+            mdiag = P[1] * nrm + P[2];
+          } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {  // rmp2.py:212-226
+            float s2 = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) {
+              const float e = my_q[j] - lf.va[j];
+              s2 += e * e;
+            }
+            nrm = sqrtf(s2);
+            mdiag = P[0] + P[4];
+          } else {  // rmp.py:330-347
+            mdiag = P[2];
+          }
+  #pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const int ii = i < N ? i : 0;
+            const float qi_ = my_q[ii], qdi = my_qd[ii];
+            float acc;
+            if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {
+              acc = -(P[0] * nrm) * qdi;
+            } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {
+              const float e = qi_ - (STAGE ? lf.va[ii] : pick4(lf.va, m, sub));
+              const float pos = (nrm < P[3]) ? (-e * P[1]) : (-P[3] * (e / nrm) * P[1]);
+              acc = pos + (-P[2] * qdi);
+            } else {
+              acc = P[0] * ((STAGE ? lf.va[ii] : pick4(lf.va, m, sub)) - qi_) - P[1] * qdi;
+            }
+            fv[m] += (double)(mdiag * acc);
+          }
+          // A_jj += m: column j's diagonal lives in local row j >> 2 of lane sub == (j & 3)
+          const double dm = (double)mdiag;
+  #pragma unroll
+          for (int j = 0; j < N; ++j) A[j >> 2][j] += (sub == (j & 3)) ? dm : 0.0;
+        } else if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
+          // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) evaluated on the FULL matrix (quirk Q4): every off-diagonal
+          // entry is w, the diagonal is w / (1 - ratio_i^2).  A constant plus a diagonal: no n x n loop of products --
+          //   A_ij += w ,  A_ii += d_i - w ,  f_i += w sum_j xdd_j + (d_i - w) xdd_i
+          const float cutoff = P[0] - P[1];
+          const float w = P[3] / 1.0f;
+          float xo[ROWS], dg[ROWS], sx = 0.f;
+  #pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const float qdj = my_qd[i < N ? i : 0];
+            const float dv = fabsf(qdj) - cutoff;
+            const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
+            const float acc = -fabsf(P[2] * dv) * sgn;
+            xo[m] = (i < n_dof && !(fabsf(qdj) < cutoff)) ? acc : 0.f;
+            const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
+            dg[m] = P[3] / (1.0f - ratio * ratio);
+            sx += xo[m];
+          }
+          sx = quad_sum(sx);
+          const double wd = (double)w;
+  #pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sub + kQuad * m;
+            const bool row_ok = i < n_dof;
+            const double wr = row_ok ? wd : 0.0;
+            const double dd = row_ok ? (double)dg[m] - wd : 0.0;  // exact: A_ii = w + (d_i - w) = d_i
+  #pragma unroll
+            for (int j = 0; j < N; ++j)
+              if (j < n_dof && (j >= kQuad * m || !sym)) A[m][j] += wr;  // (sym: the blocks below the diagonal are not kept)
+  #pragma unroll
+            for (int c = 0; c < kQuad; ++c)
+              if (kQuad * m + c < N) A[m][kQuad * m + c] += (sub == c) ? dd : 0.0;
+            fv[m] += (double)(row_ok ? fmaf(w, sx, (dg[m] - w) * xo[m]) : 0.f);
+          }
+        } else {
+          // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij)
+          float zeta[N], xdd[N], cw[N], beta, wsc;
+          // each lane forms the terms of ITS dofs (i = sub + 4 m) once; the quad then broadcasts them (three DPP moves per
+          // dof and array) instead of every lane recomputing all n of them -- the divisions below are IEEE sequences
+          auto expand = [&](const float (&own)[ROWS], float (&full)[N]) {
+  #pragma unroll
+            for (int j = 0; j < N; ++j) {
+              const float v = own[j >> 2];
+              full[j] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
+            }
+          };
+          if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
+            // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
+            const float rr_ = 0.15f;
+            const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
+            const float iqd_max = (float)(60.0 / (20.0 * (2.0 * 3.14159265358979323846)));
+            float cw_o[ROWS], zeta_o[ROWS], xdd_o[ROWS], s2 = 0.f;
+  #pragma unroll
+            for (int m = 0; m < ROWS; ++m) {
+              const int i = sub + kQuad * m;
+              const int ii = i < N ? i : 0;
+              const float qj = my_q[ii], qdj = my_qd[ii];
+              const float lo_ = STAGE ? lf.va[ii] : pick4(lf.va, m, sub), hi_ = STAGE ? lf.vb[ii] : pick4(lf.vb, m, sub);
+              const float irange = rcp1(hi_ - lo_);
+              const float du = (hi_ - qj) * irange;
+              const float dl = (qj - lo_) * irange;
+              const float d = fminf(du, dl);
+              const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
+              cw_o[m] = (i < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
+              zeta_o[m] = (i < N) ? qdj * iqd_max : 0.f;
+              s2 += zeta_o[m] * zeta_o[m];
+              xdd_o[m] = -P[0] * qj - P[1] * qdj;
+            }
+            s2 = quad_sum(s2);
+            const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
+            // soft norm h = |v| + (1/c) log(1 + exp(-2 c |v|)), c = 5   (helper/rmp_helper.py:62-65)
+            const float hh = nrm + 0.2f * (0.693147182464599609375f * __builtin_amdgcn_logf(1.0f + exp1(-10.0f * nrm)));
+            const float ihh = rcp1(hh);
+  #pragma unroll
+            for (int m = 0; m < ROWS; ++m) zeta_o[m] *= ihh;
+            expand(cw_o, cw);
+            expand(zeta_o, zeta);
+            expand(xdd_o, xdd);
+            beta = 0.9f;
+            wsc = 1.0f;
+          } else {
+            // TargetPolicy on the identity map, rmp.py:241-260 (goal is an n-vector)
+            const float alpha = P[0], beta_d = P[1], c = P[2];
+            float v[N], s2 = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) {
+              v[j] = (j < n_dof) ? my_goal[lf.goal_offset + j] - my_q[j] : 0.f;
+              s2 += v[j] * v[j];
+            }
+            const float vn = sqrtf(s2);
+            const float hq = vn + c * logf(1.0f + expf(-2.0f * c * vn));
+            const float inv_h = 1.0f / hq;
+            float f2 = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) {
+              xdd[j] = alpha * (inv_h * v[j]) - beta_d * my_qd[j];
+              f2 += xdd[j] * xdd[j];
+              cw[j] = 1.0f;
+            }
+            const float fn = sqrtf(f2);
+            const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
+  #pragma unroll
+            for (int j = 0; j < N; ++j) zeta[j] = xdd[j] / hs;
+            beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
+            wsc = expf(-vn / 3.0f);
+          }
+          const float omb = 1.0f - beta;
+          const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
+          int sd = sub;  // (opaque copy, as for the walk's base row)
+          if (MINW >= 3) asm volatile("" : "+v"(sd));
+  #pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            const int i = sd + kQuad * m;
+            const bool row_ok = i < n_dof;
+            // zeta_i of MY row: select from the statically indexed vector
+            float zi = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) zi = (j == i) ? zeta[j] : zi;
+            float fi = 0.f;
+  #pragma unroll
+            for (int j = 0; j < N; ++j) {
+              if (j >= n_dof) continue;
+              // JointLimitAvoidance scales COLUMN j by the limit weight of joint j, which is exactly 0 unless
+              // that joint is inside its limit band: skip the column when that holds for the whole wave
+              if (is_jla && !__any(cw[j] != 0.f)) continue;
+              const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
+              float a = is_jla ? cw[j] * Hij : wsc * Hij;
+              a = row_ok ? a : 0.f;
+              if (!SYM || j >= kQuad * m) A[m][j] += (double)a;  // (sym: the blocks below the diagonal are not kept)
+              fi += a * xdd[j];
+            }
+            fv[m] += (double)fi;
+          }
+        }
+      }
+  };
+  // Phase order per wave.  The four waves of a SIMD start together and would walk their kinematic trees together -- the
+  // one phase that is a dependent chain (latency bound, the SIMD issues next to nothing) -- and then crowd the issue-bound
+  // leaf phases together.  The identity-map leaves depend on nothing the walk produces, so the waves in the ODD wave slots
+  // of a SIMD run them BEFORE the walk (symmetric form only: the general form's mirror step would overwrite what they add
+  // below the diagonal blocks): their issue-dense work fills the slots the even waves' walks leave empty, and their walks
+  // run beside the even waves' frame loops.
+  const bool ident_first = kIdentFirst && ((__builtin_amdgcn_s_getreg(0x1804) & 1) != 0);  // HW_ID[3:0] = wave slot in its SIMD
+  if (ident_first) {
+    zero_system();
+    identity_leaves();
+  }
+
   // ---- phase 2: serial tree walk (component layout), ONCE per step ------------------------------
   // Deliberately a tiny loop with nothing else in it: the walk is one dependent chain, so every
   // instruction in its body is latency.  The frame's control word travels inside its LDS record;
@@ -833,9 +1054,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     QuadState slot[SLOTS > 0 ? SLOTS : 1] = {};
     // loop-local copies of the long-lived LDS addresses: their own short live ranges -- the 128-register build otherwise
     // reloads the spilled originals inside the loop (4 scratch loads per frame on the kernel's one serial chain)
-    float* wloc = loc;
-    const float* wqd = my_qd;
-    if (MINW >= 3) asm volatile("" : "+v"(wloc), "+v"(wqd));  // (the builds with registers to spare lose 3 % to it)
+    // (the OFFSETS are laundered, not the pointers: an opaque pointer loses its LDS address space and every access through
+    // it becomes a 64-bit flat_load / flat_store instead of a ds_read / ds_write)
+    int wloc_off = QuadLds<N>::kLoc + gi_loc(g, n_ops), wqd_off = QuadLds<N>::kQd + gi * N;
+    if (MINW >= 3) asm volatile("" : "+v"(wloc_off), "+v"(wqd_off));  // (the builds with registers to spare lose 3 % to it)
+    float* wloc = lds + wloc_off;
+    const float* wqd = lds + wqd_off;
     const float4* rec4n = reinterpret_cast<const float4*>(wloc);
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2];
     // {axis, ctl} of the frame: wave-uniform, one 16-byte fetch per frame (scalar cache, or the staged copy), one ahead
@@ -921,15 +1145,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
 #pragma nounroll
   for (int pass = 0; pass < 2; ++pass) {
-    // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
-    double A[ROWS][N];
-    double fv[ROWS];
-#pragma unroll
-    for (int m = 0; m < ROWS; ++m) {
-      fv[m] = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) A[m][j] = 0.0;
-    }
+    if (!(ident_first && pass == 0)) zero_system();
 
     // row-joint records: world axis z_i and origin o_i of the joints that own MY rows (slot [p = o | v | a | z] of the
     // joint's frame), read once per pass instead of once per leaf frame
@@ -955,8 +1171,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // ---- leaves on FK task maps, frame by frame (only the frames that carry leaves) --------------
     // (scalar-cache walk: the frame's flattened record is fetched one frame ahead -- a dependent scalar fetch costs
     // ~200 cycles and the old chain leaf_ops[t] -> ops[k] -> fk_leaves[i] -> leaves[id] had four of them per frame)
-    const float* floc = loc;  // (loop-local copy, as in the walk)
-    if (MINW >= 3) asm volatile("" : "+v"(floc));
+    int floc_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);  // (loop-local copy, as in the walk: the offset, not the pointer)
+    if (MINW >= 3) asm volatile("" : "+v"(floc_off));
+    const float* floc = lds + floc_off;
     // explicit-pair plain builds with registers to spare (two waves per SIMD): the next leaf's pairs are prefetched
     // (MEASURED SLOWER and therefore off: holding the next leaf's 48 registers through the pull-back makes the 256-register
     // build spill 40 dwords in the frame loop -- 184.1 us per step at 65 536 robots against 123.7 without the prefetch)
@@ -1181,7 +1398,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         }
       }
     };
-    constexpr bool sym = SYM;
     if (!sym) mirror();
 
     switch (hdr.prio_tail) {  // (s_setprio takes an immediate)
@@ -1192,195 +1408,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     }
     RMP2_STAMP();  // 3: FK leaves done
     // ---- identity-task-map leaves (row layout) -------------------------------------------------
-    for (int li = 0; li < n_id; ++li) {
-      // (scalar-cache walk: the identity leaves follow the FK leaves in exec_leaves[], in execution order -- no index fetch)
-      const DevLeaf& lfr = STAGE ? leaves[uni<STAGE>(id_list[li])] : prog->exec_leaves[hdr.n_fk + li];
-      const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lfr);  // one 64-byte load
-      struct {
-        int kind, goal_offset;
-        const float* va;
-        const float* vb;
-      } lf = {uni<STAGE>(lh.kind), uni<STAGE>(lh.goal_offset), lfr.va, lfr.vb};
-      const float* P = lh.P;
-      if (lf.kind == RMP2_LEAF_JOINT_DAMPING || lf.kind == RMP2_LEAF_CSPACE_BIASING ||
-          lf.kind == RMP2_LEAF_CONFIG_SPACE_BIASING) {
-        // diagonal metrics m * I:  A_ii += m, f_i += m * xdd_i
-        float mdiag, nrm = 0.f;
-        if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {  // rmp2.py:127-137
-          float s2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) s2 += my_qd[j] * my_qd[j];
-          nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
-          mdiag = P[1] * nrm + P[2];
-        } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {  // rmp2.py:212-226
-          float s2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            const float e = my_q[j] - lf.va[j];
-            s2 += e * e;
-          }
-          nrm = sqrtf(s2);
-          mdiag = P[0] + P[4];
-        } else {  // rmp.py:330-347
-          mdiag = P[2];
-        }
-#pragma unroll
-        for (int m = 0; m < ROWS; ++m) {
-          const int i = sub + kQuad * m;
-          const int ii = i < N ? i : 0;
-          const float qi_ = my_q[ii], qdi = my_qd[ii];
-          float acc;
-          if (lf.kind == RMP2_LEAF_JOINT_DAMPING) {
-            acc = -(P[0] * nrm) * qdi;
-          } else if (lf.kind == RMP2_LEAF_CSPACE_BIASING) {
-            const float e = qi_ - (STAGE ? lf.va[ii] : pick4(lf.va, m, sub));
-            const float pos = (nrm < P[3]) ? (-e * P[1]) : (-P[3] * (e / nrm) * P[1]);
-            acc = pos + (-P[2] * qdi);
-          } else {
-            acc = P[0] * ((STAGE ? lf.va[ii] : pick4(lf.va, m, sub)) - qi_) - P[1] * qdi;
-          }
-          fv[m] += (double)(mdiag * acc);
-        }
-        // A_jj += m: column j's diagonal lives in local row j >> 2 of lane sub == (j & 3)
-        const double dm = (double)mdiag;
-#pragma unroll
-        for (int j = 0; j < N; ++j) A[j >> 2][j] += (sub == (j & 3)) ? dm : 0.0;
-      } else if (lf.kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
-        // rmp2.py:100-112: metric = w / (1 - diag(ratio^2)) evaluated on the FULL matrix (quirk Q4): every off-diagonal
-        // entry is w, the diagonal is w / (1 - ratio_i^2).  A constant plus a diagonal: no n x n loop of products --
-        //   A_ij += w ,  A_ii += d_i - w ,  f_i += w sum_j xdd_j + (d_i - w) xdd_i
-        const float cutoff = P[0] - P[1];
-        const float w = P[3] / 1.0f;
-        float xo[ROWS], dg[ROWS], sx = 0.f;
-#pragma unroll
-        for (int m = 0; m < ROWS; ++m) {
-          const int i = sub + kQuad * m;
-          const float qdj = my_qd[i < N ? i : 0];
-          const float dv = fabsf(qdj) - cutoff;
-          const float sgn = (qdj > 0.f) ? 1.f : (qdj < 0.f ? -1.f : 0.f);
-          const float acc = -fabsf(P[2] * dv) * sgn;
-          xo[m] = (i < n_dof && !(fabsf(qdj) < cutoff)) ? acc : 0.f;
-          const float ratio = fminf(dv, P[1] - 1e-6f) / P[1];
-          dg[m] = P[3] / (1.0f - ratio * ratio);
-          sx += xo[m];
-        }
-        sx = quad_sum(sx);
-        const double wd = (double)w;
-#pragma unroll
-        for (int m = 0; m < ROWS; ++m) {
-          const int i = sub + kQuad * m;
-          const bool row_ok = i < n_dof;
-          const double wr = row_ok ? wd : 0.0;
-          const double dd = row_ok ? (double)dg[m] - wd : 0.0;  // exact: A_ii = w + (d_i - w) = d_i
-#pragma unroll
-          for (int j = 0; j < N; ++j)
-            if (j < n_dof && (j >= kQuad * m || !sym)) A[m][j] += wr;  // (sym: the blocks below the diagonal are not kept)
-#pragma unroll
-          for (int c = 0; c < kQuad; ++c)
-            if (kQuad * m + c < N) A[m][kQuad * m + c] += (sub == c) ? dd : 0.0;
-          fv[m] += (double)(row_ok ? fmaf(w, sx, (dg[m] - w) * xo[m]) : 0.f);
-        }
-      } else {
-        // dense metrics  A_ij = cw_j * w * (beta zeta_i zeta_j + (1 - beta) delta_ij)
-        float zeta[N], xdd[N], cw[N], beta, wsc;
-        // each lane forms the terms of ITS dofs (i = sub + 4 m) once; the quad then broadcasts them (three DPP moves per
-        // dof and array) instead of every lane recomputing all n of them -- the divisions below are IEEE sequences
-        auto expand = [&](const float (&own)[ROWS], float (&full)[N]) {
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            const float v = own[j >> 2];
-            full[j] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
-          }
-        };
-        if (lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE) {
-          // rmp.py:357-382; A = w * H broadcasts over the LAST axis: column scaling (quirk Q2)
-          const float rr_ = 0.15f;
-          const float c2 = (float)(-3.0 / (0.15 * 0.15)), c3 = (float)(2.0 / (0.15 * 0.15 * 0.15));
-          const float iqd_max = (float)(60.0 / (20.0 * (2.0 * 3.14159265358979323846)));
-          float cw_o[ROWS], zeta_o[ROWS], xdd_o[ROWS], s2 = 0.f;
-#pragma unroll
-          for (int m = 0; m < ROWS; ++m) {
-            const int i = sub + kQuad * m;
-            const int ii = i < N ? i : 0;
-            const float qj = my_q[ii], qdj = my_qd[ii];
-            const float lo_ = STAGE ? lf.va[ii] : pick4(lf.va, m, sub), hi_ = STAGE ? lf.vb[ii] : pick4(lf.vb, m, sub);
-            const float irange = rcp1(hi_ - lo_);
-            const float du = (hi_ - qj) * irange;
-            const float dl = (qj - lo_) * irange;
-            const float d = fminf(du, dl);
-            const float spline = c3 * (d * d * d) + c2 * (d * d) + 0.f * d + 1.0f;
-            cw_o[m] = (i < n_dof) ? (d > rr_ ? 0.f : spline) : 0.f;
-            zeta_o[m] = (i < N) ? qdj * iqd_max : 0.f;
-            s2 += zeta_o[m] * zeta_o[m];
-            xdd_o[m] = -P[0] * qj - P[1] * qdj;
-          }
-          s2 = quad_sum(s2);
-          const float nrm = s2 > 0.f ? s2 * rsq1(s2) : 0.f;
-          // soft norm h = |v| + (1/c) log(1 + exp(-2 c |v|)), c = 5   (helper/rmp_helper.py:62-65)
-          const float hh = nrm + 0.2f * (0.693147182464599609375f * __builtin_amdgcn_logf(1.0f + exp1(-10.0f * nrm)));
-          const float ihh = rcp1(hh);
-#pragma unroll
-          for (int m = 0; m < ROWS; ++m) zeta_o[m] *= ihh;
-          expand(cw_o, cw);
-          expand(zeta_o, zeta);
-          expand(xdd_o, xdd);
-          beta = 0.9f;
-          wsc = 1.0f;
-        } else {
-          // TargetPolicy on the identity map, rmp.py:241-260 (goal is an n-vector)
-          const float alpha = P[0], beta_d = P[1], c = P[2];
-          float v[N], s2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            v[j] = (j < n_dof) ? my_goal[lf.goal_offset + j] - my_q[j] : 0.f;
-            s2 += v[j] * v[j];
-          }
-          const float vn = sqrtf(s2);
-          const float hq = vn + c * logf(1.0f + expf(-2.0f * c * vn));
-          const float inv_h = 1.0f / hq;
-          float f2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            xdd[j] = alpha * (inv_h * v[j]) - beta_d * my_qd[j];
-            f2 += xdd[j] * xdd[j];
-            cw[j] = 1.0f;
-          }
-          const float fn = sqrtf(f2);
-          const float hs = fn + 1.0f / c * logf(1.0f + expf(-2.0f * c * fn));
-#pragma unroll
-          for (int j = 0; j < N; ++j) zeta[j] = xdd[j] / hs;
-          beta = 1.0f - expf(-0.5f * (vn * vn) / 1.0f);
-          wsc = expf(-vn / 3.0f);
-        }
-        const float omb = 1.0f - beta;
-        const bool is_jla = lf.kind == RMP2_LEAF_JOINT_LIMIT_AVOIDANCE;
-        int sd = sub;  // (opaque copy, as for the walk's base row)
-        if (MINW >= 3) asm volatile("" : "+v"(sd));
-#pragma unroll
-        for (int m = 0; m < ROWS; ++m) {
-          const int i = sd + kQuad * m;
-          const bool row_ok = i < n_dof;
-          // zeta_i of MY row: select from the statically indexed vector
-          float zi = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) zi = (j == i) ? zeta[j] : zi;
-          float fi = 0.f;
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            if (j >= n_dof) continue;
-            // JointLimitAvoidance scales COLUMN j by the limit weight of joint j, which is exactly 0 unless
-            // that joint is inside its limit band: skip the column when that holds for the whole wave
-            if (is_jla && !__any(cw[j] != 0.f)) continue;
-            const float Hij = beta * (zi * zeta[j]) + omb * (j == i ? 1.f : 0.f);
-            float a = is_jla ? cw[j] * Hij : wsc * Hij;
-            a = row_ok ? a : 0.f;
-            if (!SYM || j >= kQuad * m) A[m][j] += (double)a;  // (sym: the blocks below the diagonal are not kept)
-            fi += a * xdd[j];
-          }
-          fv[m] += (double)fi;
-        }
-      }
-    }
+    if (!(ident_first && pass == 0)) identity_leaves();
 
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
@@ -1523,9 +1551,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       flagged = flagged || !finite;
       // slot 0 doubles as the qdd tile: a flagged robot keeps its slots for the careful pass below
       if (sub == 0 && !flagged) {
+        static_assert(N <= kSlot, "the qdd tile of a robot is its first frame slot");
+        int mo_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);  // (formed here: hoisted to the prologue it is spilled and reloaded per dof)
+        if (MINW >= 3) asm volatile("" : "+v"(mo_off));
+        float* mo = lds + mo_off;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          if (i < n_dof) my_out[i] = (float)x[i];
+        for (int i = 0; i < N; ++i) mo[i] = (float)x[i];  // (padding dofs resolve to 0; only n_dof values are stored to HBM)
       }
       RMP2_STAMP();  // 5: LU done
       if (!__any(flagged && live)) break;
@@ -1554,8 +1585,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }
       bool finite = true;
-      float* co = my_out;
-      if (MINW >= 3) asm volatile("" : "+v"(co));
+      int co_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);
+      if (MINW >= 3) asm volatile("" : "+v"(co_off));
+      float* co = lds + co_off;
       for (int i = 0; i < n_dof; ++i) {
         finite = finite && (fabs(xp[i]) < 1.7e308);
         if (sub == 0) co[i] = (float)xp[i];

@@ -99,7 +99,8 @@ class ObstacleExchange:
         cuda = self.device.type == "cuda"
         self.tables = [torch.zeros((self.world * spheres_per_rank, 4), dtype=torch.float32, device=self.device)
                        for _ in range(2)]
-        self.side = torch.cuda.Stream(self.device) if cuda else None
+        # (highest priority: the gather's few workgroups are dispatched ahead of the next step kernel's, which fill the GPU)
+        self.side = torch.cuda.Stream(self.device, priority=-1) if cuda else None
         # (fences, not torch events: a default event between two step kernels costs ~7 us of the step, see _Fence)
         fences = cuda and self.collective
         # ready[b]: "table b has been gathered".  At world 1 the gather is a local copy and a device-scope fence orders it;
@@ -167,6 +168,119 @@ class ObstacleExchange:
             if not attached:
                 ev.record(torch.cuda.current_stream(self.device))
             self.reader_done[self._last] = ev
+
+
+def rccl_library_path() -> str:
+    """The librccl.so this process already uses: PyTorch's own copy (torch/lib), else the ROCm installation's."""
+    import os
+    cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so"]
+    for c in cand:
+        if os.path.exists(c):
+            return c
+    raise RuntimeError("no librccl.so found next to torch or under /opt/rocm/lib")
+
+
+class NativeObstacleExchange:
+    """ObstacleExchange with the all-gather, the stream orderings and the step launch inside librmp2_hip.so
+    (include/rmp2.h rmp2_exchange_*): ONE C-ABI call per control step.  The Python-driven exchange above costs ~50 us of
+    host time per step (the c10d collective call alone ~20 us) -- more than the 44 us the step kernel takes, so a config-4
+    rank driven through it is host bound.  The RCCL communicator is the library's own (ncclCommInitRank on a unique id that
+    rank 0 creates and torch.distributed broadcasts); with no process group it is a communicator of one rank.
+
+        exch = NativeObstacleExchange(spheres_per_rank, device)      # collective over the default group
+        exch.start(local0)                                           # table of step 0
+        for k in ...: qdd = exch.step(engine, q, qd, goal, out, next_local=local_k_plus_1)
+    """
+
+    def __init__(self, spheres_per_rank: int, device, group=None):
+        import ctypes
+        from . import _native
+        self._lib = _native.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("NativeObstacleExchange needs a HIP device (the CPU test path uses ObstacleExchange)")
+        collective = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if collective else 1
+        self.rank = dist.get_rank(group) if collective else 0
+        self.spheres_per_rank = int(spheres_per_rank)
+        path = rccl_library_path().encode()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            rc = self._lib.rmp2_exchange_unique_id(path, buf)
+            if rc != 0:
+                raise _native.Rmp2Error("rmp2_exchange_unique_id: " + self._lib.rmp2_last_error(None).decode())
+            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        if collective and self.world > 1:
+            t = uid.to(self.device)
+            dist.broadcast(t, 0, group=group)
+            uid = t.cpu()
+        uid_buf = (ctypes.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+        self._h = ctypes.c_void_p()
+        rc = self._lib.rmp2_exchange_create(path, uid_buf, self.rank, self.world, self.device.index or 0,
+                                            self.spheres_per_rank, ctypes.byref(self._h))
+        if rc != 0:
+            raise _native.Rmp2Error("rmp2_exchange_create: " + self._lib.rmp2_last_error(None).decode())
+        self._table = ctypes.c_void_p()
+        self._ctypes = ctypes
+
+    def _check(self, rc):
+        if rc != 0:
+            from . import _native
+            raise _native.Rmp2Error(f"rmp2_exchange error {rc}: " + self._lib.rmp2_exchange_last_error(self._h).decode())
+
+    def set_peer_wait(self, on: bool = True) -> None:
+        """A one-rank exchange keeps the GPU-side wait an N-rank one needs (single-GPU emulation of an N-rank run)."""
+        self._check(self._lib.rmp2_exchange_set_peer_wait(self._h, 1 if on else 0))
+
+    @property
+    def pending(self) -> int:
+        """Gathers started and not yet consumed by a step."""
+        return int(self._lib.rmp2_exchange_pending(self._h))
+
+    def start(self, local: torch.Tensor, stream=None, local_is_ready: bool = False) -> None:
+        """Issue the gather of `local` [spheres_per_rank, 4] (contiguous fp32 on the device; it must stay untouched until the
+        gather has run).  local_is_ready: the caller guarantees `local` is complete now (no ordering event on `stream`)."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.rmp2_exchange_start(self._h, local.data_ptr(), 1 if local_is_ready else 0, s))
+
+    def bind(self, engine, q, qd, goal, out, next_local=None, stream=None, next_local_is_ready: bool = False):
+        """Pre-marshal the per-step call on FIXED buffers: returns launch() = one C-ABI call (wait for the oldest gathered
+        table, issue the gather of `next_local`, launch the step with the reader fence as its completion signal)."""
+        from . import descriptor as D
+        C = self._ctypes
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        goal_ptr = goal.data_ptr() if goal is not None else None
+        goal_stride = 0 if (goal is None or goal.dim() == 1) else engine.desc.goal_floats
+        fn, xh, eh = self._lib.rmp2_exchange_step, self._h, engine._h
+        qp, qdp, R = q.data_ptr(), qd.data_ptr(), q.shape[0]
+        nl = next_local.data_ptr() if next_local is not None else None
+        nlr = 1 if next_local_is_ready else 0
+        oref, tref = C.byref(o), C.byref(self._table)
+        keep = (q, qd, goal, out, next_local, o)
+
+        def launch(_keep=keep):
+            rc = fn(xh, eh, qp, qdp, goal_ptr, goal_stride, nl, nlr, oref, R, s, tref)
+            if rc:
+                self._check(rc)
+        return launch
+
+    def step(self, engine, q, qd, goal, out, next_local=None, stream=None, next_local_is_ready: bool = False):
+        self.bind(engine, q, qd, goal, out, next_local, stream, next_local_is_ready)()
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rmp2_exchange_destroy(self._h)
+            self._h = self._ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Fleet:
