@@ -829,7 +829,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // fp64 system, row-distributed: local row m holds global row i = sub + 4 m
   double A[ROWS][N];
   double fv[ROWS];
-  auto zero_system = [&]() {
+  auto zero_system = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
       fv[m] = 0.0;
@@ -839,7 +839,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   };
   constexpr bool sym = SYM;
   // ---- identity-task-map leaves (row layout): they need q and qd only, not the kinematics ------------------------
-  auto identity_leaves = [&]() {
+  auto identity_leaves = [&]() __attribute__((always_inline)) {
       for (int li = 0; li < n_id; ++li) {
         // (scalar-cache walk: the identity leaves follow the FK leaves in exec_leaves[], in execution order -- no index fetch)
         const DevLeaf& lfr = STAGE ? leaves[uni<STAGE>(id_list[li])] : prog->exec_leaves[hdr.n_fk + li];
@@ -933,7 +933,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           float zeta[N], xdd[N], cw[N], beta, wsc;
           // each lane forms the terms of ITS dofs (i = sub + 4 m) once; the quad then broadcasts them (three DPP moves per
           // dof and array) instead of every lane recomputing all n of them -- the divisions below are IEEE sequences
-          auto expand = [&](const float (&own)[ROWS], float (&full)[N]) {
+          auto expand = [&](const float (&own)[ROWS], float (&full)[N]) __attribute__((always_inline)) {
   #pragma unroll
             for (int j = 0; j < N; ++j) {
               const float v = own[j >> 2];
@@ -1143,8 +1143,13 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   }
   RMP2_STAMP();  // 2: walk done
 
-#pragma nounroll
-  for (int pass = 0; pass < 2; ++pass) {
+  // One accumulation + resolve pass over the wave's robots.  PASS 0 is the fast path (elimination without row exchanges);
+  // PASS 1 re-accumulates and runs the careful solver for the robots PASS 0 flagged.  Two INSTANTIATIONS of one body, not a
+  // two-trip loop: inside a loop every lane predicate of the resolve (sub == c, i < n_dof, ...) is loop invariant, gets
+  // hoisted in front of the loop and stays live -- as an SGPR pair parked in a VGPR lane -- through the whole frame loop
+  // (round 2: ~100 v_writelane before the loop, ~250 v_readlane inside it).  The second copy is cold code.
+  auto run_pass = [&](auto pass_c) __attribute__((always_inline)) {
+    constexpr int pass = decltype(pass_c)::value;
     if (!(ident_first && pass == 0)) zero_system();
 
     // row-joint records: world axis z_i and origin o_i of the joints that own MY rows (slot [p = o | v | a | z] of the
@@ -1377,7 +1382,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     // Sets whose leaves are all symmetric (hdr.sym) never need the lower blocks on the fast path: the identity leaves
     // add symmetric terms and the elimination takes its multipliers from the broadcast pivot row (M[i][k] = M[k][i]);
     // the mirror is then only run for the debug output of M and for the careful solver of a flagged robot.
-    auto mirror = [&]() {
+    auto mirror = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int m = 1; m < ROWS; ++m) {
 #pragma unroll
@@ -1466,7 +1471,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         if (n_dof > 1) my_out[1] = (float)x1;
       }
       flagged = false;
-      break;
+      return;
     } else if (pass == 0) {
       // ---- resolve: row-distributed fp64 elimination without row exchanges -------------------
       // (certification and fall-through exactly as lu_solve<N>, rmp2_solve.h)
@@ -1474,7 +1479,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       double inv_piv[N];
       // symmetric sets: only the block-upper part (row block m, columns >= 4 m) is read and updated;
       // a multiplier whose entry lies below the diagonal blocks is taken from the broadcast pivot row, M[i][k] = M[k][i]
-      auto eliminate = [&](auto symc) {
+      auto eliminate = [&](auto symc) __attribute__((always_inline)) {
         constexpr bool SYME = decltype(symc)::value;
         double scale = 0.0;
 #pragma unroll
@@ -1559,7 +1564,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         for (int i = 0; i < N; ++i) mo[i] = (float)x[i];  // (padding dofs resolve to 0; only n_dof values are stored to HBM)
       }
       RMP2_STAMP();  // 5: LU done
-      if (!__any(flagged && live)) break;
+      return;  // (the caller runs the careful pass if any robot of the wave was flagged)
     } else if (flagged) {
       // ---- rare path: gather the whole system into every lane of the quad, careful solve -------
       if (sym) mirror();  // (the fast path of a symmetric set keeps the block-upper part only)
@@ -1594,7 +1599,9 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       }
       if (!finite) status |= RMP2_STATUS_NONFINITE;
     }
-  }
+  };
+  run_pass(std::integral_constant<int, 0>{});
+  if (N != 2 && __any(flagged && live)) run_pass(std::integral_constant<int, 1>{});
   if (ro.substeps > 0) {
     // plant: qdd held, semi-implicit Euler (qd += dt qdd; q += dt qd); every lane advances ITS dofs
     int gio = gi;
