@@ -46,6 +46,9 @@ WORKLOADS = {
                     name="Franka Panda, target + joint-limit + damping, 4096 robots/GPU (BASELINE configs[1])"),
     "config3": dict(robots=65536, bytes=120, flops=66.0e3,
                     name="Franka Panda cluttered: 8 control points x 32 shared spheres, 65536 robots/GPU (BASELINE configs[2])"),
+    "config3c": dict(robots=65536, bytes=120, flops=66.0e3,
+                     name="Franka Panda cluttered with CAPSULE obstacles (the reference's cylinders, simulation.py:495-500, as "
+                          "capsules): 8 control points x 32 shared capsules, 65536 robots/GPU"),
     "config3b": dict(robots=65536, bytes=6264, flops=66.0e3, bound="hbm",
                      name="Franka Panda cluttered, interface B: 256 explicit closest-point pairs per robot (p_link, p_obs "
                           "[R, 256, 3], the reference's Datamanager layout), 65536 robots/GPU (BASELINE.md section 3 row 3-B)"),
@@ -376,7 +379,9 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         return launch, eng, desc, table, s, None, keep
     K = Cf.N_SPHERES
     spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
-    if workload == "config3":
+    if workload == "config3c":
+        spheres_np = Cf.sample_capsules(np.random.default_rng(7), K)
+    if workload in ("config3", "config3c"):
         obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
         launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
         return launch, eng, desc, table, s, spheres_np, keep
@@ -613,7 +618,7 @@ def worker(args) -> int:
     desc = table = s = None
     bound = "valu"
 
-    if workload in ("config2", "config3", "config3b", "config4"):
+    if workload in ("config2", "config3", "config3b", "config3c", "config4"):
         one_step, eng, desc, table, s, spheres_np, keep = build_config34(workload, args, dev, local_rank, rank, world, R)
         kern = timer.run(one_step, args.steps, args.warmup)
         # result check, outside the timed region: the buffers the timed steps wrote, against the oracle

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RMP2_ABI_VERSION 1
+#define RMP2_ABI_VERSION 2
 
 #define RMP2_MAX_FRAMES 32  /* frames (= URDF joints) per robot type                    */
 #define RMP2_MAX_DOF 16     /* actuated joints per robot type                            */
@@ -302,12 +302,17 @@ int rmp2_step(rmp2_handle *h, const float *q, const float *qd, const float *goal
  * q and qd (device, [R][n_dof]) are advanced IN PLACE; out->qdd receives the last qdd, out->status the
  * OR of the per-step status words.  Goals and the sphere table are constant during the rollout;
  * RMP2_OBS_EXPLICIT_PAIRS is rejected (closest-point pairs are only valid for the state they were
- * computed at).  Resolve semantics are those of RMP2_SOLVE_AUTO; a handle created with RMP2_SOLVE_PINV is refused
- * (RMP2_ERR_UNSUPPORTED) rather than silently resolved differently from what was asked for. */
+ * computed at).  A handle created with RMP2_SOLVE_PINV rolls out with the strict pseudo-inverse on every robot and step (the
+ * 16-lanes-per-robot mapping at any fleet size; RMP2_ERR_UNSUPPORTED where that mapping cannot hold the program) -- never
+ * resolved differently from what was asked for. */
 typedef struct rmp2_rollout_cfg {
   int32_t n_control_steps;
   int32_t substeps;
   float dt;
+  int32_t table_steps; /* obstacle motion inside the rollout (the reference re-reads the obstacle data every control step,
+                          06_cluttered_environment.py:120-131): 0 or 1 = one table for all control steps; n_control_steps =
+                          one table per control step, obs->spheres then holds [n_control_steps][n_spheres][4 (spheres) or 8
+                          (capsules)] and control step k reads table k (sphere modes only; ragged lists index every table) */
 } rmp2_rollout_cfg;
 
 int rmp2_rollout(rmp2_handle *h, float *q, float *qd, const float *goal, int32_t goal_stride,

@@ -612,8 +612,28 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     bad = bad || (__builtin_popcount(member_lo) + __builtin_popcount(member_hi) != count);
     use_member = !__any(bad);
   }
+  const int n_iters_blk = ROLL ? ro.n_iters : 1;  // (uniform over the block: tail waves meet the barriers below without stepping)
 #pragma nounroll
-  for (int it = 0; ROLL ? (it < n_iters) : (it == 0 && n_live > 0); ++it) {
+  for (int it = 0; ROLL ? (it < n_iters_blk) : (it == 0 && n_live > 0); ++it) {
+  // moving obstacles (RolloutArgs::table_stride): control step `it` reads table `it`.  The LDS image is shared by the
+  // block's waves: every wave must be through with table it - 1 before it is overwritten, and see table it before reading
+  const float* const step_table = obs.spheres + (size_t)it * (size_t)(ROLL ? ro.table_stride : 0);
+  if (ROLL && ro.table_stride != 0 && it > 0 && n_sph_lds > 0) {
+    if (WAVES > 1) __syncthreads(); else hex_sync();
+    constexpr int kBlk2 = kWave * WAVES;
+    const int tid2 = threadIdx.x;
+    for (int i = tid2; i < (CAP ? 2 : 1) * n_sph_lds; i += kBlk2) {
+      const float4 sv2 = reinterpret_cast<const float4*>(step_table)[i];
+      if (CAP) {
+        reinterpret_cast<float4*>(sph_lds_base)[i] = sv2;
+      } else {
+        reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(sv2, hdr.cull_c0);
+        sph_lds_base[4 * n_sph_lds + i] = sv2.w;
+      }
+    }
+    if (WAVES > 1) __syncthreads(); else hex_sync();
+  }
+  if (ROLL && it >= n_iters) continue;
   // ---- kinematics of all frames (hex_kinematics below): world transforms, J qd and Jdot qd of every origin ------
   const float* TW;
   if (n_ops <= kHex)
@@ -754,7 +774,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
             pair_loop<kPairsSharedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, s,
                                                   P3, V3, A3, lh.P, IP, S, h);
           else
-            pair_loop<kPairsSharedGlobal, CAP, kHex>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres,
+            pair_loop<kPairsSharedGlobal, CAP, kHex>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres,
                                                      s, P3, V3, A3, lh.P, IP, S, h);
         } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
           const int lidx = uni<true>(lf.index);
@@ -779,7 +799,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
             pair_loop<kPairsRaggedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
                                                   P3, V3, A3, lh.P, IP, S, h);
           else
-            pair_loop<kPairsRaggedGlobal, CAP, kHex>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
+            pair_loop<kPairsRaggedGlobal, CAP, kHex>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
                                                      P3, V3, A3, lh.P, IP, S, h);
         }
 #pragma unroll

@@ -1228,9 +1228,13 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //     hex    9.0   10.1   12.0   17.1   18.9   27.7   52.5
   //     quad  11.3   11.9   11.9   12.3   12.2   12.4   15.5
   const int hex_max = h->has_point ? 20480 : 8192;
-  if (hex_ok && (h->kernel_choice == 3 || (h->kernel_choice == 0 && R <= hex_max)) &&
+  // the fused rollout of a solve = PINV handle (the reference's only resolve, rmp.py:153-154, inside the closed loop): the hex
+  // mapping carries the strict pseudo-inverse through its careful path at any fleet size
+  const bool strict_rollout = h->strict && rollout;
+  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max)) &&
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
+  if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (the quad mapping's resolve is AUTO: never a silent change of semantics)
   const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && R > 32768));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
@@ -1578,7 +1582,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
 
 int rmp2_step(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
               const rmp2_obstacles* obs, const rmp2_outputs* out, int32_t R, void* stream) {
-  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr};
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr, 0};
   return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
 }
 
@@ -1775,7 +1779,7 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   o.spheres = x->table[b];
   void* const saved = h->step_fence;
   h->step_fence = x->reader_done[b];
-  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr};
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr, 0};
   const int rc = step_impl(h, q, qd, goal, goal_stride, &o, out, ro, R, stream);
   h->step_fence = saved;
   if (rc != RMP2_OK) return x->error = h->error, rc;
@@ -1792,12 +1796,14 @@ int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t
     return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: need n_control_steps >= 1, substeps >= 0, dt >= 0");
   if (obs && obs->mode == RMP2_OBS_EXPLICIT_PAIRS)
     return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: explicit closest-point pairs go stale as the robots move; use a sphere mode");
-  if (h->strict)
-    return fail(h, RMP2_ERR_UNSUPPORTED,
-                "rollout: solve = PINV (the strict pseudo-inverse for every robot) exists for single control steps only; "
-                "create the engine with RMP2_SOLVE_AUTO (same result wherever M is well conditioned, pseudo-inverse "
-                "fall-through per robot otherwise)");
-  const RolloutArgs ro{cfg->n_control_steps, cfg->substeps, cfg->dt, q, qd};
+  RolloutArgs ro{cfg->n_control_steps, cfg->substeps, cfg->dt, q, qd, 0};
+  if (cfg->table_steps > 1) {
+    if (cfg->table_steps != cfg->n_control_steps)
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: table_steps must be 0, 1 or n_control_steps");
+    if (!obs || (obs->mode != RMP2_OBS_SHARED_SPHERES && obs->mode != RMP2_OBS_RAGGED_SPHERES))
+      return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: per-step obstacle tables need a sphere / capsule table mode");
+    ro.table_stride = obs->n_spheres * (obs->primitive == RMP2_PRIM_CAPSULE ? 8 : 4);
+  }
   return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
 }
 

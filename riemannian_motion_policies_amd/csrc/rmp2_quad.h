@@ -281,6 +281,10 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
 // Table image in LDS for K spheres: K x float4 {-2cx, -2cy, -2cz, w} followed by K radii.
 constexpr float kCullSlack = 1.0002f;
 __host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
+// quad mapping: capsule tables keep only the four-float range-test records in LDS (bounding sphere of the capsule); the
+// capsule itself (8 floats) is fetched from global memory by the lanes that evaluate an in-range pair -- 512 B for 32
+// capsules instead of 1 024: the wave's LDS stays within the 10 240 B that let sixteen waves share a CU
+__host__ __device__ constexpr int quad_table_floats(bool cap, int k) { return cap ? 4 * k : ((5 * k + 3) & ~3); }
 
 __device__ __forceinline__ float4 sphere_aux(const float4 sp, float c0) {
   const float thr = fmaxf(sp.w + c0, 0.f);
@@ -316,12 +320,16 @@ __device__ __forceinline__ int select_bit(uint32_t m, int r) {
 // MEMBER: the robot sees only the spheres whose bit is set in (member_lo, member_hi) -- a ragged list over a table of at
 // most 64 spheres IS a membership mask: the loop then runs in the dense form (positions are sphere indices read from
 // LDS) and the in-range mask is ANDed with it; no dependent global load of a list entry per test slot and per trip.
-template <bool RAGGED, int W, bool SKIP = false, bool MEMBER = false>
+// CAPS: the primitives are capsules (`caps`: the caller's [K][8] table in global memory = (a, radius, b, -)); the staged
+// records test the capsule's bounding sphere (centre = midpoint of the axis, radius = half length + capsule radius), the
+// exact nearest point of the axis is formed for the in-range pairs only (one trip ahead of its use).
+template <bool RAGGED, int W, bool SKIP = false, bool MEMBER = false, bool CAPS = false>
 __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, const int32_t* ci, int count, int max_count,
                                                  int sub, const float P3[3], const float V3[3], const float A3[3],
                                                  const float* P, const float* IP, float S[6], float h[3],
                                                  unsigned long long* dbg = nullptr, uint32_t member_lo = 0u,
-                                                 uint32_t member_hi = 0u) {
+                                                 uint32_t member_hi = 0u, const float* caps = nullptr) {
+  static_assert(!(CAPS && W != 4), "capsule culling exists in the quad mapping");
   static_assert(!(RAGGED && MEMBER), "a membership mask replaces the list");
   static_assert(W == 4 || W == 16, "quad or hex");
   const float4* aux = reinterpret_cast<const float4*>(tab);
@@ -364,27 +372,63 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
 #ifdef RMP2_STAMPS
     if (dbg) dbg[1] += (unsigned long long)total;  // in-range pairs of the first robot of the wave
 #endif
+    // next pair of this lane: (on, index into the table); CAPS: its capsule record, fetched one trip ahead
+    auto take = [&](bool& on_, int& sidx_) __attribute__((always_inline)) {
+      on_ = (W == 4) ? (rem != 0u) : (rank < total);
+      int j = 0;
+      if (W == 4) {
+        j = on_ ? (__builtin_ffs((int)rem) - 1) : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rem &= rem - 1u;   // (0 & anything stays 0)
+      } else {
+        j = on_ ? select_bit(m, rank) : 0;
+        rank += W;
+      }
+      const int pos = base + j;
+      sidx_ = on_ ? pos : 0;
+      if (RAGGED) sidx_ = on_ ? ci[pos] : 0;
+    };
+    bool on_n = false;
+    int sidx_n = 0;
+    float4 ca_n = make_float4(0.f, 0.f, 0.f, 0.f), cb_n = ca_n;
+    if (CAPS) {
+      take(on_n, sidx_n);
+      ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
+      cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+    }
     while (true) {
-      const bool on = (W == 4) ? (rem != 0u) : (rank < total);
+      bool on;
+      int sidx;
+      float4 ca, cb;
+      if (CAPS) {
+        on = on_n, sidx = sidx_n, ca = ca_n, cb = cb_n;
+      } else {
+        take(on, sidx);
+      }
       if (!__any(on)) break;
 #ifdef RMP2_STAMPS
       if (dbg) dbg[0] += 1ull;  // trips of the wave
 #endif
-      int j = 0;
-      if (W == 4) {
-        j = on ? (__builtin_ffs((int)rem) - 1) : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rem &= rem - 1u;   // (0 & anything stays 0)
+      float diff[3], r;
+      if (CAPS) {
+        take(on_n, sidx_n);
+        ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
+        cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+        // nearest point of the capsule axis a-b to the control point (rmp2_device.h capsule_centre; same arithmetic as the
+        // un-culled loop above)
+        const float u[3] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
+        const float w[3] = {P3[0] - ca.x, P3[1] - ca.y, P3[2] - ca.z};
+        const float uu = dot3(u, u);
+        float t = uu > 0.f ? dot3(w, u) * rcp1(uu) : 0.f;
+        t = fminf(fmaxf(t, 0.f), 1.f);
+        const float ctr[3] = {fmaf(t, u[0], ca.x), fmaf(t, u[1], ca.y), fmaf(t, u[2], ca.z)};
+        diff[0] = P3[0] - ctr[0], diff[1] = P3[1] - ctr[1], diff[2] = P3[2] - ctr[2];
+        r = ca.w;
       } else {
-        j = on ? select_bit(m, rank) : 0;
-        rank += W;
+        const float4 a = aux[sidx];
+        r = rad[sidx];
+        diff[0] = fmaf(0.5f, a.x, P3[0]), diff[1] = fmaf(0.5f, a.y, P3[1]), diff[2] = fmaf(0.5f, a.z, P3[2]);  // p - c, exactly
       }
-      const int pos = base + j;
-      int sidx = on ? pos : 0;
-      if (RAGGED) sidx = on ? ci[pos] : 0;
-      const float4 a = aux[sidx];
-      const float r = rad[sidx];
-      const float diff[3] = {fmaf(0.5f, a.x, P3[0]), fmaf(0.5f, a.y, P3[1]), fmaf(0.5f, a.z, P3[2])};  // p - c, exactly
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
       const float inv = rsq0(d2);
       const float d = d2 * inv - r;
@@ -570,6 +614,9 @@ struct RolloutArgs {
   float dt;
   float* q_out;
   float* qd_out;
+  // obstacle motion inside the rollout (06_cluttered_environment.py:120-131 re-reads the obstacle data every control step):
+  // floats between the tables of consecutive control steps ([n_iters][K][4 or 8] behind obs.spheres); 0 = one table
+  int32_t table_stride = 0;
 };
 
 struct QuadHdr {
@@ -616,17 +663,22 @@ __device__ __forceinline__ int uni(int v) {
 // other modes' code: no per-lane 64-bit addresses of pair arrays, CSR lists, debug rows or rollout outputs for the
 // compiler to hoist into the prologue and park in scratch (what the 128-register build spilled in round 2).
 constexpr int kObsAny = -1;
-template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, bool PLAIN = false>
+// FLAVOR: kGeneral = everything at run time (debug outputs M / f, rollout loop, any obstacle mode); kPlainStep = one control
+// step, no debug outputs, OBS fixed; kPlainRollout = the fused rollout loop, no debug outputs, OBS fixed (sphere-table modes).
+constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
+template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
                       OutArgs out, RolloutArgs ro_arg, int R) {
   const int obs_mode = OBS == kObsAny ? obs.mode : OBS;
-  const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr} : ro_arg;
+  constexpr bool PLAIN = FLAVOR == kPlainStep;   // no rollout loop
+  constexpr bool LEAN = FLAVOR != kGeneral;      // no debug outputs
+  const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr, 0} : ro_arg;
 #ifdef RMP2_STAMPS
-  if (PLAIN) out.M = nullptr;  // (diagnostic build: the stamps travel behind the f rows, so the plain build keeps that pointer)
+  if (LEAN) out.M = nullptr;  // (diagnostic build: the stamps travel behind the f rows, so the plain build keeps that pointer)
 #else
-  if (PLAIN) out.M = nullptr, out.f = nullptr;
+  if (LEAN) out.M = nullptr, out.f = nullptr;
 #endif
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
   constexpr bool kIdentFirst = SYM && PLAIN && MINW >= 3 && RMP2_IDENT_FIRST;  // (see "Phase order per wave" below)
@@ -671,7 +723,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   float* const sph_lds_base = lds + QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(n_ops);  // 16-byte aligned
   const uint32_t rev_mask = hdr.rev_mask;
   // staged copies (STAGE) live behind the local-transform records
-  float* const stage_base = sph_lds_base + sphere_lds_floats(CAP, n_sph_lds);
+  float* const stage_base = sph_lds_base + quad_table_floats(CAP, n_sph_lds);
   DevOp* const s_ops = reinterpret_cast<DevOp*>(stage_base);
   DevLeaf* const s_leaves = reinterpret_cast<DevLeaf*>(s_ops + n_ops);
   int32_t* const s_fk = reinterpret_cast<int32_t*>(s_leaves + hdr.n_leaves);
@@ -684,6 +736,25 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const int32_t* const id_list = STAGE ? s_id : prog->id_leaves;
   const int32_t* const leaf_ops = STAGE ? s_lo : prog->leaf_ops;
   const int n_live = min(kRobotsPerWave, R - r0);
+  // the obstacle table's LDS image (no barrier inside: the caller owns the ordering against its readers)
+  auto stage_table = [&](const float* table) __attribute__((always_inline)) {
+    if (CAP) {  // range-test records of the capsules' bounding spheres (the capsules themselves stay in global memory)
+      for (int i = lane; i < n_sph_lds; i += kWave) {
+        const float4 ca = reinterpret_cast<const float4*>(table)[2 * i];
+        const float4 cb = reinterpret_cast<const float4*>(table)[2 * i + 1];
+        const float hx = 0.5f * (cb.x - ca.x), hy = 0.5f * (cb.y - ca.y), hz = 0.5f * (cb.z - ca.z);
+        const float hl = sqrtf(hx * hx + hy * hy + hz * hz) * 1.000001f;  // (rounded up: the test must never under-cover)
+        reinterpret_cast<float4*>(sph_lds_base)[i] =
+            sphere_aux(make_float4(ca.x + hx, ca.y + hy, ca.z + hz, ca.w + hl), hdr.cull_c0);
+      }
+    } else {  // image for the culled pair loop: {-2c, |c|^2 - thr^2} records, then the radii
+      for (int i = lane; i < n_sph_lds; i += kWave) {
+        const float4 sp = reinterpret_cast<const float4*>(table)[i];
+        reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(sp, hdr.cull_c0);
+        sph_lds_base[4 * n_sph_lds + i] = sp.w;
+      }
+    }
+  };
   {
     const int tile = n_live * n_dof;
     const float* gq = q + (size_t)r0 * n_dof;
@@ -701,17 +772,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         lds[QuadLds<N>::kQd + rr * N + jj] = 0.f;
       }
     }
-    if (obs_mode == RMP2_OBS_SHARED_SPHERES || obs_mode == RMP2_OBS_RAGGED_SPHERES) {
-      if (CAP) {
-        for (int i = lane; i < 8 * n_sph_lds; i += kWave) sph_lds_base[i] = obs.spheres[i];
-      } else {  // image for the culled pair loop: {-2c, |c|^2 - thr^2} records, then the radii
-        for (int i = lane; i < n_sph_lds; i += kWave) {
-          const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[i];
-          reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(sp, hdr.cull_c0);
-          sph_lds_base[4 * n_sph_lds + i] = sp.w;
-        }
-      }
-    }
+    if (obs_mode == RMP2_OBS_SHARED_SPHERES || obs_mode == RMP2_OBS_RAGGED_SPHERES) stage_table(obs.spheres);
     if (STAGE) {
       const uint4* src = reinterpret_cast<const uint4*>(prog->ops);
       uint4* dst = reinterpret_cast<uint4*>(s_ops);
@@ -753,7 +814,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   // twice): such a wave keeps the list walk.
   uint32_t member_lo = 0u, member_hi = 0u;
   bool use_member = false;
-  if (obs_mode == RMP2_OBS_RAGGED_SPHERES && !CAP && obs.n_spheres <= 64) {
+  if (obs_mode == RMP2_OBS_RAGGED_SPHERES && obs.n_spheres <= 64) {
     const int rr_ = live ? robot : 0;
     const int b0 = obs.csr_offset[rr_];
     const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
@@ -781,6 +842,12 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   for (int it = 0; it < ro.n_iters; ++it) {
   __builtin_amdgcn_s_setprio(3);  // (every control step of a fused rollout starts over)
   flagged = false;
+  // moving obstacles: control step `it` reads table `it` (one wave per block: the LDS image is the wave's own; its readers of
+  // the previous step are done -- same wave, program order -- and the barrier of phase 1 below publishes the new image)
+  const float* const step_table = obs.spheres + (size_t)it * (size_t)(!PLAIN ? ro.table_stride : 0);
+  if (!PLAIN && ro.table_stride != 0 && it > 0 &&
+      (obs_mode == RMP2_OBS_SHARED_SPHERES || obs_mode == RMP2_OBS_RAGGED_SPHERES))
+    stage_table(step_table);
   // ---- phase 1: local transforms T_constant @ T_variable(q) of ALL frames, in parallel -------
   // (kinematics.py:222-240).  They do not depend on the chain, so lane `sub` of the quad builds
   // the frames k = sub, sub+4, ... (branch-free: the joint type selects by arithmetic) and
@@ -1252,19 +1319,16 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
           if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
-            if (spheres_in_lds && !CAP)
+            if (spheres_in_lds)
 #ifdef RMP2_STAMPS
-              pair_loop_culled<false, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
-                                             IP, S, h, &seg_[5]);
+              pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                     V3, A3, lh.P, IP, S, h, &seg_[5], 0u, 0u, step_table);
 #else
-              pair_loop_culled<false, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3, A3, lh.P,
-                                             IP, S, h);
+              pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                     V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
 #endif
-            else if (spheres_in_lds)
-              pair_loop<kPairsSharedLds, CAP>(sph_lds, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
-                                         A3, lh.P, IP, S, h);
             else
-              pair_loop<kPairsSharedGlobal, CAP>(obs.spheres, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
+              pair_loop<kPairsSharedGlobal, CAP>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
                                             P3, V3, A3, lh.P, IP, S, h);
           } else if (obs_mode == RMP2_OBS_EXPLICIT_PAIRS) {
             const int lidx = uni<STAGE>(lf.index);
@@ -1297,8 +1361,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
                                                thr * thr * kCullSlack, S, h);
             }
           } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
-            pair_loop_culled<false, kQuad, (MINW >= 2), true>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3, V3,
-                                                             A3, lh.P, IP, S, h, nullptr, member_lo, member_hi);
+            pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                  V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);
           } else {
             int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
             if (MINW >= 3) asm volatile("" : "+v"(rr_));
@@ -1307,14 +1371,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             int max_count = count;
 #pragma unroll
             for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
-            if (spheres_in_lds && !CAP)
-              pair_loop_culled<true, kQuad, (MINW >= 2)>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3, V3, A3, lh.P,
-                                            IP, S, h);
-            else if (spheres_in_lds)
-              pair_loop<kPairsRaggedLds, CAP>(sph_lds, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub, P3, V3,
-                                         A3, lh.P, IP, S, h);
+            if (spheres_in_lds)
+              pair_loop_culled<true, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3,
+                                                                    V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
             else
-              pair_loop<kPairsRaggedGlobal, CAP>(obs.spheres, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
+              pair_loop<kPairsRaggedGlobal, CAP>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
                                             P3, V3, A3, lh.P, IP, S, h);
           }
           RMP2_SEG(2);  // distance leaf: cull + pair trips
@@ -1417,7 +1478,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 
     RMP2_STAMP();  // 4: identity leaves done
     // optional debug outputs: the combined metric / force before the resolve
-    if (!PLAIN && pass == 0 && live && (out.M || out.f)) {
+    if (!LEAN && pass == 0 && live && (out.M || out.f)) {
       // (the 64-bit row addresses are formed HERE, from an opaque copy of the robot index: hoisted to the prologue -- where
       // the compiler otherwise puts them -- they are spilled by every wave of the register-capped builds and read back
       // only when the debug outputs are asked for)
@@ -1479,6 +1540,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       double inv_piv[N];
       // symmetric sets: only the block-upper part (row block m, columns >= 4 m) is read and updated;
       // a multiplier whose entry lies below the diagonal blocks is taken from the broadcast pivot row, M[i][k] = M[k][i]
+      bool nonfinite_matrix = false;
       auto eliminate = [&](auto symc) __attribute__((always_inline)) {
         constexpr bool SYME = decltype(symc)::value;
         double scale = 0.0;
@@ -1490,6 +1552,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         scale = fmax(scale, dppd<kXor2>(scale));
         const double tiny = 1e-11 * scale;
         flagged = !(scale > 0.0) || !(scale < 1.7e308);
+        nonfinite_matrix = !(scale < 1.7e308);  // (NaN compares false: NaN or Inf somewhere in the metric)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
           const int ks = k & 3, km = k >> 2;
@@ -1554,6 +1617,25 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
       for (int i = 0; i < N; ++i)
         if (i < n_dof) finite = finite && (fabs(x[i]) < 1.7e308);
       flagged = flagged || !finite;
+      // A system that is not finite to begin with (NaN / Inf state, e.g. a robot past the JointVelocityCap pole, quirk Q4)
+      // resolves to NaN in the reference (tf.linalg.pinv of a NaN matrix) and in the careful solver; it is settled HERE --
+      // q-double-dot = NaN, status NONFINITE -- instead of sending its whole wave through the second pass: in a closed-loop
+      // rollout such a robot stays non-finite for the rest of the horizon and would cost its wave a second frame loop
+      // every control step (the launch waits for its slowest wave).
+      {
+        double fs = 0.0;
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) fs = fmax(fs, fabs(fv[m]) < 1.7e308 ? 0.0 : 1.0);
+        fs = fmax(fs, dppd<kXor1>(fs));
+        fs = fmax(fs, dppd<kXor2>(fs));
+        const bool sys_nonfinite = nonfinite_matrix || fs > 0.0;
+        if (sys_nonfinite) {
+#pragma unroll
+          for (int i = 0; i < N; ++i) x[i] = __builtin_nan("");
+          status |= RMP2_STATUS_NONFINITE | RMP2_STATUS_PINV_PATH;
+          flagged = false;
+        }
+      }
       // slot 0 doubles as the qdd tile: a flagged robot keeps its slots for the careful pass below
       if (sub == 0 && !flagged) {
         static_assert(N <= kSlot, "the qdd tile of a robot is its first frame slot");

@@ -12,7 +12,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const int n_sph_lds = (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES)
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
-                                            sphere_lds_floats(o.capsule, n_sph_lds));
+                                            quad_table_floats(o.capsule, n_sph_lds));
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
@@ -31,7 +31,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   // two waves up to ceil(b) = 3 and for 5 and 6, four for 4 and from 7 on.  Sets with a JointLimitAvoidance leaf (general
   // form, 48-56 spilled dwords at 128 registers) keep two waves.
   const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
-  const bool symk = h->symmetric && N == 9 && !o.capsule;
+  const bool symk = h->symmetric && N == 9;
   int minw = h->quad_minw;
   if (minw == 0) {
     const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
@@ -42,38 +42,63 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   }
   const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
-#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, PLAIN)                                                             \
-  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, PLAIN>), dim3(blocks), dim3(kWave), bytes, s, \
+#define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, FLAVOR)                                                            \
+  RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, FLAVOR>), dim3(blocks), dim3(kWave), bytes, s, \
                    h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
   // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
   // template with sphere tables (symk above); everything else takes the general form
 #define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \
   do {                                                                                                                  \
-    if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false, kObsAny, false);                                          \
-    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9), kObsAny, false);                                      \
-    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false, kObsAny, false);                                                   \
+    if (o.capsule && symk) RMP2_QUAD_LAUNCH(MINW, STAGE, true, (N == 9), kObsAny, kGeneral);                               \
+    else if (o.capsule) RMP2_QUAD_LAUNCH(MINW, STAGE, true, false, kObsAny, kGeneral);                                     \
+    else if (symk) RMP2_QUAD_LAUNCH(MINW, STAGE, false, (N == 9), kObsAny, kGeneral);                                      \
+    else RMP2_QUAD_LAUNCH(MINW, STAGE, false, false, kObsAny, kGeneral);                                                   \
   } while (0)
   // plain control steps of the throughput builds (no debug outputs, no rollout, sphere primitives): one instantiation per
   // obstacle mode
 #define RMP2_QUAD_PLAIN_SYM(MINW, SYM)                                                                                  \
   do {                                                                                                                  \
     switch (o.mode) {                                                                                                   \
-      case RMP2_OBS_SHARED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_SHARED_SPHERES, true); break;    \
-      case RMP2_OBS_RAGGED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_RAGGED_SPHERES, true); break;    \
-      case RMP2_OBS_EXPLICIT_PAIRS: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_EXPLICIT_PAIRS, true); break;    \
-      default: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_NONE, true); break;                                   \
+      case RMP2_OBS_SHARED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_SHARED_SPHERES, kPlainStep); break;    \
+      case RMP2_OBS_RAGGED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_RAGGED_SPHERES, kPlainStep); break;    \
+      case RMP2_OBS_EXPLICIT_PAIRS: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_EXPLICIT_PAIRS, kPlainStep); break;    \
+      default: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_NONE, kPlainStep); break;                                   \
     }                                                                                                                   \
   } while (0)
 #define RMP2_QUAD_PLAIN(MINW)                                                                                           \
   do {                                                                                                                  \
-    if (symk) RMP2_QUAD_PLAIN_SYM(MINW, (N == 9));                                                                      \
+    if (o.capsule && symk) RMP2_QUAD_LAUNCH(MINW, false, true, (N == 9), RMP2_OBS_SHARED_SPHERES, kPlainStep);                \
+    else if (o.capsule) RMP2_QUAD_LAUNCH(MINW, false, true, false, RMP2_OBS_SHARED_SPHERES, kPlainStep);                      \
+    else if (symk) RMP2_QUAD_PLAIN_SYM(MINW, (N == 9));                                                                 \
     else RMP2_QUAD_PLAIN_SYM(MINW, false);                                                                              \
   } while (0)
 #ifdef RMP2_STAMPS
-  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !o.capsule;  // (stamps ride behind out.f)
+  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && (!o.capsule || o.mode == RMP2_OBS_SHARED_SPHERES);  // (stamps ride behind out.f)
 #else
-  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !out.f && !o.capsule;
+  const bool plain = ro.n_iters == 1 && ro.substeps == 0 && !ro.q_out && !out.M && !out.f &&
+                     (!o.capsule || o.mode == RMP2_OBS_SHARED_SPHERES);  // (capsule tables: the shared-table plain build only)
 #endif
+  // fused rollouts of sphere-table / obstacle-free sets (no debug outputs): the lean rollout builds -- the general build
+  // spills 76 dwords at 128 registers (88 us per control step at 65 536 robots against 41 for a plain step)
+#define RMP2_QUAD_ROLL_SYM(MINW, SYM)                                                                                   \
+  do {                                                                                                                  \
+    switch (o.mode) {                                                                                                   \
+      case RMP2_OBS_SHARED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_SHARED_SPHERES, kPlainRollout); break; \
+      case RMP2_OBS_RAGGED_SPHERES: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_RAGGED_SPHERES, kPlainRollout); break; \
+      default: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_NONE, kPlainRollout); break;                          \
+    }                                                                                                                   \
+  } while (0)
+  const bool lean_rollout = !plain && !out.M && !out.f && !o.capsule && o.mode != RMP2_OBS_EXPLICIT_PAIRS && !latency;
+  if (lean_rollout) {
+    if (minw == 3) minw = 2;  // (the lean rollout exists at two and four waves per SIMD)
+    if (minw == 4) {
+      if (symk) RMP2_QUAD_ROLL_SYM(4, (N == 9)); else RMP2_QUAD_ROLL_SYM(4, false);
+    } else {
+      if (symk) RMP2_QUAD_ROLL_SYM(2, (N == 9)); else RMP2_QUAD_ROLL_SYM(2, false);
+    }
+    return;
+  }
+#undef RMP2_QUAD_ROLL_SYM
   if (latency) RMP2_QUAD_BY_CAP(1, true);
   else if (plain && minw == 4) RMP2_QUAD_PLAIN(4);
   else if (plain && minw == 3) RMP2_QUAD_PLAIN(3);

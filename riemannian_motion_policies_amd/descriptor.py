@@ -14,7 +14,7 @@ import numpy as np
 
 from .urdf import KinematicTable
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_FRAMES = 32
 MAX_DOF = 16
 MAX_LEAVES = 48
@@ -114,7 +114,7 @@ class Outputs(C.Structure):
 
 
 class RolloutCfg(C.Structure):
-    _fields_ = [("n_control_steps", C.c_int32), ("substeps", C.c_int32), ("dt", C.c_float)]
+    _fields_ = [("n_control_steps", C.c_int32), ("substeps", C.c_int32), ("dt", C.c_float), ("table_steps", C.c_int32)]
 
 
 class LeafSpec:

@@ -217,12 +217,24 @@ class Engine:
         self._lib.rmp2_set_step_fence(self._h, fence._h if fence is not None else None)
         self._fence_attached = fence is not None
 
+    def obstacle_trajectory(self, tables: torch.Tensor, csr_offset=None, csr_index=None):
+        """Obstacle tables of a rollout with MOVING obstacles: `tables` [n_control_steps, K, 4] (spheres) or
+        [n_control_steps, K, 8] (capsules); control step k of rollout(..., obstacles=this) reads tables[k]."""
+        tables = _f32(tables, self.device)
+        if tables.dim() != 3 or tables.shape[2] not in (4, 8):
+            raise ValueError("tables must be [n_control_steps, K, 4] or [n_control_steps, K, 8]")
+        o = self.obstacles(spheres=tables[0], csr_offset=csr_offset, csr_index=csr_index)
+        o.spheres = tables.data_ptr()
+        o._keep.append(tables)
+        o._table_steps = int(tables.shape[0])
+        return o
+
     def rollout(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
                 n_control_steps: int = 1, substeps: int = 10, dt: float = 0.01, out: Optional[torch.Tensor] = None,
                 status: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
         """Closed-loop rollout in ONE launch: `n_control_steps` x (control step, then `substeps` semi-implicit
         Euler ticks of `dt` with qdd held).  q and qd (contiguous fp32 device tensors) are advanced IN PLACE;
-        returns the last qdd."""
+        returns the last qdd.  obstacles = obstacle_trajectory(...): the obstacles move between control steps."""
         for t in (q, qd):
             if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError("rollout needs contiguous fp32 CUDA tensors (they are updated in place)")
@@ -251,7 +263,10 @@ class Engine:
                     and status.dtype in (torch.int32, torch.uint32) and status.numel() == R):
                 raise ValueError("status must be a contiguous int32 / uint32 tensor of R elements on the engine's device")
             o.status = status.data_ptr()
-        cfg = D.RolloutCfg(int(n_control_steps), int(substeps), float(dt))
+        table_steps = int(getattr(obstacles, "_table_steps", 0)) if obstacles is not None else 0
+        if table_steps > 1 and table_steps != int(n_control_steps):
+            raise ValueError(f"the obstacle trajectory holds {table_steps} tables, the rollout has {n_control_steps} control steps")
+        cfg = D.RolloutCfg(int(n_control_steps), int(substeps), float(dt), table_steps)
         s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         rc = self._lib.rmp2_rollout(self._h, q.data_ptr(), qd.data_ptr(), goal_ptr, goal_stride,
                                     C.byref(obstacles) if obstacles is not None else None, C.byref(cfg), C.byref(o), R, s)

@@ -250,16 +250,85 @@ def test_fused_rollout_against_the_oracle(hip_lib, golden_dir, workload, kernel)
         assert np.abs(q_ref[tame] - g["q"][tame]).max() > 1e-3   # the fleet moved
 
 
-def test_rollout_refuses_a_strict_pinv_handle(hip_lib):
-    """rmp2_rollout resolves by elimination with per-robot pseudo-inverse fall-through; a handle created with solve="pinv"
-    asked for the strict pseudo-inverse on every robot and must be refused, not silently resolved otherwise."""
-    import torch
-    from riemannian_motion_policies_amd import _native, configs as Cf
+def _engine_k(desc, kernel):
     from riemannian_motion_policies_amd.engine import Engine
+    old_env = os.environ.get("RMP2_KERNEL")
+    if kernel:
+        os.environ["RMP2_KERNEL"] = kernel
+    try:
+        return Engine(desc, 0)
+    finally:
+        if kernel:
+            if old_env is None:
+                del os.environ["RMP2_KERNEL"]
+            else:
+                os.environ["RMP2_KERNEL"] = old_env
+
+
+def test_rollout_with_the_strict_pseudo_inverse(hip_lib, golden_dir):
+    """The reference's ONLY resolve (tf.linalg.pinv, rmp.py:153-154) inside the fused closed loop: a handle created with
+    solve = "pinv" rolls out with the strict pseudo-inverse on every robot and step (round 2 refused it), against the
+    oracle's closed loop -- whose resolve is the SVD-style pseudo-inverse for every robot."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    g = np.load(os.path.join(golden_dir, "config2.npz"))
     _, desc = Cf.config2("pinv")
-    eng = Engine(desc, 0)
-    s = Cf.sample_panda_states(np.random.default_rng(2), 8)
-    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
-    eng.step(q, qd, goal)  # single steps are fine
-    with pytest.raises(_native.Rmp2Error, match="PINV"):
-        eng.rollout(q, qd, goal, n_control_steps=2)
+    eng = _engine_k(desc, None)
+    sub, dt, K = 10, 0.01, 5
+    q_ref, qd_ref, peak = _oracle_rollout(desc, g["q"], g["qd"], g["goal"], K, sub, dt)
+    qf, qdf = torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["qd"]).cuda()
+    st = torch.zeros(len(g["q"]), dtype=torch.int32, device="cuda")
+    eng.rollout(qf, qdf, torch.from_numpy(g["goal"]).cuda(), n_control_steps=K, substeps=sub, dt=dt, status=st)
+    torch.cuda.synchronize()
+    assert "strict" in eng.last_kernel()
+    tame = np.isfinite(q_ref).all(axis=1) & (peak <= 20.0)
+    eq = np.abs(qf.cpu().numpy() - q_ref).max(axis=1) / np.maximum(1.0, np.abs(q_ref).max(axis=1))
+    ev = np.abs(qdf.cpu().numpy() - qd_ref).max(axis=1) / np.maximum(1.0, np.abs(qd_ref).max(axis=1))
+    assert tame.mean() > 0.95 and (eq[tame] <= 1e-5).all() and (ev[tame] <= 1e-4).all(), f"{eq[tame].max():.2e} {ev[tame].max():.2e}"
+    assert not (st.cpu().numpy() & 4).any(), "strict mode does not report a PINV_PATH fall-through: it IS the requested resolve"
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad"])
+@pytest.mark.parametrize("prim", ["spheres", "capsules"])
+def test_rollout_with_moving_obstacles(hip_lib, golden_dir, kernel, prim):
+    """Obstacle motion inside the fused rollout (the reference re-reads the obstacle data every control step,
+    06_cluttered_environment.py:120-131): control step k reads table k of a [K_steps, K, 4 | 8] trajectory.  Against the
+    same loop driven from the host with one rmp2_step per control step on table k (same arithmetic), and against the
+    rollout on the FIRST table alone (which must differ: the tables really move)."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    _, desc = Cf.config3()
+    eng = _engine_k(desc, kernel)
+    R, sub, dt, K = len(g["q"]), 10, 0.01, 6
+    base = g["spheres"] if prim == "spheres" else Cf.sample_capsules(np.random.default_rng(4), 32)
+    if prim == "capsules":     # random capsules are not clearance-filtered: lifted above the arms (mild repulsion, no contact)
+        base = base.copy()
+        base[:, 2] += np.float32(0.6)
+        base[:, 6] += np.float32(0.6)
+    tabs = np.stack([base.copy() for _ in range(K)])
+    for k in range(K):
+        tabs[k, :, 2] += np.float32(0.04 * k)          # the clutter rises 4 cm per control step
+        if prim == "capsules":
+            tabs[k, :, 6] += np.float32(0.04 * k)
+    tt = torch.from_numpy(tabs).cuda()
+    goal = torch.from_numpy(g["goal"]).cuda()
+    q, qd = torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["qd"]).cuda()
+    for k in range(K):                                  # host-driven loop, table k at control step k
+        qdd = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tt[k]))
+        for _ in range(sub):
+            qd = torch.addcmul(qd, qdd, torch.tensor(dt, device="cuda"))   # (not fused: rounding differs from the kernel's fma)
+            q = q + dt * qd
+    qf, qdf = torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["qd"]).cuda()
+    eng.rollout(qf, qdf, goal, obstacles=eng.obstacle_trajectory(tt), n_control_steps=K, substeps=sub, dt=dt)
+    q1, qd1 = torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["qd"]).cuda()
+    eng.rollout(q1, qd1, goal, obstacles=eng.obstacles(spheres=tt[0]), n_control_steps=K, substeps=sub, dt=dt)
+    torch.cuda.synchronize()
+    assert kernel in eng.last_kernel()
+    ok = torch.isfinite(q).all(dim=1) & torch.isfinite(qf).all(dim=1)
+    err = (qf - q).abs().max(dim=1).values[ok]
+    assert ok.float().mean().item() > 0.9 and err.median().item() < 1e-5 and (err < 1e-3).float().mean().item() > 0.95, \
+        f"{prim} {kernel}: median {err.median().item():.2e} max {err.max().item():.2e}"
+    assert (qf - q1).abs().max().item() > 1e-4, "the moving tables must change the trajectory"
+    with pytest.raises(ValueError, match="tables"):
+        eng.rollout(qf, qdf, goal, obstacles=eng.obstacle_trajectory(tt), n_control_steps=K + 1)

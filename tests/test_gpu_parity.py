@@ -168,6 +168,28 @@ def test_shared_goal_and_status_nonfinite(torch_mod):
                    obstacles=eng.obstacles(spheres=torch.from_numpy(sph)))
     ref = O.step(desc, s["q"], s["qd"], np.tile(goal, (16, 1)), spheres=sph)
     _check(out.cpu().numpy(), ref["qdd64"], "shared goal")
+    # the status word: a NaN state and a joint exactly on the JointVelocityCap pole (|qd| = 0.5 - 2 * 0.15 = 0.2: the
+    # metric's diagonal entry is w / (1 - 1) = Inf) must come back flagged NONFINITE, through every mapping the dispatcher
+    # may pick (16 robots: hex; 20 000: quad), the robots next to them untouched
+    for R in (16, 20000):
+        s2 = Cf.sample_panda_states(np.random.default_rng(6), R)
+        s2["q"][3, 2] = np.nan
+        # (the pole in fp32: |qd| - (v_max - r) must equal -r exactly -- 0.2f misses it by one ulp, (0.5f - 0.15f) - 0.15f hits it)
+        s2["qd"][5, 1] = np.float32(np.float32(np.float32(0.5) - np.float32(0.15)) - np.float32(0.15))
+        st = torch.zeros(R, dtype=torch.int32, device="cuda")
+        out2 = eng.step(torch.from_numpy(s2["q"]), torch.from_numpy(s2["qd"]), torch.from_numpy(goal),
+                        obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st)
+        torch.cuda.synchronize()
+        stc, o2 = st.cpu().numpy(), out2.cpu().numpy()
+        assert stc[3] & 1 and not np.isfinite(o2[3]).all(), f"R={R}: NaN state not flagged ({eng.last_kernel()})"
+        assert stc[5] & 1 and not np.isfinite(o2[5]).all(), f"R={R}: velocity-cap pole not flagged ({eng.last_kernel()})"
+        others = np.ones(R, bool)
+        others[[3, 5]] = False
+        assert (stc[others] & 1).sum() == 0 and np.isfinite(o2[others]).all()
+        ref2 = O.step(desc, s2["q"][:64], s2["qd"][:64], np.tile(goal, (64, 1))[: min(R, 64)], spheres=sph)["qdd64"] if R >= 64 else None
+        if ref2 is not None:
+            m = others[:64]
+            _check(o2[:64][m], ref2[m], f"robots next to the non-finite ones, R={R}")
 
 
 def test_full_size_properties(torch_mod):
