@@ -329,6 +329,14 @@ int rmp2_rollout(rmp2_handle *h, float *q, float *qd, const float *goal, int32_t
  * reproduces the fused table mode.  p_link / p_obs: device [R][n_distance_leaves*K][3].   */
 int rmp2_closest_points(rmp2_handle *h, const float *q, const rmp2_obstacles *table, float *p_link, float *p_obs,
                         int32_t R, void *stream);
+/* The same stage with LINK GEOMETRY: the reference's control points are PyBullet's closest points on the link's collision
+ * SHAPE, different for every (link, obstacle) pair (simulation.py:462-484 -> data_management.py:22-37), not the frame
+ * origin.  link_capsules: device [n_distance_leaves][8] = (a.xyz, radius, b.xyz, unused), the link of the i-th distance leaf
+ * as a capsule in that leaf's FRAME coordinates (urdf.py link_capsules: from the URDF's primitive collision geometry, or
+ * supplied by the caller for mesh links).  Per pair: the nearest points of the link capsule's and the obstacle primitive's
+ * surfaces (capsule-vs-sphere, capsule-vs-capsule).  link_capsules == NULL: rmp2_closest_points. */
+int rmp2_closest_points_links(rmp2_handle *h, const float *q, const rmp2_obstacles *table, const float *link_capsules,
+                              float *p_link, float *p_obs, int32_t R, void *stream);
 
 /* Forward kinematics of every frame: T[R][n_frames][16] row-major 4x4
  * (UrdfForwardKinematic.forward, kinematics.py:212-247, for all frames at once).      */

@@ -54,6 +54,8 @@ def lib():
     l.rmp2_forward_kinematics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     l.rmp2_closest_points.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(D.Obstacles), C.c_void_p, C.c_void_p,
                                       C.c_int32, C.c_void_p]
+    l.rmp2_closest_points_links.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(D.Obstacles), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int32, C.c_void_p]
     l.rmp2_differentiate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     l.rmp2_differentiate_euler.argtypes = l.rmp2_differentiate.argtypes

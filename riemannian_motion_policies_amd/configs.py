@@ -279,3 +279,43 @@ def sample_ragged(rng: np.random.Generator, R: int, K: int = N_SPHERES):
     index = np.concatenate([rng.permutation(K)[:c] for c in counts]).astype(np.int32) if offset[-1] else \
         np.zeros(0, np.int32)
     return offset, index
+
+
+def pairs_from_link_capsules(T: np.ndarray, link_capsules: np.ndarray, table: np.ndarray):
+    """Closest points of LINK capsules and obstacle primitives in fp64 numpy (independent of the engine): T [R, C, 4, 4]
+    world transforms of the distance leaves' frames, link_capsules [C, 8] in frame coordinates, table [K, 4] spheres or
+    [K, 8] capsules -> p_link, p_obs [R, C*K, 3].  Segment-segment closest points by the clamped normal equations."""
+    T = T.astype(np.float64)
+    R, Cn = T.shape[:2]
+    K = table.shape[0]
+    lc = link_capsules.astype(np.float64)
+    A = T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 0:3])
+    B = T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 4:7])
+    rl = lc[:, 3]
+    tb = table.astype(np.float64)
+    Cc = tb[:, 0:3]
+    Dd = tb[:, 4:7] if tb.shape[1] == 8 else tb[:, 0:3]
+    ro = tb[:, 3]
+    p1, q1 = A[:, :, None, :], B[:, :, None, :]
+    p2, q2 = Cc[None, None, :, :], Dd[None, None, :, :]
+    d1, d2, r = q1 - p1, np.broadcast_to(q2 - p2, (R, Cn, K, 3)), p1 - p2
+    a = (d1 * d1).sum(-1) + 0 * r[..., 0]
+    e = (d2 * d2).sum(-1) + 0 * r[..., 0]
+    f = (d2 * r).sum(-1)
+    c = (d1 * r).sum(-1)
+    b = (d1 * d2).sum(-1)
+    with np.errstate(all="ignore"):
+        denom = a * e - b * b
+        s = np.where(denom > 0, np.clip((b * f - c * e) / np.where(denom > 0, denom, 1.0), 0, 1), 0.0)
+        t = np.where(e > 0, (b * s + f) / np.where(e > 0, e, 1.0), 0.0)
+        s = np.where(t < 0, np.clip(-c / np.where(a > 0, a, 1.0), 0, 1), np.where(t > 1, np.clip((b - c) / np.where(a > 0, a, 1.0), 0, 1), s))
+        t = np.clip(t, 0, 1)
+        s = np.where(a > 0, s, 0.0)
+        s = np.where((e > 0) | (a <= 0), s, np.clip(-c / np.where(a > 0, a, 1.0), 0, 1))
+    X = p1 + s[..., None] * d1
+    Y = p2 + t[..., None] * d2
+    n = X - Y
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    p_link = X - rl[None, :, None, None] * n
+    p_obs = Y + ro[None, None, :, None] * n
+    return p_link.reshape(R, Cn * K, 3).astype(np.float32), p_obs.reshape(R, Cn * K, 3).astype(np.float32)

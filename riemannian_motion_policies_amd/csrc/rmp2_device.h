@@ -136,6 +136,46 @@ __device__ __forceinline__ void capsule_centre(const float4 ra, const float4 rb,
   ctr[2] = ra.z + t * u[2];
 }
 
+// Closest points of two segments p1-q1 and p2-q2 (the axes of two capsules): parameters s, t in [0, 1] of the nearest
+// points c1 = p1 + s (q1 - p1), c2 = p2 + t (q2 - p2).  The standard clamped solution of the 2 x 2 normal equations
+// (degenerate segments -- points -- included); the link-capsule case of the reference's closest-point stage, which
+// PyBullet answers for the link's collision shape (simulation.py:462-484).
+__device__ __forceinline__ void segment_segment(const float p1[3], const float q1[3], const float p2[3], const float q2[3],
+                                                float& s, float& t) {
+  const float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+  const float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+  const float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const float a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+  const float e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+  const float f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+  const float c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+  const float b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+  if (!(a > 0.f) && !(e > 0.f)) {  // both are points
+    s = t = 0.f;
+    return;
+  }
+  if (!(a > 0.f)) {  // the first is a point
+    s = 0.f;
+    t = fminf(fmaxf(f / e, 0.f), 1.f);
+    return;
+  }
+  if (!(e > 0.f)) {  // the second is a point
+    t = 0.f;
+    s = fminf(fmaxf(-c / a, 0.f), 1.f);
+    return;
+  }
+  const float denom = a * e - b * b;  // >= 0; 0 for parallel axes: any s does, 0 is taken
+  s = denom > 0.f ? fminf(fmaxf((b * f - c * e) / denom, 0.f), 1.f) : 0.f;
+  t = (b * s + f) / e;
+  if (t < 0.f) {
+    t = 0.f;
+    s = fminf(fmaxf(-c / a, 0.f), 1.f);
+  } else if (t > 1.f) {
+    t = 1.f;
+    s = fminf(fmaxf((b - c) / a, 0.f), 1.f);
+  }
+}
+
 struct OutArgs {
   float* __restrict__ qdd;
   uint32_t* __restrict__ status;

@@ -587,7 +587,7 @@ rmp2_fk_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q,
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave)
 rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const ObsArgs obs,
-                    float* __restrict__ p_link, float* __restrict__ p_obs, int R) {
+                    const float* __restrict__ link_caps, float* __restrict__ p_link, float* __restrict__ p_obs, int R) {
   const int robot = blockIdx.x * kWave + threadIdx.x;
   if (robot >= R) return;
   const float* my_q = q + (size_t)robot * prog->n_dof;
@@ -611,6 +611,47 @@ rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict
       const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
       if (lf.taskmap != RMP2_TASKMAP_FK_DISTANCE) continue;
       const size_t base = ((size_t)robot * obs.n_pairs + obs.pair_begin[lf.index]) * 3;
+      if (link_caps) {
+        // link geometry: the leaf's link as a capsule (a, radius, b) in the frame's own coordinates; per pair the nearest
+        // points of the link capsule and the obstacle primitive (their surfaces), as PyBullet reports them for the link's
+        // collision shape (simulation.py:462-484 -> data_management.py:22-37)
+        const float* lc = link_caps + 8 * (obs.pair_begin[lf.index] / obs.n_spheres);  // ordinal of the distance leaf
+        float A[3], B[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          A[i] = cur.p[i] + cur.R[3 * i] * lc[0] + cur.R[3 * i + 1] * lc[1] + cur.R[3 * i + 2] * lc[2];
+          B[i] = cur.p[i] + cur.R[3 * i] * lc[4] + cur.R[3 * i + 1] * lc[5] + cur.R[3 * i + 2] * lc[6];
+        }
+        const float r_link = lc[3];
+        for (int b = 0; b < obs.n_spheres; ++b) {
+          float C[3], D[3], r_obs;
+          if (obs.capsule) {
+            const float4 ca = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
+            const float4 cb = reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1];
+            C[0] = ca.x, C[1] = ca.y, C[2] = ca.z, D[0] = cb.x, D[1] = cb.y, D[2] = cb.z, r_obs = ca.w;
+          } else {
+            const float4 sp = reinterpret_cast<const float4*>(obs.spheres)[b];
+            C[0] = D[0] = sp.x, C[1] = D[1] = sp.y, C[2] = D[2] = sp.z, r_obs = sp.w;
+          }
+          float sl, to;
+          segment_segment(A, B, C, D, sl, to);
+          float X[3], Y[3], n[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            X[c] = A[c] + sl * (B[c] - A[c]);
+            Y[c] = C[c] + to * (D[c] - C[c]);
+            n[c] = X[c] - Y[c];
+          }
+          const float dn = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float u = n[c] / dn;
+            p_link[base + 3 * b + c] = X[c] - r_link * u;
+            p_obs[base + 3 * b + c] = Y[c] + r_obs * u;
+          }
+        }
+        continue;
+      }
       for (int b = 0; b < obs.n_spheres; ++b) {
         float4 sp;
         float ctr[3];
@@ -1825,6 +1866,11 @@ int rmp2_forward_kinematics(rmp2_handle* h, const float* q, float* T, int32_t R,
 
 int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* table, float* p_link, float* p_obs,
                         int32_t R, void* stream) {
+  return rmp2_closest_points_links(h, q, table, nullptr, p_link, p_obs, R, stream);
+}
+
+int rmp2_closest_points_links(rmp2_handle* h, const float* q, const rmp2_obstacles* table, const float* link_capsules,
+                              float* p_link, float* p_obs, int32_t R, void* stream) {
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
   if (!q || !table || !p_link || !p_obs || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
   if (table->mode != RMP2_OBS_SHARED_SPHERES || table->n_spheres < 0 || (table->n_spheres > 0 && !table->spheres))
@@ -1857,9 +1903,9 @@ int rmp2_closest_points(rmp2_handle* h, const float* q, const rmp2_obstacles* ta
   o.pair_begin = h->d_pair_begin;
   const int blocks = (R + kWave - 1) / kWave;
   switch (h->n_slots) {
-    case 0: hipLaunchKernelGGL((rmp2_closest_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
-    case 1: hipLaunchKernelGGL((rmp2_closest_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
-    default: hipLaunchKernelGGL((rmp2_closest_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, p_link, p_obs, R); break;
+    case 0: hipLaunchKernelGGL((rmp2_closest_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, link_capsules, p_link, p_obs, R); break;
+    case 1: hipLaunchKernelGGL((rmp2_closest_kernel<1>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, link_capsules, p_link, p_obs, R); break;
+    default: hipLaunchKernelGGL((rmp2_closest_kernel<2>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, link_capsules, p_link, p_obs, R); break;
   }
   HIP_TRY(h, hipGetLastError());
   return RMP2_OK;

@@ -281,10 +281,13 @@ class Engine:
         _native.check(self._lib.rmp2_forward_kinematics(self._h, q.data_ptr(), T.data_ptr(), R, s), self._h)
         return T
 
-    def closest_points(self, q: torch.Tensor, table):
+    def closest_points(self, q: torch.Tensor, table, link_capsules=None):
         """Closest-point preprocessing stage on its own (simulation.py:462-484 calculate_distances):
         returns (p_link, p_obs), each [R, n_distance_leaves * K, 3], for the shared primitive `table`
-        built by obstacles(spheres=...).  The pair arrays can be fed back as obstacles(p_link=, p_obs=)."""
+        built by obstacles(spheres=...).  The pair arrays can be fed back as obstacles(p_link=, p_obs=).
+        link_capsules [n_distance_leaves, 8] = (a, radius, b, -) in each leaf's frame coordinates: the control point of a
+        pair is then the nearest point of the LINK's capsule to the obstacle (different per pair, as PyBullet reports it),
+        not the frame origin."""
         q = _f32(q, self.device)
         R = q.shape[0]
         n_dist = sum(1 for i in range(self.desc.n_leaves) if self.desc.leaves[i].taskmap == D.TASKMAP_FK_DISTANCE)
@@ -292,8 +295,14 @@ class Engine:
         p_link = torch.empty((R, P, 3), dtype=torch.float32, device=self.device)
         p_obs = torch.empty_like(p_link)
         s = torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(self._lib.rmp2_closest_points(self._h, q.data_ptr(), C.byref(table), p_link.data_ptr(),
-                                                    p_obs.data_ptr(), R, s), self._h)
+        lc_ptr = None
+        if link_capsules is not None:
+            link_capsules = _f32(link_capsules, self.device)
+            if tuple(link_capsules.shape) != (n_dist, 8):
+                raise ValueError(f"link_capsules must be [{n_dist}, 8] (one capsule per distance leaf, in leaf order)")
+            lc_ptr = link_capsules.data_ptr()
+        _native.check(self._lib.rmp2_closest_points_links(self._h, q.data_ptr(), C.byref(table), lc_ptr, p_link.data_ptr(),
+                                                          p_obs.data_ptr(), R, s), self._h)
         return p_link, p_obs
 
     def differentiate(self, q: torch.Tensor, qd: torch.Tensor, frame: int):

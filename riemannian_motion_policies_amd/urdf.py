@@ -278,6 +278,54 @@ def compile_urdf(urdf_filepath: str, order: Sequence[str]) -> KinematicTable:
     )
 
 
+def link_capsules(urdf_filepath: str, table: KinematicTable, frames: Sequence[str], default_radius: float = 0.06) -> np.ndarray:
+    """Link capsules [len(frames), 8] = (a, radius, b, 0) in FRAME coordinates for the closest-point stage with link
+    geometry (Engine.closest_points(link_capsules=), include/rmp2.h rmp2_closest_points_links): the link that moves with
+    each frame as a capsule.  The reference asks PyBullet for the closest points on the link's collision SHAPE
+    (simulation.py:462-484); here that shape is reduced to a capsule:
+      * <cylinder length radius>: the cylinder's axis (local z of the collision origin), shortened by the radius at both ends;
+      * <box size>: the box's longest edge as the axis, radius = half the larger of the two other edges, shortened likewise;
+      * <sphere radius>: a capsule of zero length;
+      * <mesh> / no primitive (the Panda): the segment from the frame origin to the origin of its first child frame (the next
+        joint), radius `default_radius` -- a stand-in a caller replaces by capsules fitted to the collision meshes."""
+    root = ElementTree.parse(urdf_filepath).getroot()
+    link_by_name = {l.attrib["name"]: l for l in root.findall("link")}
+    out = np.zeros((len(frames), 8), dtype=np.float32)
+    for i, fr in enumerate(frames):
+        f = table.frame_index(fr)
+        link = link_by_name.get(table.link_names[f])
+        col = link.find("collision") if link is not None else None
+        geom = col.find("geometry") if col is not None else None
+        origin = col.find("origin") if col is not None else None
+        xyz = np.asarray(_floats(origin.attrib.get("xyz") if origin is not None else None), dtype=np.float64)
+        Rc = rotation_from_rpy_reference_order(_floats(origin.attrib.get("rpy") if origin is not None else None)).astype(np.float64)
+        prim = None
+        if geom is not None:
+            for tag in ("cylinder", "box", "sphere"):
+                if geom.find(tag) is not None:
+                    prim = (tag, geom.find(tag))
+        if prim is not None and prim[0] == "cylinder":
+            r, L = float(prim[1].attrib["radius"]), float(prim[1].attrib["length"])
+            half = max(L / 2.0 - r, 0.0)
+            axis = Rc @ np.array([0.0, 0.0, 1.0])
+        elif prim is not None and prim[0] == "box":
+            size = np.asarray(_floats(prim[1].attrib["size"]), dtype=np.float64)
+            k = int(np.argmax(size))
+            r = float(np.max(np.delete(size, k))) / 2.0
+            half = max(size[k] / 2.0 - r, 0.0)
+            axis = Rc @ np.eye(3)[k]
+        elif prim is not None and prim[0] == "sphere":
+            r, half, axis = float(prim[1].attrib["radius"]), 0.0, np.array([0.0, 0.0, 1.0])
+        else:
+            kids = [c for c in range(table.n_frames) if table.parent[c] == f]
+            b = table.T_const[kids[0], :3, 3].astype(np.float64) if kids else np.zeros(3)
+            out[i] = [0.0, 0.0, 0.0, default_radius, b[0], b[1], b[2], 0.0]
+            continue
+        a, b = xyz - half * axis, xyz + half * axis
+        out[i] = [a[0], a[1], a[2], r, b[0], b[1], b[2], 0.0]
+    return out
+
+
 def panda_table() -> KinematicTable:
     return compile_urdf(PANDA_URDF, PANDA_ORDER)
 

@@ -158,3 +158,50 @@ def test_closest_points_abi_errors(torch_mod):
     g = torch.zeros((4, 3), device="cuda")
     assert lib.rmp2_step(eng._h, q.data_ptr(), qd.data_ptr(), g.data_ptr(), 3, C.byref(o), C.byref(res), 4, None) == -1
     assert b"primitive" in lib.rmp2_last_error(eng._h)
+
+
+@pytest.mark.parametrize("prim", ["spheres", "capsules"])
+@pytest.mark.parametrize("robot", ["panda", "two_joint"])
+def test_closest_points_with_link_geometry(torch_mod, prim, robot):
+    """rmp2_closest_points_links: per pair the nearest points of the LINK's capsule and the obstacle primitive (what the
+    reference gets from PyBullet for the link's collision shape, simulation.py:462-484), against the fp64 closed form
+    (itself pinned by a brute-force scan in tests/test_oracle_pins.py); the pairs then drive the explicit-pair step, whose
+    result must equal the oracle's on the same pairs."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf as U
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    R, K = 97, 9
+    if robot == "panda":
+        table, desc = Cf.config3()
+        s = Cf.sample_panda_states(rng, R)
+        lc = U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)
+    else:
+        table, desc = Cf.config5_two_joint()
+        s = Cf.sample_two_joint_states(rng, R)
+        lc = U.link_capsules(U.TWO_JOINT_URDF, table, Cf.TWO_JOINT_CONTROL_POINT_FRAMES)   # boxes / cylinders of the URDF
+        assert np.allclose(lc[0], [0.05, 0, 0, 0.05, 0.95, 0, 0, 0])
+    tab = Cf.sample_spheres(rng, K) if prim == "spheres" else Cf.sample_capsules(rng, K)
+    tab[:, 2] += np.float32(0.9)     # above the arms: clear of contact, the pairs stay well conditioned
+    if prim == "capsules":
+        tab[:, 6] += np.float32(0.9)
+    eng = Engine(desc, 0)
+    t_dev = eng.obstacles(spheres=torch.from_numpy(tab))
+    pl, po = eng.closest_points(torch.from_numpy(s["q"]), t_dev, link_capsules=torch.from_numpy(lc))
+    T = O.forward_kinematics(desc, s["q"], precision="f64")
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    pl_ref, po_ref = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
+    assert np.abs(pl.cpu().numpy() - pl_ref).max() < 2e-6 and np.abs(po.cpu().numpy() - po_ref).max() < 2e-6
+    # the control points really differ from the frame origins, pair by pair
+    pl0, _ = eng.closest_points(torch.from_numpy(s["q"]), t_dev)
+    assert (pl - pl0).abs().max().item() > 0.03
+    # ... and feed the reference-faithful explicit-pair step
+    qdd = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
+                   obstacles=eng.obstacles(p_link=pl, p_obs=po))
+    torch.cuda.synchronize()
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], p_link=pl.cpu().numpy(), p_obs=po.cpu().numpy())
+    ok = np.linalg.cond(ref["M"]) < 100 if robot == "two_joint" else np.ones(R, bool)
+    err = np.abs(qdd.cpu().numpy() - ref["qdd64"]).max(axis=1)
+    tol = 1e-5 * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
+    assert (err[ok] <= tol[ok]).all() and ok.sum() > R // 3, f"worst {err[ok].max():.2e}"

@@ -306,3 +306,38 @@ def test_exp06_parameters_typed_from_the_script_not_from_configs(golden_dir):
             pairs[4 + k] = (np.repeat(o, K, 0), (c + rad * (diff / dist)).astype(np.float32))
         qdd, _, _ = TA.evaluate_one(fk, leaves, g["q"][r], g["qd"][r], g["goal"][r], pairs)
         assert np.abs(qdd - g["qdd"][r]).max() <= 1e-9 * max(1.0, np.abs(g["qdd"][r]).max()), (r, qdd, g["qdd"][r])
+
+
+def test_link_capsule_closest_points_against_a_brute_force_scan():
+    """The fp64 closed form the GPU stage is tested against (configs.pairs_from_link_capsules: segment-segment closest points
+    of a link capsule and an obstacle primitive) against a brute-force scan of both axes (401 x 401 samples per pair):
+    the distance between the returned surface points must equal the scanned minimum axis distance minus both radii."""
+    from riemannian_motion_policies_amd import configs as Cf
+    rng = np.random.default_rng(31)
+    R, Cn, K = 3, 4, 5
+    T = np.tile(np.eye(4), (R, Cn, 1, 1))
+    for r in range(R):
+        for c in range(Cn):
+            Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            T[r, c, :3, :3] = Q * np.sign(np.linalg.det(Q))
+            T[r, c, :3, 3] = rng.uniform(-0.5, 0.5, 3)
+    lc = np.zeros((Cn, 8), np.float32)
+    lc[:, 0:3] = rng.uniform(-0.2, 0.2, (Cn, 3))
+    lc[:, 4:7] = rng.uniform(-0.2, 0.2, (Cn, 3))
+    lc[:, 3] = rng.uniform(0.03, 0.08, Cn)
+    lc[0, 4:7] = lc[0, 0:3]                                  # a degenerate link (a point)
+    for tab in (Cf.sample_spheres(rng, K), Cf.sample_capsules(rng, K)):
+        pl, po = Cf.pairs_from_link_capsules(T, lc, tab)
+        u = np.linspace(0, 1, 401)
+        for r in range(R):
+            for c in range(Cn):
+                A = T[r, c, :3, 3] + T[r, c, :3, :3] @ lc[c, 0:3]
+                B = T[r, c, :3, 3] + T[r, c, :3, :3] @ lc[c, 4:7]
+                X = A[None] + u[:, None] * (B - A)[None]
+                for k in range(K):
+                    C0 = tab[k, 0:3].astype(np.float64)
+                    D0 = tab[k, 4:7].astype(np.float64) if tab.shape[1] == 8 else C0
+                    Y = C0[None] + u[:, None] * (D0 - C0)[None]
+                    dmin = np.sqrt(((X[:, None, :] - Y[None, :, :]) ** 2).sum(-1)).min()
+                    got = np.linalg.norm(pl[r, c * K + k].astype(np.float64) - po[r, c * K + k])
+                    assert abs(got - abs(dmin - lc[c, 3] - tab[k, 3])) < 2e-3, (r, c, k, got, dmin)
