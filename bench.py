@@ -468,12 +468,11 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
     steps, warmup = min(args.steps, 500), min(args.warmup, 50)
     rows, extra = [], {}
     if workload == "config5":
-        cost = None
-        if args.calibrate:
-            cost = MixedFleetShard.calibrate_costs(local_rank, robots=args.calibrate_robots)
-        extra["cost_model_ns"] = {k: {"per_robot": v[0], "per_pair": v[1]} for k, v in (cost or MixedFleetShard.DEFAULT_COST).items()}
-        extra["cost_model_source"] = "measured in this run (--calibrate)" if cost else "fleet.MixedFleetShard.DEFAULT_COST"
-        plans = {"calibrated": cost or MixedFleetShard.DEFAULT_COST}
+        curves = MixedFleetShard.calibrate_curves(local_rank) if args.calibrate else MixedFleetShard.DEFAULT_CURVES
+        extra["cost_model"] = {"kind": "kernel time curves per robot type (us per step at a ladder of fleet sizes)",
+                               "curves": {k: {"robots": list(v[0]), "us": [round(float(x), 2) for x in v[1]]} for k, v in curves.items()}}
+        extra["cost_model_source"] = "measured in this run (--calibrate)" if args.calibrate else "fleet.MixedFleetShard.DEFAULT_CURVES"
+        plans = {"calibrated": {"curves": curves}}
         if args.compare_flop_model:   # the round-2 weights (SURVEY 8(d) flops), for the before / after of the imbalance
             plans = {"flop_model_round2": {"two_joint": (0.5e3, 240.0), "panda": (4.0e3, 240.0)}, **plans}
         for pname, c in plans.items():
@@ -484,7 +483,7 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
                     shard.capture()
                 k = Timed(dev, False).run(shard.step, steps, warmup)
                 prow.append({"rank": r, "two_joint": shard.n_two_joint, "panda": shard.n_panda,
-                             "us_per_step": k["dt"] / steps * 1e6, "est_cost_us": shard.work / 1e3 if pname == "calibrated" else None,
+                             "us_per_step": k["dt"] / steps * 1e6, "est_us": shard.work / 1e3 if pname == "calibrated" else None,
                              "kernels": {key: p["engine"].last_kernel() for key, p in shard.parts.items()}})
                 del shard
                 gc.collect()
@@ -634,16 +633,18 @@ def worker(args) -> int:
     else:
         # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, cost-balanced cut across the ranks ----
         cost = None
-        if args.calibrate:   # rank 0 measures, every rank cuts with the same numbers
-            c = torch.zeros(4, dtype=torch.float64, device=dev)
+        if args.calibrate:   # rank 0 measures the time curves, every rank cuts with the same numbers
+            n = len(MixedFleetShard.CURVE_SIZES)
+            c = torch.zeros(2 * n, dtype=torch.float64, device=dev)
             if rank == 0:
-                m = MixedFleetShard.calibrate_costs(local_rank, robots=args.calibrate_robots)
-                c = torch.tensor([*m["two_joint"], *m["panda"]], dtype=torch.float64, device=dev)
+                m = MixedFleetShard.calibrate_curves(local_rank)
+                c = torch.tensor(list(m["two_joint"][1]) + list(m["panda"][1]), dtype=torch.float64, device=dev)
             if use_dist:
                 dist.broadcast(c, 0)
             c = c.tolist()
-            cost = {"two_joint": (c[0], c[1]), "panda": (c[2], c[3])}
-            line_extra["cost_model_ns"] = cost
+            sz = list(MixedFleetShard.CURVE_SIZES)
+            cost = {"curves": {"two_joint": (sz, c[:n]), "panda": (sz, c[n:])}}
+            line_extra["cost_model"] = {"robots": sz, "two_joint_us": c[:n], "panda_us": c[n:]}
         shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve, cost=cost)
         # (a HIP graph of the two-stream step replays SLOWER than the eager sequence on this runtime -- 62.1 against 40.3 us per
         # step, profiles/r03_config5_graph_ab.txt: its cross-stream edges become full barriers -- so eager is the default)

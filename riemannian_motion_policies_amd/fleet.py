@@ -388,6 +388,159 @@ class MixedFleetShard:
             out[key] = (per_robot, per_pair)
         return out
 
+    # Kernel time is NOT linear in the robot count: a mapping fills the GPU in rounds (16 384 robots put one wave on every
+    # SIMD), so 21 700 Pandas cost as much as 32 768.  The cut below therefore works on measured TIME CURVES per type:
+    # us per step of the type's engine at a ladder of fleet sizes, with the fleet's own list-length distribution
+    # (calibrate_curves; tracked copy: profiles/r03_cost_calibration.json).
+    CURVE_SIZES = (2048, 4096, 8192, 8208, 12288, 16384, 16400, 20480, 24576, 32768, 32784, 40960, 49152, 65536, 65552,
+                   81920, 98304, 131072)
+    DEFAULT_CURVES = None   # filled below the class (measured on MI355X)
+
+    @staticmethod
+    def calibrate_curves(device: int, sizes=None, seed: int = 5, steps: int = 120):
+        """Measure {type: (sizes, us per step)} on `device` with ragged lists k ~ U{0..K} (the fleet's distribution)."""
+        import numpy as np
+        from . import configs as Cf
+        from .engine import Engine
+        dev = torch.device("cuda", device)
+        sizes = list(sizes or MixedFleetShard.CURVE_SIZES)
+        out = {}
+        for key, builder, sampler, first in (("two_joint", Cf.config5_two_joint, Cf.sample_two_joint_states, 0),
+                                             ("panda", Cf.config3, Cf.sample_panda_states, 1)):
+            _, desc = builder("auto")
+            eng = Engine(desc, device)
+            sph = Cf.sample_spheres(np.random.default_rng([seed, first]))
+            if key == "two_joint":
+                sph[:, :2] *= 2.0
+                sph[:, 2] = 0.1
+            spt = torch.from_numpy(sph).to(dev)
+            us = []
+            for R in sizes:
+                rng = np.random.default_rng([seed, 77, R])
+                st = sampler(rng, R)
+                off, idx = Cf.sample_ragged(rng, R)
+                q, qd, goal = (torch.from_numpy(st[x]).to(dev) for x in ("q", "qd", "goal"))
+                obs = eng.obstacles(spheres=spt, csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx))
+                launch, _ = eng.bind(q, qd, goal, obstacles=obs)
+                for _ in range(20):
+                    launch()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(steps):
+                    launch()
+                b.record()
+                torch.cuda.synchronize(dev)
+                us.append(a.elapsed_time(b) * 1e3 / steps)
+            out[key] = (sizes, us)
+        return out
+
+    @staticmethod
+    def plan_by_curves(total: int, world: int, counts, curves, pair_share=0.2):
+        """Cut the type-sorted fleet so that the slowest rank's ESTIMATED TIME is minimal: bisection on the step time T; for
+        a given T the ranks are filled in order with as many robots as the type's time curve allows (a rank that holds both
+        types runs its two kernels within T in sum).  Robots count by their list length: effective robots =
+        sum(1 - pair_share + pair_share * k_r / mean k).  Returns (cuts, ranges, est_us per rank)."""
+        import numpy as np
+        counts = np.asarray(counts, dtype=np.float64)
+        n_tj = total // 2
+        types = ("two_joint", "panda")
+        seg = {"two_joint": (0, n_tj), "panda": (n_tj, total)}
+        eff, curve = {}, {}
+        for t in types:
+            lo, hi = seg[t]
+            k = counts[lo:hi]
+            w = (1.0 - pair_share) + pair_share * k / max(k.mean(), 1e-9) if hi > lo else k
+            eff[t] = np.concatenate([[0.0], np.cumsum(w)])           # effective robots up to position i
+            sz, us = (np.asarray(x, dtype=np.float64) for x in curves[t])
+            us = np.maximum.accumulate(us)                            # monotone: invertible
+            # (a non-empty part costs at least the smallest measured launch: a 200-robot sliver of a second type is not free)
+            curve[t] = (np.concatenate([[0.0, 1.0], sz]), np.concatenate([[0.0, us[0]], us]))
+
+        def time_of(t, n_eff):
+            sz, us = curve[t]
+            if n_eff <= sz[-1]:
+                return float(np.interp(n_eff, sz, us))
+            return float(us[-1] * n_eff / sz[-1])                    # beyond the ladder: proportional
+
+        def cap_of(t, T):
+            """largest effective robot count of type t with time <= T"""
+            sz, us = curve[t]
+            if T <= 0:
+                return 0.0
+            if T >= us[-1]:
+                return float(sz[-1] * T / us[-1])
+            j = int(np.searchsorted(us, T, side="right")) - 1       # us[j] <= T < us[j+1]
+            if us[j + 1] == us[j]:
+                return float(sz[j + 1])
+            return float(sz[j] + (sz[j + 1] - sz[j]) * (T - us[j]) / (us[j + 1] - us[j]))
+
+        def fill(T):
+            pos = {"two_joint": 0, "panda": 0}       # robots of each type assigned so far (positions in the type's range)
+            cuts, est = [0], []
+            for r in range(world):
+                budget = T
+                took = {}
+                for t in types:
+                    n_t = seg[t][1] - seg[t][0]
+                    if pos[t] >= n_t or budget <= 0:
+                        continue
+                    if t == "panda" and pos["two_joint"] < n_tj:
+                        continue                      # contiguous cut: Pandas only after the last TwoJoint robot
+                    cap = cap_of(t, budget)
+                    target = eff[t][pos[t]] + cap
+                    new = int(np.searchsorted(eff[t], target, side="right")) - 1
+                    new = max(min(new, n_t), pos[t])
+                    took[t] = (pos[t], new)
+                    budget -= time_of(t, eff[t][new] - eff[t][pos[t]])
+                    pos[t] = new
+                cuts.append(pos["two_joint"] + pos["panda"])
+                est.append(T - budget)
+            return cuts, est, pos["two_joint"] + pos["panda"] >= total
+
+        lo_T, hi_T = 0.0, sum(time_of(t, eff[t][-1]) for t in types) + 1.0
+        for _ in range(40):
+            mid = 0.5 * (lo_T + hi_T)
+            if fill(mid)[2]:
+                hi_T = mid
+            else:
+                lo_T = mid
+        cuts, est, ok = fill(hi_T)
+        if any(cuts[r + 1] == cuts[r] for r in range(world)) and world > 1 and 0 < n_tj < total:
+            # a fleet too small to fill the ranks at the minimal step time (a launch costs its latency floor however few
+            # robots it carries): no rank is left empty -- the ranks are dealt to the types in proportion to their times and
+            # every type is split evenly (by effective robots) over its ranks
+            t_all = {t: time_of(t, eff[t][-1]) for t in types}
+            n_a = int(round(world * t_all["two_joint"] / max(t_all["two_joint"] + t_all["panda"], 1e-12)))
+            n_a = min(max(n_a, 1), world - 1)
+            cuts = [0]
+            for t, n_r, base in (("two_joint", n_a, 0), ("panda", world - n_a, n_tj)):
+                for i in range(1, n_r + 1):
+                    target = eff[t][-1] * i / n_r
+                    cuts.append(base + min(int(np.searchsorted(eff[t], target, side="left")), len(eff[t]) - 1))
+            est = []
+            for r in range(world):
+                t = "two_joint" if r < n_a else "panda"
+                lo_, hi_ = cuts[r] - seg[t][0], cuts[r + 1] - seg[t][0]
+                est.append(time_of(t, eff[t][hi_] - eff[t][lo_]))
+        cuts[-1] = total
+        for r in range(1, world + 1):
+            cuts[r] = max(cuts[r], cuts[r - 1])
+        # slivers: a rank that holds both types with fewer than 256 robots of one of them hands those to the neighbour that
+        # runs that type anyway (a second kernel launch for a handful of robots costs its latency floor)
+        for r in range(world):
+            lo, hi = cuts[r], cuts[r + 1]
+            if lo < n_tj < hi:
+                if hi - n_tj < 256 and r + 1 < world:
+                    cuts[r + 1] = n_tj
+                elif n_tj - lo < 256 and r > 0:
+                    cuts[r] = n_tj
+        ranges = []
+        for r in range(world):
+            lo, hi = cuts[r], cuts[r + 1]
+            ranges.append({"two_joint": (min(lo, n_tj), min(hi, n_tj)),
+                           "panda": (max(lo, n_tj) - n_tj, max(hi, n_tj) - n_tj)})
+        return cuts, ranges, est
+
     @staticmethod
     def plan(total: int, world: int, counts, cost=None):
         """counts[r] = obstacles robot r sees, in TYPE-SORTED order (first total // 2 robots: TwoJoint, rest: Panda).
@@ -395,6 +548,16 @@ class MixedFleetShard:
         Returns (cuts, ranges, work): cuts = world + 1 indices into the sorted fleet; ranges[rank] = {type: (lo, hi)} in
         per-type robot numbering; work[r] = estimated ns of robot r."""
         import numpy as np
+        if cost is None and MixedFleetShard.DEFAULT_CURVES is not None:
+            cost = {"curves": MixedFleetShard.DEFAULT_CURVES}
+        if cost is not None and "curves" in cost:
+            cuts, ranges, est = MixedFleetShard.plan_by_curves(total, world, counts, cost["curves"])
+            work = np.zeros(total)                     # per-robot share of its rank's estimated time (ns)
+            for r in range(world):
+                n = cuts[r + 1] - cuts[r]
+                if n > 0:
+                    work[cuts[r]:cuts[r + 1]] = est[r] * 1e3 / n
+            return cuts, ranges, work
         cost = cost or MixedFleetShard.DEFAULT_COST
         counts = np.asarray(counts)
         n_tj = total // 2
@@ -537,3 +700,10 @@ class MixedFleetShard:
 
     def dominant_kernel(self) -> str:
         return self.parts[self._dom]["engine"].last_kernel()
+
+
+# measured on one MI355X (profiles/r03_cost_calibration.json: tools/calibrate_costs.py, kernels of round 3)
+MixedFleetShard.DEFAULT_CURVES = {
+    "two_joint": (list(MixedFleetShard.CURVE_SIZES), [8.98, 11.73, 10.24, 11.87, 12.08, 12.34, 11.89, 12.27, 12.4, 12.45, 12.94, 13.65, 13.81, 15.7, 16.45, 17.91, 24.7, 28.58]),
+    "panda": (list(MixedFleetShard.CURVE_SIZES), [20.41, 20.89, 24.82, 32.5, 32.76, 33.11, 34.09, 35.42, 35.57, 36.14, 39.3, 40.86, 41.84, 47.91, 65.8, 70.76, 78.2, 90.65]),
+}

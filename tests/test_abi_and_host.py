@@ -187,10 +187,21 @@ def test_mixed_fleet_plan_is_a_balanced_partition():
     for r in range(world):
         (a, b), (c, d) = ranges[r]["two_joint"], ranges[r]["panda"]
         assert (b - a) + (d - c) == cuts[r + 1] - cuts[r]
-    loads = [work[cuts[r]:cuts[r + 1]].sum() for r in range(world)]
-    assert max(loads) <= work.sum() / world + work.max()      # balanced to within one robot
+    assert all(cuts[r + 1] > cuts[r] for r in range(world)), "no rank may be left empty"
     assert max(cuts[r + 1] - cuts[r] for r in range(world)) > 1.5 * min(cuts[r + 1] - cuts[r] for r in range(world)), \
-        "TwoJoint robots are ~5x cheaper: a work-balanced cut must NOT be an equal-count cut"
+        "TwoJoint robots are cheaper: a time-balanced cut must NOT be an equal-count cut"
+    # the full-size fleet on 8 ranks: cut by the measured time curves (fleet.MixedFleetShard.DEFAULT_CURVES) -- kernel time
+    # moves in rounds of 16 384 robots, so the Pandas are spread thin and the cheap TwoJoint robots packed
+    big = rng.integers(0, 33, size=262144)
+    cuts8, ranges8, _ = MixedFleetShard.plan(262144, 8, big)
+    est = MixedFleetShard.plan_by_curves(262144, 8, big, MixedFleetShard.DEFAULT_CURVES)[2]
+    assert cuts8[-1] == 262144 and max(est) <= 1.1 * (sum(est) / 8) + 5.0
+    assert sum(1 for r in ranges8 if r["two_joint"][1] > r["two_joint"][0]) <= 3 and \
+        sum(1 for r in ranges8 if r["panda"][1] > r["panda"][0]) >= 5
+    # the round-2 linear model stays available
+    cutsl, _, workl = MixedFleetShard.plan(total, world, counts, cost=MixedFleetShard.DEFAULT_COST)
+    loads = [workl[cutsl[r]:cutsl[r + 1]].sum() for r in range(world)]
+    assert max(loads) <= workl.sum() / world + workl.max()      # balanced to within one robot
     # one rank: everything
     cuts1, ranges1, _ = MixedFleetShard.plan(total, 1, counts)
     assert cuts1 == [0, total] and ranges1[0] == {"two_joint": (0, n_tj), "panda": (0, total - n_tj)}

@@ -43,3 +43,41 @@ def test_awkward_fleet_sizes_default_dispatch(hip_lib, name):
         tol = 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))     # the tolerance of tests/test_gpu_parity.py
         assert (err <= tol).all(), f"{name} R={R}: worst {err.max():.3e} ({eng.last_kernel()})"
         assert int((st != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_eight_rank_shard_shapes_of_the_mixed_fleet(rank):
+    """BASELINE config 5 at its full size: the shards rank 0 and rank 7 of the 262 144-robot fleet would own on 8 GPUs
+    (fleet.MixedFleetShard.synthetic: tens of thousands of ragged TwoJoint robots on one GPU / ~22 k ragged Pandas),
+    built and stepped on this GPU exactly as bench.py --emulate-world 8 does, against the oracle on a sample of each robot
+    type present; every robot finite (or flagged)."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle as O
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    shard = MixedFleetShard.synthetic(262144, 8, rank, 0)
+    assert shard.n_two_joint + shard.n_panda > 15000
+    for _ in range(2):
+        shard.step()
+    torch.cuda.synchronize()
+    n_ref = 160
+    for key, part in shard.parts.items():
+        q, qd, goal, _ = part["keep"]
+        h = part["host"]
+        n = min(n_ref, part["n"])
+        off = h["csr_offset"][: n + 1]
+        ref = O.step(part["desc"], q[:n].cpu().numpy(), qd[:n].cpu().numpy(), goal[:n].cpu().numpy(),
+                     spheres=h["spheres"], csr_offset=off, csr_index=h["csr_index"][: off[-1]])
+        got = part["out"][:n].cpu().numpy()
+        err = np.abs(got - ref["qdd64"]).max(axis=1)
+        tol = 1e-5 * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
+        # perf inputs are unrestricted (near-contact robots, and the TwoJoint set has no inertia leaf): the relative bound of
+        # test_config5_* applies to the ill-conditioned ones
+        cond = np.linalg.cond(ref["M"])
+        ok = (err <= tol) | (err <= 1e-3 * np.abs(ref["qdd64"]).max(axis=1)) | (cond > 100)
+        assert ok.mean() >= 0.97, f"rank {rank} {key}: worst {err.max():.3e}, {(~ok).sum()} of {n} out"
+        allout = part["out"].cpu().numpy()
+        assert np.isfinite(allout).mean() > 0.999, f"rank {rank} {key}: {np.isnan(allout).any(axis=1).sum()} non-finite robots"
