@@ -464,31 +464,9 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
 //   pass 2  the set bits are dealt round-robin to the quad's lanes, which fetch their pair again (an L1 / L2 hit: the
 //           lines were read a few hundred cycles ago) and run the transcendental chain on it.
 struct F3 { float x, y, z; };
-// One leaf's first 32 pairs as this lane holds them between the loads and the range test: pairs sub, sub + 4, ... of both
-// arrays.  PairRegs travels from one leaf to the next: the loads of the NEXT leaf's chunk are issued as soon as this leaf's
-// tests have freed the registers, and land while this leaf's in-range pairs are evaluated and pulled back (the step is
-// bound by memory latency otherwise: one round trip per leaf on every wave's critical path).
-struct PairRegs {
-  F3 a[8], o[8];
-  const float* tag;  // p_link base the registers were loaded from (nullptr: nothing prefetched)
-};
-__device__ __forceinline__ void pair_regs_load(PairRegs& r, const float* pl, const float* po, int sub) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pos = sub + kQuad * i;
-    r.a[i] = *reinterpret_cast<const F3*>(pl + 3 * pos);
-    r.o[i] = *reinterpret_cast<const F3*>(po + 3 * pos);
-  }
-  r.tag = pl;
-}
-// next_pl / next_po: first pair of the leaf that follows in execution order when that leaf has a full chunk (>= 32
-// pairs), else nullptr
-template <bool PREFETCH>
 __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const float* po, int count, int sub,
                                                           const float P3[3], const float V3[3], const float A3[3],
-                                                          const float* P, const float* IP, float thr2, float S[6], float h[3],
-                                                          PairRegs* pf = nullptr, const float* next_pl = nullptr,
-                                                          const float* next_po = nullptr) {
+                                                          const float* P, const float* IP, float thr2, float S[6], float h[3]) {
   const float vv = dot3(V3, V3);
   auto diff_of = [&](int b, float diff[3]) {
     const F3 a = *reinterpret_cast<const F3*>(pl + 3 * b);
@@ -503,21 +481,22 @@ __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const
     if (base + 32 <= count) {
       // full chunk (the usual case: 32 pairs per leaf): all sixteen loads are issued before the first test -- a guarded
       // loop pays one memory round trip per slot (measured: 163 us per step at 65 536 robots, latency bound)
-      PairRegs loc;
-      PairRegs& r = PREFETCH ? *pf : loc;
-      // (wave-uniform: the tag is the robot's own row address, but every lane of the wave prefetched the same leaf)
-      if (!PREFETCH || base != 0 || !__all(r.tag == pl)) pair_regs_load(r, pl + 3 * base, po + 3 * base, sub);
+      // (holding the NEXT leaf's 48 registers through the pull-back as a prefetch was tried: the 256-register build then
+      // spills 40 dwords in the frame loop -- 184 us per step against 124; tools/experiments/README.md)
+      F3 a[8], o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float dx = (P3[0] + (r.a[i].x - P3[0])) - r.o[i].x;
-        const float dy = (P3[1] + (r.a[i].y - P3[1])) - r.o[i].y;
-        const float dz = (P3[2] + (r.a[i].z - P3[2])) - r.o[i].z;
+        const int pos = base + sub + kQuad * i;
+        a[i] = *reinterpret_cast<const F3*>(pl + 3 * pos);
+        o[i] = *reinterpret_cast<const F3*>(po + 3 * pos);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dx = (P3[0] + (a[i].x - P3[0])) - o[i].x;
+        const float dy = (P3[1] + (a[i].y - P3[1])) - o[i].y;
+        const float dz = (P3[2] + (a[i].z - P3[2])) - o[i].z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         m |= !(d2 > thr2) ? (1u << (kQuad * i)) : 0u;
-      }
-      if (PREFETCH && base + 32 >= count) {  // last chunk of this leaf tested: the registers are free for the next leaf
-        if (next_pl) pair_regs_load(r, next_pl, next_po, sub);
-        else r.tag = nullptr;
       }
     } else {
 #pragma unroll
@@ -1246,12 +1225,6 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
     int floc_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);  // (loop-local copy, as in the walk: the offset, not the pointer)
     if (MINW >= 3) asm volatile("" : "+v"(floc_off));
     const float* floc = lds + floc_off;
-    // explicit-pair plain builds with registers to spare (two waves per SIMD): the next leaf's pairs are prefetched
-    // (MEASURED SLOWER and therefore off: holding the next leaf's 48 registers through the pull-back makes the 256-register
-    // build spill 40 dwords in the frame loop -- 184.1 us per step at 65 536 robots against 123.7 without the prefetch)
-    constexpr bool kPrefetchPairs = false && OBS == RMP2_OBS_EXPLICIT_PAIRS && PLAIN && !STAGE && MINW <= 2;
-    PairRegs pair_regs;
-    pair_regs.tag = nullptr;
     int4 lfr_next = STAGE ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4*>(&prog->leaf_frames[0]);
     for (int t = 0; t < hdr.n_leaf_ops; ++t) {
       if (MINW >= 3) {  // thirds of the frame loop at 3 / 2 / 1
@@ -1337,29 +1310,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
             // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
             const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
-            if constexpr (kPrefetchPairs) {
-              // the leaf that follows in execution order (exec_leaves[] holds the FK leaves in that order): when it is a
-              // distance leaf with a full chunk its first 32 pairs are prefetched by this leaf's loop
-              const float* npl = nullptr;
-              const float* npo = nullptr;
-              const int e = op.leaf_begin + li;
-              if (e + 1 < hdr.n_fk) {
-                const DevLeaf& nx = prog->exec_leaves[e + 1];
-                if (nx.taskmap == RMP2_TASKMAP_FK_DISTANCE) {
-                  const int npb = obs.pair_begin[nx.index];
-                  if (obs.pair_begin[nx.index + 1] - npb >= 32) {
-                    const size_t nb = ((size_t)(live ? robot : 0) * obs.n_pairs + npb) * 3;
-                    npl = obs.p_link + nb;
-                    npo = obs.p_obs + nb;
-                  }
-                }
-              }
-              pair_loop_explicit_culled<true>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
-                                              thr * thr * kCullSlack, S, h, &pair_regs, npl, npo);
-            } else {
-              pair_loop_explicit_culled<false>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
-                                               thr * thr * kCullSlack, S, h);
-            }
+            pair_loop_explicit_culled(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
+                                      thr * thr * kCullSlack, S, h);
           } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
             pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
                                                                   V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);
