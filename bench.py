@@ -402,9 +402,9 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         # gather + stream orderings + launch inside librmp2_hip.so: one C-ABI call per control step (the torch.distributed
         # loop below costs ~50 us of host time per step -- more than the step kernel takes)
         from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
-        exch = exch if isinstance(exch, NativeObstacleExchange) else NativeObstacleExchange(K // world, dev)
-        if exch.pending == 0:   # (a reused exchange -- the emulation -- still holds the previous user's last gather)
-            exch.start(local)
+        exch = exch if isinstance(exch, NativeObstacleExchange) else NativeObstacleExchange(K // world, dev, depth=args.exchange_depth)
+        while exch.pending < exch.depth:   # (a reused exchange -- the emulation -- still holds the previous user's gathers)
+            exch.start(local, local_is_ready=True)
         # (the rank's slice is static in this benchmark -- as the fixed `local_ready` event of the torch-driven loop below --
         # so no producer event is put between two step kernels; a moving slice orders itself with next_local_is_ready=False)
         one_step = exch.bind(eng, q, qd, goal, out, next_local=local, next_local_is_ready=True)
@@ -496,7 +496,7 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
         from riemannian_motion_policies_amd import configs as Cf
         from riemannian_motion_policies_amd.fleet import NativeObstacleExchange, ObstacleExchange
         native = args.exchange == "native"
-        exch = NativeObstacleExchange(Cf.N_SPHERES, dev) if native else ObstacleExchange(Cf.N_SPHERES, dev)
+        exch = NativeObstacleExchange(Cf.N_SPHERES, dev, depth=args.exchange_depth) if native else ObstacleExchange(Cf.N_SPHERES, dev)
         if native:
             exch.set_peer_wait(True)   # (time the orderings an N-rank exchange needs, not the one-rank shortcut)
         for r in range(W):
@@ -629,7 +629,7 @@ def worker(args) -> int:
         total_robots = R * world
         bound = wl.get("bound", "valu")
         parallelism = f"robot-batch split x{world}" + (
-            f", RCCL all-gather of the sphere table per step (side stream, double-buffered; exchange = {args.exchange})" if workload == "config4" else "")
+            f", RCCL all-gather of the sphere table per step (side stream, exchange = {args.exchange}, tables gathered {args.exchange_depth if args.exchange == 'native' else 1} step(s) ahead)" if workload == "config4" else "")
     else:
         # ---- config 5: type-sorted mixed fleet, ragged obstacle lists, cost-balanced cut across the ranks ----
         cost = None
@@ -736,6 +736,9 @@ def main():
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="config4: obstacle exchange inside librmp2_hip.so (one C-ABI call per step) or driven from Python "
                          "through torch.distributed (A/B)")
+    ap.add_argument("--exchange-depth", type=int, default=2, choices=[1, 2],
+                    help="config4, native exchange: tables gathered this many control steps ahead (2: a full step of slack "
+                         "for the gather, one more step of obstacle staleness)")
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")

@@ -269,15 +269,21 @@ int rmp2_exchange_create(const char *rccl_library, const rmp2_rccl_uid *uid, int
                          int spheres_per_rank, rmp2_exchange **out);
 int rmp2_exchange_destroy(rmp2_exchange *x);
 const char *rmp2_exchange_last_error(const rmp2_exchange *x);
-int rmp2_exchange_pending(const rmp2_exchange *x);   /* gathers started and not yet consumed by a step (0 .. 2) */
+int rmp2_exchange_pending(const rmp2_exchange *x);
+/* Pipeline depth (before the first rmp2_exchange_start): depth + 1 gathers may be outstanding, depth + 1 table buffers are
+ * in use.  1 (default): the table of step k is gathered while step k - 1 runs, from slices produced before step k - 1 was
+ * issued.  2: gathered while steps k - 2 and k - 1 run -- one more control step of obstacle staleness, and a full step of
+ * slack for the gather: it only gets a CU when waves of the running step retire (the step kernel fills every SIMD), so at
+ * depth 1 the next step regularly waits for it. */
+int rmp2_exchange_set_depth(rmp2_exchange *x, int32_t depth);   /* gathers started and not yet consumed by a step (0 .. 2) */
 /* on != 0: a one-rank exchange orders its steps as an N-rank one does (GPU-side wait on the gathered table kept): what a
  * single-GPU EMULATION of an N-rank run must time.  No effect at nranks > 1 (the wait is always kept there). */
 int rmp2_exchange_set_peer_wait(rmp2_exchange *x, int32_t on);
 /* Issue the all-gather of `local` (device [spheres_per_rank][4]) into the free table buffer; it waits for the last step
  * that read the buffer it overwrites and -- local_is_ready == 0 -- for everything enqueued on `stream` so far (the producer
  * of `local`).  local_is_ready != 0: the caller guarantees that `local` is complete when this call is made (produced by an
- * earlier, already synchronised step of its pipeline, or static): no event is put on `stream`.  At most two gathers may be
- * outstanding. */
+ * earlier, already synchronised step of its pipeline, or static): no event is put on `stream`.  At most depth + 1 gathers may
+ * be outstanding. */
 int rmp2_exchange_start(rmp2_exchange *x, const float *local, int32_t local_is_ready, void *stream);
 /* One control step (as rmp2_step with SHARED_SPHERES) on the OLDEST outstanding table.  next_local != NULL: the gather of
  * the next table is issued before the launch (same as rmp2_exchange_start(x, next_local, next_local_is_ready, stream)).

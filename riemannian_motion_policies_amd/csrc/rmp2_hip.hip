@@ -1657,18 +1657,20 @@ int load_rccl(const char* path, RcclApi& api, std::string& err) {
 }  // namespace
 
 struct rmp2_exchange {
+  static constexpr int kBuf = 3;                   // table buffers: depth + 1 are in use
   RcclApi api;
   void* comm = nullptr;
   int device = 0, rank = 0, world = 1, per_rank = 0;
-  float* table[2] = {nullptr, nullptr};    // [world * per_rank][4]
-  hipStream_t side = nullptr;              // the gathers' stream
-  hipEvent_t ready[2] = {nullptr, nullptr};        // gather into table b complete
-  hipEvent_t reader_done[2] = {nullptr, nullptr};  // last kernel that read table b complete (the launch's own stop event)
+  int depth = 1;                                   // gathers that may be outstanding minus one ... see rmp2_exchange_set_depth
+  float* table[kBuf] = {nullptr, nullptr, nullptr};    // [world * per_rank][4]
+  hipStream_t side = nullptr;                      // the gathers' stream
+  hipEvent_t ready[kBuf] = {nullptr, nullptr, nullptr};        // gather into table b complete
+  hipEvent_t reader_done[kBuf] = {nullptr, nullptr, nullptr};  // last kernel that read table b complete (the launch's own stop event)
   hipEvent_t produced = nullptr;                   // "everything enqueued on the caller's stream so far"
-  bool reader_valid[2] = {false, false};
-  int pending[2] = {0, 0}, n_pending = 0, next = 0;
+  bool reader_valid[kBuf] = {false, false, false};
+  int pending[kBuf] = {0, 0, 0}, n_pending = 0, next = 0;
   bool peer_wait = false;  // keep the GPU-side wait at world 1 too (the single-GPU emulation of an N-rank run: rmp2_exchange_set_peer_wait)
-  int throttle_us = 500;  // bound of the host throttle in rmp2_exchange_step (0: free-running; RMP2_EXCHANGE_THROTTLE_US in tuning builds)
+  int throttle_us = 500;  // bound of the host throttle in rmp2_exchange_step (0: free-running; RMP2_EXCHANGE_THROTTLE_US)
   std::string error;
 };
 
@@ -1699,7 +1701,7 @@ int rmp2_exchange_create(const char* rccl_library, const rmp2_rccl_uid* uid, int
     // reader_done[] / produced order work of THIS GPU only (rmp2_fence_* rules)
     const unsigned ready_flags = hipEventDisableTiming | (nranks == 1 ? hipEventDisableSystemFence : 0u);
     const unsigned local_flags = hipEventDisableTiming | hipEventDisableSystemFence;
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+    for (int b = 0; b < rmp2_exchange::kBuf && e == hipSuccess; ++b) {
       e = hipMalloc(&x->table[b], sizeof(float) * 4 * nranks * spheres_per_rank);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ready[b], ready_flags);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&x->reader_done[b], local_flags);
@@ -1731,7 +1733,7 @@ int rmp2_exchange_destroy(rmp2_exchange* x) {
   (void)hipSetDevice(x->device);
   if (x->side) (void)hipStreamSynchronize(x->side);
   if (x->comm && x->api.CommDestroy) x->api.CommDestroy(x->comm);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < rmp2_exchange::kBuf; ++b) {
     if (x->table[b]) (void)hipFree(x->table[b]);
     if (x->ready[b]) (void)hipEventDestroy(x->ready[b]);
     if (x->reader_done[b]) (void)hipEventDestroy(x->reader_done[b]);
@@ -1745,6 +1747,14 @@ int rmp2_exchange_destroy(rmp2_exchange* x) {
 int rmp2_exchange_set_peer_wait(rmp2_exchange* x, int32_t on) {
   if (!x) return RMP2_ERR_INVALID_ARGUMENT;
   x->peer_wait = on != 0;
+  return RMP2_OK;
+}
+
+int rmp2_exchange_set_depth(rmp2_exchange* x, int32_t depth) {
+  if (!x || depth < 1 || depth > rmp2_exchange::kBuf - 1) return RMP2_ERR_INVALID_ARGUMENT;
+  if (x->n_pending != 0) return x->error = "set the depth before the first gather is started", RMP2_ERR_INVALID_ARGUMENT;
+  x->depth = depth;
+  x->next = 0;
   return RMP2_OK;
 }
 
@@ -1763,7 +1773,8 @@ const char* rmp2_exchange_last_error(const rmp2_exchange* x) { return x ? x->err
 // the buffer it overwrites.
 int rmp2_exchange_start(rmp2_exchange* x, const float* local, int32_t local_is_ready, void* stream) {
   if (!x || !local) return RMP2_ERR_INVALID_ARGUMENT;
-  if (x->n_pending >= 2) return x->error = "two gathers are outstanding: step before starting a third", RMP2_ERR_INVALID_ARGUMENT;
+  if (x->n_pending > x->depth)
+    return x->error = "too many gathers outstanding (depth + 1): step before starting another", RMP2_ERR_INVALID_ARGUMENT;
   const int b = x->next;
   if (!local_is_ready) {  // order the gather behind the producer of `local` on the caller's stream (an event packet between
     XCH_TRY(x, hipEventRecord(x->produced, static_cast<hipStream_t>(stream)));  // two step kernels: ~4 us of the step)
@@ -1774,7 +1785,7 @@ int rmp2_exchange_start(rmp2_exchange* x, const float* local, int32_t local_is_r
   if (r != 0) return x->error = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(r) : "?"), RMP2_ERR_HIP;
   XCH_TRY(x, hipEventRecord(x->ready[b], x->side));
   x->pending[x->n_pending++] = b;
-  x->next ^= 1;
+  x->next = (x->next + 1) % (x->depth + 1);
   return RMP2_OK;
 }
 
@@ -1788,7 +1799,7 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   if (!x || !h) return RMP2_ERR_INVALID_ARGUMENT;
   if (x->n_pending < 1) return x->error = "no gathered table outstanding: rmp2_exchange_start first", RMP2_ERR_INVALID_ARGUMENT;
   const int b = x->pending[0];
-  x->pending[0] = x->pending[1];
+  for (int i = 1; i < x->n_pending; ++i) x->pending[i - 1] = x->pending[i];
   --x->n_pending;
   // Host throttle: wait (bounded) until the gather of THIS step's table has completed -- it was issued one call ago and runs
   // as soon as step k - 2 has finished, so the host stays at most ~1.5 steps ahead of the GPU, which is all the launch

@@ -192,11 +192,12 @@ class NativeObstacleExchange:
         for k in ...: qdd = exch.step(engine, q, qd, goal, out, next_local=local_k_plus_1)
     """
 
-    def __init__(self, spheres_per_rank: int, device, group=None):
+    def __init__(self, spheres_per_rank: int, device, group=None, depth: int = 1):
         import ctypes
         from . import _native
         self._lib = _native.lib()
         self.device = torch.device(device)
+        self.depth = int(depth)
         if self.device.type != "cuda":
             raise ValueError("NativeObstacleExchange needs a HIP device (the CPU test path uses ObstacleExchange)")
         collective = dist.is_available() and dist.is_initialized()
@@ -223,6 +224,8 @@ class NativeObstacleExchange:
             raise _native.Rmp2Error("rmp2_exchange_create: " + self._lib.rmp2_last_error(None).decode())
         self._table = ctypes.c_void_p()
         self._ctypes = ctypes
+        if self.depth != 1:   # (depth + 1 gathers outstanding: include/rmp2.h rmp2_exchange_set_depth)
+            self._check(self._lib.rmp2_exchange_set_depth(self._h, self.depth))
 
     def _check(self, rc):
         if rc != 0:

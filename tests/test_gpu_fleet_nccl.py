@@ -138,12 +138,13 @@ def test_bound_launches_signal_the_reader_fence_themselves(nccl_group, golden_di
         exch.start(local); exch.start(local); exch.start(local)
 
 
-def test_native_exchange_one_call_per_step_against_the_oracle(hip_lib, golden_dir):
+@pytest.mark.parametrize("depth", [1, 2])
+def test_native_exchange_one_call_per_step_against_the_oracle(hip_lib, golden_dir, depth):
     """The exchange inside librmp2_hip.so (rmp2_exchange_*: RCCL bound at run time, communicator of its own): gather,
     stream orderings and the step launch are one C-ABI call per control step.  The table moves every step; step k must
-    see table k through whichever of the two buffers it lands in, the `local` slice is rewritten on the launch stream
-    between steps (the gather of step k + 1 must wait for that producer, and must not overwrite the buffer step k - 1 is
-    still reading)."""
+    see table k through whichever buffer it lands in (depth + 1 buffers, tables gathered `depth` steps ahead), the slices
+    are rewritten on the launch stream between steps (a gather must wait for that producer, and must not overwrite a buffer
+    an earlier step is still reading)."""
     import torch
     import oracle as O
     from riemannian_motion_policies_amd import configs as Cf
@@ -156,25 +157,30 @@ def test_native_exchange_one_call_per_step_against_the_oracle(hip_lib, golden_di
     reps = 64   # 4 096 robots: the kernels take long enough for a missing ordering to show
     q, qd, goal = (torch.from_numpy(np.tile(g[k], (reps, 1))).to(dev) for k in ("q", "qd", "goal"))
     out = torch.empty_like(q)
-    K = len(g["spheres"])
-    tables = [g["spheres"].copy() for _ in range(6)]
+    K, steps = len(g["spheres"]), 6
+    tables = [g["spheres"].copy() for _ in range(steps + depth)]
     for k, t in enumerate(tables):
         t[:, :2] *= np.float32(1.0 + 0.03 * k)
     dev_tables = [torch.from_numpy(t).to(dev) for t in tables]
-    local = dev_tables[0].clone()
-    exch = NativeObstacleExchange(K, dev)
+    # the slice of a gather must stay untouched until the gather has run: one slice buffer per outstanding gather (+ 1)
+    slices = [torch.empty_like(dev_tables[0]) for _ in range(depth + 1)]
+    exch = NativeObstacleExchange(K, dev, depth=depth)
     assert exch.world == 1
-    exch.start(local)
-    launch = exch.bind(eng, q, qd, goal, out, next_local=local)
+    for k in range(depth):                      # prime: tables 0 .. depth - 1
+        slices[k % (depth + 1)].copy_(dev_tables[k])
+        exch.start(slices[k % (depth + 1)])
+    assert exch.pending == depth
     outs, seen = [], []
-    for k in range(5):
-        local.copy_(dev_tables[k + 1])      # producer of the NEXT table on the launch stream, right before the call that gathers it
-        launch()                            # waits for table k, gathers table k + 1 from `local`, launches step k
+    for k in range(steps):
+        sl = slices[(k + depth) % (depth + 1)]
+        sl.copy_(dev_tables[k + depth])         # producer of table k + depth on the launch stream, right before the call that gathers it
+        exch.step(eng, q, qd, goal, out, next_local=sl)   # waits for table k, gathers table k + depth, launches step k
         seen.append(exch._table.value)
         outs.append(out[: g["q"].shape[0]].clone())
     torch.cuda.synchronize(dev)
-    assert len(set(seen)) == 2 and seen[0] == seen[2] == seen[4] and seen[1] == seen[3], "the two table buffers must alternate"
-    for k in range(5):
+    assert len(set(seen)) == depth + 1 and all(seen[i] == seen[i + depth + 1] for i in range(steps - depth - 1)), \
+        "the table buffers must rotate"
+    for k in range(steps):
         # (about WHICH table a step read, not about near-contact rounding: 1e-4 relative against tables that differ by
         # more than 1e-3 from one step to the next -- as test_bound_launches_signal_the_reader_fence_themselves)
         ref = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[k])["qdd64"]
@@ -185,5 +191,6 @@ def test_native_exchange_one_call_per_step_against_the_oracle(hip_lib, golden_di
             prev = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[k - 1])["qdd64"]
             assert np.abs(ref - prev).max() > 1e-3
     with pytest.raises(Exception, match="outstanding"):
-        exch.start(local); exch.start(local); exch.start(local)
+        for _ in range(depth + 2):
+            exch.start(slices[0])
     exch.close()
