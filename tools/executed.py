@@ -28,9 +28,11 @@ out = {"workload": sys.argv[4], "robots": int(sys.argv[5]),
        "salu_insts_per_wave": a.get("SQ_INSTS_SALU", 0) / waves,
        "lds_insts_per_wave": a.get("SQ_INSTS_LDS", 0) / waves,
        "vmem_insts_per_wave": (a.get("SQ_INSTS_VMEM_RD", 0) + a.get("SQ_INSTS_VMEM_WR", 0)) / waves if "SQ_INSTS_VMEM_RD" in a else None,
-       "gpu_busy_cycles_per_launch": busy,
-       "issue_slot_occupancy": (a["SQ_INSTS_VALU"] / n_simd * 2.0) / busy if busy else None,
-       "issue_slot_occupancy_note": "VALU instructions per SIMD x 2 cycles (wave64 fp32 issue) / GRBM_GUI_ACTIVE of the dispatch",
+       "wave_lifetime_cycles": 4.0 * a["SQ_WAVE_CYCLES"] / waves,
+       "issue_slot_occupancy": (a["SQ_INSTS_VALU"] / n_simd * 2.0) / (4.0 * a["SQ_WAVE_CYCLES"] / waves),
+       "issue_slot_occupancy_note": "VALU instructions per SIMD x 2 cycles (wave64 fp32 issue) / mean wave lifetime in cycles "
+                                    "(4 x SQ_WAVE_CYCLES / SQ_WAVES: the counter ticks every fourth cycle; all waves of the launch are "
+                                    "co-resident at this fleet size, so a wave's lifetime is the kernel's duration)",
        "pair_trips_per_wave_step": float(m.group(1)) if m else None,
        "in_range_pairs_per_robot_step": float(m.group(2)) if m else None,
        "in_range_pair_fraction": float(m.group(2)) / 256.0 if m else None,
