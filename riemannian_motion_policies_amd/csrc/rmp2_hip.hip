@@ -1268,7 +1268,13 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //     R:    4096   8192  12288  16384  20480  32768  65536
   //     hex    9.0   10.1   12.0   17.1   18.9   27.7   52.5
   //     quad  11.3   11.9   11.9   12.3   12.2   12.4   15.5
-  const int hex_max = h->has_point ? 20480 : 8192;
+  // Attached-point leaves (round 3: carried by the quad mapping too, per-pair Jacobians collapsed into one pull-back per
+  // frame) -- quad at every fleet size (profiles/r03_dispatch_sweep.txt, exp-05 set on the Panda, 4 pairs per leaf, us per step):
+  //     R:    4096  16384  20480  32768  65536
+  //     hex   33.3   80.3  102.8  155.0  301.5
+  //     quad  26.3   28.6   33.5   58.3   90.8
+  //     lane  79.7   80.6   83.8   88.9  105.1
+  const int hex_max = h->has_point ? 0 : 8192;
   // the fused rollout of a solve = PINV handle (the reference's only resolve, rmp.py:153-154, inside the closed loop): the hex
   // mapping carries the strict pseudo-inverse through its careful path at any fleet size
   const bool strict_rollout = h->strict && rollout;
@@ -1276,8 +1282,9 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (the quad mapping's resolve is AUTO: never a silent change of semantics)
-  const bool lane = !rollout && (h->has_point || h->kernel_choice == 1 ||
-                                 (h->kernel_choice == 0 && !h->has_distance && R > 32768));
+  // (attached-point leaves: hex up to 20 480 robots, the quad mapping beyond -- round 3; the lane mapping on request)
+  const bool lane = !rollout && (h->kernel_choice == 1 ||
+                                 (h->kernel_choice == 0 && !h->has_distance && !h->has_point && R > 32768));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
     case 0: (N == 2 ? launch_quad_n2_s0 : launch_quad_n9_s0)(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;

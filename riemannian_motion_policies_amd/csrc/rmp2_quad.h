@@ -645,7 +645,12 @@ constexpr int kObsAny = -1;
 // FLAVOR: kGeneral = everything at run time (debug outputs M / f, rollout loop, any obstacle mode); kPlainStep = one control
 // step, no debug outputs, OBS fixed; kPlainRollout = the fused rollout loop, no debug outputs, OBS fixed (sphere-table modes).
 constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
-template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral>
+// PT: the set carries attached-point leaves ([FK, TaskmapRelative4x4, 4x4 -> position] + CollisionAvoidance, taskmap.py:79-99,
+// rmp.py:264-315): every frame additionally leaves its world rotation, angular velocity and angular bias acceleration in LDS
+// (16 floats per robot and frame behind the other regions).
+constexpr int kPtSlot = 16;
+template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral,
+          bool PT = false>
 __global__ void __launch_bounds__(kWave, MINW)
 rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
                       const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
@@ -660,6 +665,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   if (LEAN) out.M = nullptr, out.f = nullptr;
 #endif
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
+  static_assert(!PT || (MINW < 4 && !CAP && FLAVOR == kGeneral), "attached-point leaves: general flavour, row records in registers");
   constexpr bool kIdentFirst = SYM && PLAIN && MINW >= 3 && RMP2_IDENT_FIRST;  // (see "Phase order per wave" below)
   // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
@@ -709,6 +715,8 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   int32_t* const s_id = s_fk + RMP2_MAX_LEAVES;
   int32_t* const s_lo = s_id + RMP2_MAX_LEAVES;
   float* const s_goal = reinterpret_cast<float*>(s_lo + kMaxOps);
+  // attached-point builds: [16 robots][n_ops][16] = rows of the world rotation (9), w (3), alpha (3), behind everything else
+  float* const pt_base = STAGE ? s_goal + 16 * kRobotsPerWave : stage_base;
   const DevOp* const ops = STAGE ? s_ops : prog->ops;
   const DevLeaf* const leaves = STAGE ? s_leaves : prog->leaves;
   const int32_t* const fk_list = STAGE ? s_fk : prog->fk_leaves;
@@ -1179,6 +1187,14 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         fr[3 + sub] = vn;
         fr[6 + sub] = an;
         fr[9 + sub] = z;
+        if (PT) {  // row `sub` of the world rotation and component `sub` of w and alpha, for the attached-point leaves
+          float* pr = pt_base + (g * n_ops + k) * kPtSlot;
+          pr[3 * sub] = Rn[0];
+          pr[3 * sub + 1] = Rn[1];
+          pr[3 * sub + 2] = Rn[2];
+          pr[9 + sub] = wn;
+          pr[12 + sub] = aln;
+        }
       }
       if (SLOTS > 0 && c_save >= 0) {
 #pragma unroll
@@ -1271,7 +1287,78 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         const int lf_kind = lh.kind;
         float S[6], h[3];
         RMP2_SEG(0);  // frame record + leaf head on chip
-        if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+        // attached-point leaf: the sums over its pairs that the pull-back below needs (see there)
+        bool pt_leaf = false;
+        float ptW = 0.f, ptRho[3] = {0.f, 0.f, 0.f}, ptQ[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ptTau[3] = {0.f, 0.f, 0.f};
+        if (PT && lh.taskmap == RMP2_TASKMAP_FK_POINT) {
+          // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position] + CollisionAvoidance (metric w(d) I), pair b:
+          //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J_b = J_p + [z_j x r]_j (revolute dofs).
+          // Every pair has its OWN Jacobian, but it differs from the frame origin's by a term linear in r, so the sums over
+          // the pairs collapse into 16 numbers and ONE pull-back per frame:
+          //   M += W J_p^T J_p - J_p^T [rho]x Z - (..)^T + Z^T Q Z ,   f += J_p^T h + Z^T tau
+          //   W = sum w_b, rho = sum w_b r_b, Q = sum w_b (|r_b|^2 I - r_b r_b^T), h = sum w_b e_b, tau = sum w_b r_b x e_b,
+          //   e_b = xdd_b - c_b, Z = the revolute dofs' world axes (zero columns for prismatic dofs and non-ancestors).
+          // (The hex and lane mappings pull every pair back through its own columns; same sums to fp32 rounding.)
+          pt_leaf = true;
+          const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * kPtSlot);
+          const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2], q3 = pr4[3];
+          const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+          const float W3[3] = {q2.y, q2.z, q2.w}, AL3[3] = {q3.x, q3.y, q3.z};
+          const int lidx = uni<STAGE>(lf.index);
+          const int pb = obs.pair_begin[lidx];
+          const int count = obs.pair_begin[lidx + 1] - pb;
+          const size_t pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
+          h[0] = h[1] = h[2] = 0.f;
+          for (int t = 0; kQuad * t < count; ++t) {  // (the pair layout is shared by the fleet: wave-uniform trip count)
+            const int b_raw = kQuad * t + sub;
+            const bool on = b_raw < count;
+            const size_t b = pbase + (on ? b_raw : 0);
+            const float rel[3] = {obs.p_link[3 * b], obs.p_link[3 * b + 1], obs.p_link[3 * b + 2]};
+            const float nv[3] = {obs.p_obs[3 * b], obs.p_obs[3 * b + 1], obs.p_obs[3 * b + 2]};
+            const float dd = obs.dist[b];
+            float r[3], t1[3], t2[3], xdp[3], cp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * rel[0] + Rm[3 * c + 1] * rel[1] + Rm[3 * c + 2] * rel[2];
+            cross3(W3, r, t1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
+            cross3(W3, t1, t2);
+            cross3(AL3, r, t1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cp[c] = A3[c] + t1[c] + t2[c];
+            float xdd[3], wgt;
+            leaf_collision_avoidance(lh.P, dd, nv, xdp, xdd, wgt);
+            if (!on) wgt = 0.f;
+            const float e[3] = {xdd[0] - cp[0], xdd[1] - cp[1], xdd[2] - cp[2]};
+            float re[3];
+            cross3(r, e, re);
+            const float rr = dot3(r, r);
+            ptW += wgt;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              ptRho[c] = fmaf(wgt, r[c], ptRho[c]);
+              h[c] = fmaf(wgt, e[c], h[c]);
+              ptTau[c] = fmaf(wgt, re[c], ptTau[c]);
+            }
+            ptQ[0] = fmaf(wgt, rr - r[0] * r[0], ptQ[0]);
+            ptQ[1] = fmaf(wgt, -r[0] * r[1], ptQ[1]);
+            ptQ[2] = fmaf(wgt, -r[0] * r[2], ptQ[2]);
+            ptQ[3] = fmaf(wgt, rr - r[1] * r[1], ptQ[3]);
+            ptQ[4] = fmaf(wgt, -r[1] * r[2], ptQ[4]);
+            ptQ[5] = fmaf(wgt, rr - r[2] * r[2], ptQ[5]);
+          }
+          ptW = quad_sum(ptW);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            ptRho[c] = quad_sum(ptRho[c]);
+            h[c] = quad_sum(h[c]);
+            ptTau[c] = quad_sum(ptTau[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 6; ++c) ptQ[c] = quad_sum(ptQ[c]);
+          S[0] = S[3] = S[5] = ptW;   // (the metric of the origin term: W I)
+          S[1] = S[2] = S[4] = 0.f;
+        } else if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
           float gl[3], xdd[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
@@ -1365,6 +1452,11 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
         // below.  Column j lives in lane (j & 3) as its local row j >> 2: it is broadcast right where it is consumed.
         RMP2_SEG(3);  // Jacobian columns of my rows
         float u[ROWS][3];
+        float myz[PT ? ROWS : 1][3], tz[PT ? ROWS : 1][3];   // (attached-point leaves: my rows' revolute axes, and Q z_i - c_i x rho)
+        if (PT) {
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m) myz[m][0] = myz[m][1] = myz[m][2] = tz[m][0] = tz[m][1] = tz[m][2] = 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) {
           u[m][0] = u[m][1] = u[m][2] = 0.f;
@@ -1373,6 +1465,19 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
           u[m][1] = S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2];
           u[m][2] = S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2];
           fv[m] += (double)dot3(mycol[m], h);
+          if (PT) {  // attached-point leaf:  A_ij += c_j . (W c_i - rho x z_i) + z_j . (Q z_i - c_i x rho),  f_i += z_i . tau
+            const bool actz = pt_leaf && rjrev[m] && ((op.anc_mask >> (sub + kQuad * m)) & 1u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) myz[m][c] = actz ? rjz[m][c] : 0.f;
+            float rz[3], cr2[3];
+            cross3(ptRho, myz[m], rz);
+            cross3(mycol[m], ptRho, cr2);
+            u[m][0] -= rz[0], u[m][1] -= rz[1], u[m][2] -= rz[2];
+            tz[m][0] = ptQ[0] * myz[m][0] + ptQ[1] * myz[m][1] + ptQ[2] * myz[m][2] - cr2[0];
+            tz[m][1] = ptQ[1] * myz[m][0] + ptQ[3] * myz[m][1] + ptQ[4] * myz[m][2] - cr2[1];
+            tz[m][2] = ptQ[2] * myz[m][0] + ptQ[4] * myz[m][1] + ptQ[5] * myz[m][2] - cr2[2];
+            fv[m] += (double)dot3(myz[m], ptTau);
+          }
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -1383,9 +1488,18 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
             const float v = mycol[j >> 2][cc];
             cj[cc] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
           }
+          float zj[3] = {0.f, 0.f, 0.f};
+          if (PT) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              const float v = myz[j >> 2][cc];
+              zj[cc] = (j & 3) == 0 ? bcast<0>(v) : (j & 3) == 1 ? bcast<1>(v) : (j & 3) == 2 ? bcast<2>(v) : bcast<3>(v);
+            }
+          }
 #pragma unroll
           for (int m = 0; m < ROWS; ++m)
-            if (kQuad * m <= j) A[m][j] += (double)dot3(u[m], cj);  // (a row block without ancestors adds exact zeros)
+            if (kQuad * m <= j)  // (a row block without ancestors adds exact zeros)
+              A[m][j] += (double)(PT ? dot3(u[m], cj) + dot3(tz[m], zj) : dot3(u[m], cj));
         }
         RMP2_SEG(4);  // pull-back
       }

@@ -13,6 +13,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
                                             quad_table_floats(o.capsule, n_sph_lds));
+  const size_t pt_bytes = h->has_point ? sizeof(float) * kPtSlot * kRobotsPerWave * quad_slots(h->n_ops_step) : 0;  // (rotation, w, alpha per frame)
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
@@ -40,7 +41,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     // loads (and the next leaf's prefetch) in flight per wave -- 123.7 us per step at 65 536 robots against 148.7 with four
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
   }
-  const size_t bytes = latency ? lds_bytes + stage_bytes : lds_bytes;
+  const size_t bytes = (latency ? lds_bytes + stage_bytes : lds_bytes) + pt_bytes;
   h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, FLAVOR)                                                            \
   RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, FLAVOR>), dim3(blocks), dim3(kWave), bytes, s, \
@@ -99,6 +100,23 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     return;
   }
 #undef RMP2_QUAD_ROLL_SYM
+  if (h->has_point) {
+    // attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance): the general flavour with the extra per-frame records
+    // (27 floats per frame instead of 12: two waves per SIMD at most)
+    auto raise = [&](const void* kern) {
+      if (bytes > 64 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    };
+#define RMP2_QUAD_PT(MINW, STAGE, SYM)                                                                                  \
+    do {                                                                                                                \
+      raise(reinterpret_cast<const void*>(rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, false, SYM, kObsAny, kGeneral, true>)); \
+      RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, false, SYM, kObsAny, kGeneral, true>), dim3(blocks), \
+                       dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);                          \
+    } while (0)
+    if (latency) { if (symk) RMP2_QUAD_PT(1, true, (N == 9)); else RMP2_QUAD_PT(1, true, false); }
+    else { if (symk) RMP2_QUAD_PT(2, false, (N == 9)); else RMP2_QUAD_PT(2, false, false); }
+#undef RMP2_QUAD_PT
+    return;
+  }
   if (latency) RMP2_QUAD_BY_CAP(1, true);
   else if (plain && minw == 4) RMP2_QUAD_PLAIN(4);
   else if (plain && minw == 3) RMP2_QUAD_PLAIN(3);

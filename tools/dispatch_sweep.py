@@ -1,5 +1,6 @@
 """Sweep the robot -> lane mappings (RMP2_KERNEL = hex | quad | lane) over fleet sizes for one RMP set.
-usage: dispatch_sweep.py <tj5|config3r|config3|config2> [R ...]     (tj5 = TwoJoint half of config 5, ragged lists)"""
+usage: dispatch_sweep.py <tj5|config3r|config3|config2|exp05|exp05tj> [R ...]     (tj5 = TwoJoint half of config 5, ragged lists;
+exp05 / exp05tj = attached-point leaves, TaskmapRelative4x4 + CollisionAvoidance, on the Panda / the TwoJoint, 4 pairs per leaf)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,12 @@ for kern in ("hex", "quad", "lane", "auto"):
     row = []
     for R in sizes:
         try:
-            if which == "tj5":
+            if which in ("exp05", "exp05tj"):
+                from riemannian_motion_policies_amd import descriptor as D
+                _, desc = Cf.exp05_panda() if which == "exp05" else Cf.exp05_two_joint()
+                s = (Cf.sample_panda_states if which == "exp05" else Cf.sample_two_joint_states)(np.random.default_rng(1), R)
+                sph = None
+            elif which == "tj5":
                 _, desc = Cf.config5_two_joint()
                 s = Cf.sample_two_joint_states(np.random.default_rng(1), R)
                 sph = Cf.sample_spheres(np.random.default_rng(7)); sph[:, :2] *= 2.0; sph[:, 2] = 0.1
@@ -33,8 +39,11 @@ for kern in ("hex", "quad", "lane", "auto"):
                 sph = Cf.sample_spheres(np.random.default_rng(7))
             eng = Engine(desc, 0)
             q, qd, goal = (torch.from_numpy(s[k]).to(dev) for k in ("q", "qd", "goal"))
-            spt = torch.from_numpy(sph).to(dev)
-            if which == "config2": obs = None
+            spt = torch.from_numpy(sph).to(dev) if sph is not None else None
+            if which in ("exp05", "exp05tj"):
+                rel, nv, dist = Cf.sample_point_pairs(np.random.default_rng(2), R, len(D.distance_leaf_indices(desc)), 4)
+                obs = eng.obstacles(p_link=torch.from_numpy(rel).to(dev), p_obs=torch.from_numpy(nv).to(dev), dist=torch.from_numpy(dist).to(dev))
+            elif which == "config2": obs = None
             elif which == "config3": obs = eng.obstacles(spheres=spt)
             else:
                 off, idx = Cf.sample_ragged(np.random.default_rng(3), R)
