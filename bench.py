@@ -402,7 +402,13 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         # gather + stream orderings + launch inside librmp2_hip.so: one C-ABI call per control step (the torch.distributed
         # loop below costs ~50 us of host time per step -- more than the step kernel takes)
         from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
-        exch = exch if isinstance(exch, NativeObstacleExchange) else NativeObstacleExchange(K // world, dev, depth=args.exchange_depth)
+        if not isinstance(exch, NativeObstacleExchange):
+            try:
+                exch = NativeObstacleExchange(K // world, dev, depth=args.exchange_depth)
+            except Exception as e:   # (RCCL could not be bound / the communicator not built: the torch-driven exchange still works)
+                print(f"bench.py: native exchange unavailable on rank {rank} ({e!r}); falling back to --exchange torch", file=sys.stderr)
+                args.exchange = "torch"
+                return build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=seed_rank, exch=None)
         while exch.pending < exch.depth:   # (a reused exchange -- the emulation -- still holds the previous user's gathers)
             exch.start(local, local_is_ready=True)
         # (the rank's slice is static in this benchmark -- as the fixed `local_ready` event of the torch-driven loop below --

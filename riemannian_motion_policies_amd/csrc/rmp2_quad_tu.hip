@@ -30,13 +30,16 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   //   3 waves  30.3  34.6  34.4  38.9  39.2  62.2  63.6  67.9  74.5  102.2  142.7  200.4
   //   4 waves  30.5  36.2  36.7  40.7  41.5  46.5  50.1  73.3  76.6   90.5  130.3  170.6
   // two waves up to ceil(b) = 3 and for 5 and 6, four for 4 and from 7 on.  Sets with a JointLimitAvoidance leaf (general
-  // form, 48-56 spilled dwords at 128 registers) keep two waves.
+  // form: the elimination works on full rows) follow the same rule since round 3 -- config 3 + JointLimitAvoidance:
+  //       b      2     3    3.5    4     6     8     16
+  //   2 waves  37.5  43.5  65.0  65.4  80.6  107.7  205.2
+  //   4 waves  41.8  47.7  52.5  57.3  88.5  103.4  193.8
   const bool latency = blocks <= h->quad_latency_blocks && h->goal_floats <= 16;
   const bool symk = h->symmetric && N == 9;
   int minw = h->quad_minw;
   if (minw == 0) {
     const int bc = (blocks + h->n_simd - 1) / h->n_simd;  // ceil(b)
-    minw = (symk && (bc == 4 || bc >= 7)) ? 4 : 2;
+    minw = (bc == 4 || bc >= 7) ? 4 : 2;
     // explicit pairs (interface B) are bound by memory latency, not by issue slots: the two-wave build keeps a whole leaf's
     // loads (and the next leaf's prefetch) in flight per wave -- 123.7 us per step at 65 536 robots against 148.7 with four
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
