@@ -45,6 +45,11 @@ python tools/fence_cost.py > $O/exchange_timing.txt 2>/dev/null
 (python tools/pcie_inclusive.py config2 4096; python tools/pcie_inclusive.py config3 65536) > $O/pcie_inclusive.txt 2>/dev/null
 python tools/flag_tail.py > $O/flag_tail.txt 2>/dev/null
 rm -rf $O/kt*/*/*.db $O/f3 $O/w3 $O/f3b $O/w3b $O/f2 $O/w2 $O/sq1 $O/sq2
+# the contract line once more, now that the counter files of THESE kernels exist (the line then carries traffic + executed)
+cp $O/traffic_config2.json $O/traffic_config3.json $O/traffic_config3b.json $O/executed_config3.json profiles/
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --workload config3b --no-cpu-baseline > $O/bench_config3b.json 2>/dev/null
+(python tools/dispatch_sweep.py exp05 4096 16384 20480 32768 65536; python tools/dispatch_sweep.py exp05tj 4096 16384 20480 32768 65536; python tools/minw_sweep.py config3j 32768 49152 57344 65536 98304 131072 262144) >> $O/dispatch_sweep.txt 2>/dev/null
 find $O -name "*kernel_stats.csv" -exec head -3 {} \; | cut -c1-100,180-330
 cut -c1-400 $O/bench_default.json; cat $O/traffic_config3.json $O/executed_config3.json $O/stamps.txt $O/rollout.txt $O/exchange_timing.txt $O/pcie_inclusive.txt
 du -sh $O
