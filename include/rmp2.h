@@ -344,6 +344,16 @@ int rmp2_closest_points(rmp2_handle *h, const float *q, const rmp2_obstacles *ta
 int rmp2_closest_points_links(rmp2_handle *h, const float *q, const rmp2_obstacles *table, const float *link_capsules,
                               float *p_link, float *p_obs, int32_t R, void *stream);
 
+/* The control steps of TWO engines (two robot types of one fleet shard: BASELINE config 5) issued together: arguments as two
+ * rmp2_step calls, `stream` shared.  Where a fused instantiation exists for the pair -- a 2-dof and a 3..9-dof robot type,
+ * plain steps on shared or ragged sphere tables, both fleets beyond 8 192 robots -- the two steps are ONE grid (the first
+ * blocks run A's program, the rest B's; wavefronts stay type-homogeneous); otherwise two launches on `stream`.  Results are
+ * those of the two rmp2_step calls either way; rmp2_last_kernel names what ran. */
+int rmp2_step_pair(rmp2_handle *ha, const float *qa, const float *qda, const float *goala, int32_t goal_stride_a,
+                   const rmp2_obstacles *obsa, const rmp2_outputs *outa, int32_t Ra, rmp2_handle *hb, const float *qb,
+                   const float *qdb, const float *goalb, int32_t goal_stride_b, const rmp2_obstacles *obsb,
+                   const rmp2_outputs *outb, int32_t Rb, void *stream);
+
 /* Forward kinematics of every frame: T[R][n_frames][16] row-major 4x4
  * (UrdfForwardKinematic.forward, kinematics.py:212-247, for all frames at once).      */
 int rmp2_forward_kinematics(rmp2_handle *h, const float *q, float *T, int32_t R, void *stream);

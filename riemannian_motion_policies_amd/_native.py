@@ -49,6 +49,8 @@ def lib():
     l.rmp2_destroy.argtypes = [C.c_void_p]
     l.rmp2_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
                             C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
+    _step_args = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles), C.POINTER(D.Outputs), C.c_int32]
+    l.rmp2_step_pair.argtypes = _step_args + _step_args + [C.c_void_p]
     l.rmp2_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
                                C.POINTER(D.RolloutCfg), C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
     l.rmp2_forward_kinematics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

@@ -1555,11 +1555,10 @@ int rmp2_destroy(rmp2_handle* h) {
   return RMP2_OK;
 }
 
-static int step_impl(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
-                     const rmp2_obstacles* obs, const rmp2_outputs* out, const RolloutArgs& ro, int32_t R, void* stream) {
-  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
-  if (R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "R < 0");
-  if (R == 0) return RMP2_OK;  // empty fleet: nothing to do (pointers may be null)
+// Argument checks of a control step and the kernels' view of its obstacle / output arguments (R > 0).
+static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
+                        const rmp2_obstacles* obs, const rmp2_outputs* out, const RolloutArgs& ro, int32_t R, void* stream,
+                        ObsArgs& o, OutArgs& oa) {
   if (!q || !qd || !out || !out->qdd) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "q, qd and out->qdd are required");
   if (h->goal_floats > 0) {
     if (!goal) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "this RMP set has goal-bearing leaves: goal is required");
@@ -1568,7 +1567,6 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   }
   hipStream_t s = (hipStream_t)stream;
   if (int rc = use_device(h)) return rc;
-  ObsArgs o;
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;
   if (h->has_point) {
@@ -1615,7 +1613,19 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     o.dist = obs->dist;
     o.pair_begin = h->d_pair_begin;
   }
-  OutArgs oa{out->qdd, out->status, out->M, out->f};
+  oa = OutArgs{out->qdd, out->status, out->M, out->f};
+  return RMP2_OK;
+}
+
+static int step_impl(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
+                     const rmp2_obstacles* obs, const rmp2_outputs* out, const RolloutArgs& ro, int32_t R, void* stream) {
+  if (!h) return RMP2_ERR_INVALID_ARGUMENT;
+  if (R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "R < 0");
+  if (R == 0) return RMP2_OK;  // empty fleet: nothing to do (pointers may be null)
+  ObsArgs o;
+  OutArgs oa;
+  if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;
+  hipStream_t s = (hipStream_t)stream;
   int rc;
   if (h->n_template == 2)
     rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);
@@ -1845,6 +1855,27 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   x->reader_valid[b] = true;
   if (table_out) *table_out = x->table[b];
   return RMP2_OK;
+}
+
+// Two engines, one launch (include/rmp2.h): the fused grid when an instantiation exists for the pair, else two launches.
+int rmp2_step_pair(rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int32_t gsa,
+                   const rmp2_obstacles* obsa, const rmp2_outputs* outa, int32_t Ra, rmp2_handle* hb, const float* qb,
+                   const float* qdb, const float* goalb, int32_t gsb, const rmp2_obstacles* obsb, const rmp2_outputs* outb,
+                   int32_t Rb, void* stream) {
+  if (!ha || !hb) return RMP2_ERR_INVALID_ARGUMENT;
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr, 0};
+  if (Ra > 0 && Rb > 0 && ha->device == hb->device && !ha->step_fence && !hb->step_fence) {
+    ObsArgs oa_, ob_;
+    OutArgs outa_, outb_;
+    if (int rc = prepare_step(ha, qa, qda, goala, gsa, obsa, outa, ro, Ra, stream, oa_, outa_)) return rc;
+    if (int rc = prepare_step(hb, qb, qdb, goalb, gsb, obsb, outb, ro, Rb, stream, ob_, outb_)) return rc;
+    if (launch_quad_pair(ha, qa, qda, goala, gsa, oa_, outa_, Ra, hb, qb, qdb, goalb, gsb, ob_, outb_, Rb, (hipStream_t)stream)) {
+      HIP_TRY(ha, hipGetLastError());
+      return RMP2_OK;
+    }
+  }
+  if (int rc = step_impl(ha, qa, qda, goala, gsa, obsa, outa, ro, Ra, stream)) return rc;
+  return step_impl(hb, qb, qdb, goalb, gsb, obsb, outb, ro, Rb, stream);
 }
 
 int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t goal_stride,

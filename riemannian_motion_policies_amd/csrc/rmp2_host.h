@@ -81,6 +81,16 @@ RMP2_DECL_QUAD(launch_quad_n9_s0);
 RMP2_DECL_QUAD(launch_quad_n9_s1);
 RMP2_DECL_QUAD(launch_quad_n9_s2);
 #undef RMP2_DECL_QUAD
+// rmp2_quad_pair_tu.hip: the control steps of two engines as ONE grid (a 2-dof and a 3..9-dof robot type on shared / ragged
+// sphere tables: a mixed fleet shard); false = no fused instantiation for this pair, nothing was launched
+bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int gsa, const ObsArgs& oa,
+                      const OutArgs& outa, int Ra, const rmp2_handle* hb, const float* qb, const float* qdb, const float* goalb,
+                      int gsb, const ObsArgs& ob, const OutArgs& outb, int Rb, hipStream_t s);
+inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
+  return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
+                 h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
+                 h->prio_tail >= 0 ? h->prio_tail : 0};
+}
 // rmp2_hex_tu.hip (false: the working set does not fit the CU's LDS -- the caller falls back to the quad mapping)
 bool launch_hex_n2(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                    const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s);

@@ -651,10 +651,10 @@ constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
 constexpr int kPtSlot = 16;
 template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral,
           bool PT = false>
-__global__ void __launch_bounds__(kWave, MINW)
-rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
-                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
-                      OutArgs out, RolloutArgs ro_arg, int R) {
+__device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ prog, const QuadHdr& hdr,
+                                               const float* __restrict__ q, const float* __restrict__ qd,
+                                               const float* __restrict__ goal, int goal_stride, const ObsArgs& obs, OutArgs out,
+                                               const RolloutArgs& ro_arg, int R, const int block_idx) {
   const int obs_mode = OBS == kObsAny ? obs.mode : OBS;
   constexpr bool PLAIN = FLAVOR == kPlainStep;   // no rollout loop
   constexpr bool LEAN = FLAVOR != kGeneral;      // no debug outputs
@@ -696,7 +696,7 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
   const int lane = threadIdx.x;
   const int sub = lane & 3;
   const int g = lane >> 2;
-  const int r0 = blockIdx.x * kRobotsPerWave;
+  const int r0 = block_idx * kRobotsPerWave;
   const int robot = r0 + g;
   const bool live = robot < R;
   const int n_dof = hdr.n_dof;
@@ -1798,11 +1798,49 @@ rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const fl
 #ifdef RMP2_STAMPS
   RMP2_STAMP();  // 6: stored
   if (lane == 0 && out.M == nullptr && out.f != nullptr) {  // diagnostic convention: the stamps follow the f rows
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)R * n_dof + (size_t)blockIdx.x * 16;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(out.f) + (size_t)R * n_dof + (size_t)block_idx * 16;
     for (int i = 0; i < 8; ++i) dst[i] = i < st_n ? st_[i] : 0ull;
     for (int i = 0; i < 8; ++i) dst[8 + i] = seg_[i];
   }
 #endif
+}
+
+// The control step of ONE engine: one wave (16 robots) per block.
+template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral,
+          bool PT = false>
+__global__ void __launch_bounds__(kWave, MINW)
+rmp2_step_quad_kernel(const DevProgram* __restrict__ prog, QuadHdr hdr, const float* __restrict__ q,
+                      const float* __restrict__ qd, const float* __restrict__ goal, int goal_stride, ObsArgs obs,
+                      OutArgs out, RolloutArgs ro_arg, int R) {
+  quad_step_body<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, FLAVOR, PT>(prog, hdr, q, qd, goal, goal_stride, obs, out, ro_arg, R,
+                                                                    (int)blockIdx.x);
+}
+
+// The control steps of TWO engines in ONE launch (a fleet shard that holds two robot types, BASELINE config 5): the first
+// `split` blocks run engine A's program on A's robots, the rest engine B's.  Two launches on two streams need a fork and a
+// join fence (~5 us each on this runtime) and two launches on one stream serialise; one grid needs neither, and the short
+// program's waves fill the slots the long one's leave.  Wavefronts stay type-homogeneous (a block is one wave).
+struct QuadCall {
+  const DevProgram* prog;
+  QuadHdr hdr;
+  const float* q;
+  const float* qd;
+  const float* goal;
+  int goal_stride;
+  ObsArgs obs;
+  OutArgs out;
+  int R;
+};
+template <int NA, int SA, bool SYMA, int NB, int SB, bool SYMB, int MINW, int OBS>
+__global__ void __launch_bounds__(kWave, MINW)
+rmp2_step_quad_pair_kernel(QuadCall a, QuadCall b, int split) {
+  const RolloutArgs ro{1, 0, 0.f, nullptr, nullptr, 0};
+  if ((int)blockIdx.x < split)
+    quad_step_body<NA, SA, MINW, false, false, SYMA, OBS, kPlainStep, false>(a.prog, a.hdr, a.q, a.qd, a.goal, a.goal_stride,
+                                                                            a.obs, a.out, ro, a.R, (int)blockIdx.x);
+  else
+    quad_step_body<NB, SB, MINW, false, false, SYMB, OBS, kPlainStep, false>(b.prog, b.hdr, b.q, b.qd, b.goal, b.goal_stride,
+                                                                            b.obs, b.out, ro, b.R, (int)blockIdx.x - split);
 }
 
 }  // namespace rmp2

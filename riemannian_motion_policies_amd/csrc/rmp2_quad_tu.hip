@@ -16,9 +16,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t pt_bytes = h->has_point ? sizeof(float) * kPtSlot * kRobotsPerWave * quad_slots(h->n_ops_step) : 0;  // (rotation, w, alpha per frame)
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
-  const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                    h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
-                    h->prio_tail >= 0 ? h->prio_tail : 0};
+  const QuadHdr hdr = make_quad_hdr(h);
   // latency build for grids that put at most one wave on a SIMD (256 CUs x 4): program staged in LDS, all 512 registers;
   // throughput builds beyond: scalar-cache program walk, capped at 256, 168 or 128 registers (two, three or four waves per
   // SIMD).  More waves retire the leaf phases faster per robot, but a SIMD's share of the fleet has to divide into rounds.

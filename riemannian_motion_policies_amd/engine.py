@@ -325,3 +325,33 @@ class Engine:
         _native.check(self._lib.rmp2_differentiate_euler(self._h, q.data_ptr(), qd.data_ptr(), int(frame), x.data_ptr(),
                                                          xd.data_ptr(), J.data_ptr(), c.data_ptr(), R, s), self._h)
         return x, xd, J, c
+
+
+def bind_pair(eng_a: "Engine", q_a, qd_a, goal_a, obstacles_a, out_a, eng_b: "Engine", q_b, qd_b, goal_b, obstacles_b, out_b,
+              stream=None):
+    """Pre-marshal the control steps of TWO engines (two robot types of one shard) as one C-ABI call, rmp2_step_pair: one fused
+    grid where the library has an instantiation for the pair (include/rmp2.h), two launches otherwise.  Buffers as for
+    Engine.bind (contiguous fp32 tensors on the engines' device, read and written in place).  Returns launch()."""
+    if eng_a.device != eng_b.device:
+        raise ValueError("bind_pair: both engines must live on one device")
+    for eng, q, qd, goal, obs, out in ((eng_a, q_a, qd_a, goal_a, obstacles_a, out_a), (eng_b, q_b, qd_b, goal_b, obstacles_b, out_b)):
+        _require_resident(eng.device, q=q, qd=qd, goal=goal if eng.desc.goal_floats else None, out=out)
+        eng.step(q, qd, goal, obstacles=obs, out=out, stream=stream)   # validates the arguments (and warms the kernels up)
+    lib = eng_a._lib
+    outs, args = [], []
+    for eng, q, qd, goal, obs, out in ((eng_a, q_a, qd_a, goal_a, obstacles_a, out_a), (eng_b, q_b, qd_b, goal_b, obstacles_b, out_b)):
+        o = D.Outputs()
+        o.qdd = out.data_ptr()
+        outs.append(o)
+        gp = goal.data_ptr() if eng.desc.goal_floats else None
+        gs = 0 if (not eng.desc.goal_floats or goal.dim() == 1) else eng.desc.goal_floats
+        args += [eng._h, q.data_ptr(), qd.data_ptr(), gp, gs, C.byref(obs) if obs is not None else None, C.byref(o), q.shape[0]]
+    s = stream if stream is not None else torch.cuda.current_stream(eng_a.device).cuda_stream
+    keep = (q_a, qd_a, goal_a, obstacles_a, out_a, q_b, qd_b, goal_b, obstacles_b, out_b, outs)
+    fn = lib.rmp2_step_pair
+
+    def launch(_keep=keep):
+        rc = fn(*args, s)
+        if rc:
+            _native.check(rc, eng_a._h)
+    return launch

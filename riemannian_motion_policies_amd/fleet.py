@@ -576,7 +576,8 @@ class MixedFleetShard:
         return cuts, ranges, work
 
     @classmethod
-    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None):
+    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None,
+                  fused: bool = True):
         """Synthetic config-5 fleet of `total` robots (k_r ~ U{0..32} as CSR lists into the type's
         shared sphere table); builds only this rank's shard.  `cost`: see plan()."""
         import numpy as np
@@ -627,6 +628,16 @@ class MixedFleetShard:
             self.work += float(work[first + lo:first + hi].sum())
         self.n_two_joint = self.parts.get("two_joint", {}).get("n", 0)
         self.n_panda = self.parts.get("panda", {}).get("n", 0)
+        # both types in the shard: their two steps as ONE call -- one fused grid where the library has the instantiation
+        # (rmp2_step_pair: both fleets beyond 8 192 robots), else two launches
+        self._pair_launch = None
+        if fused and len(self.parts) == 2:
+            from .engine import bind_pair
+            a, b = self.parts["two_joint"], self.parts["panda"]
+            self._pair_launch = bind_pair(a["engine"], a["keep"][0], a["keep"][1], a["keep"][2], a["keep"][3], a["out"],
+                                          b["engine"], b["keep"][0], b["keep"][1], b["keep"][2], b["keep"][3], b["out"])
+            self._pair_launch()
+            self._fused = "pair" in a["engine"].last_kernel()
         self._dom = "panda" if "panda" in self.parts else "two_joint"
         d = self.parts[self._dom]
         self.dominant_bytes, self.dominant_flops, self.dominant_robots = d["bytes"], d["flops"], d["n"]
@@ -683,9 +694,16 @@ class MixedFleetShard:
         else:
             self._step_eager()
 
+    _pair_launch = None
+    _fused = False
+
     def _step_eager(self):
-        """With both types present the two kernels overlap: the side stream forks off the
-        current stream (it sees everything enqueued so far, e.g. the simulator's state update) and joins it again."""
+        """With both types present: ONE call (rmp2_step_pair) -- a fused grid when both fleets are beyond 8 192 robots --;
+        where that is not the fused grid the two kernels overlap on two streams: the side stream forks off the current
+        stream (it sees everything enqueued so far, e.g. the simulator's state update) and joins it again."""
+        if self._pair_launch is not None and self._fused:
+            self._pair_launch()
+            return
         if self._side is None:
             for launch in self._launches:
                 launch()

@@ -81,3 +81,40 @@ def test_eight_rank_shard_shapes_of_the_mixed_fleet(rank):
         assert ok.mean() >= 0.97, f"rank {rank} {key}: worst {err.max():.3e}, {(~ok).sum()} of {n} out"
         allout = part["out"].cpu().numpy()
         assert np.isfinite(allout).mean() > 0.999, f"rank {rank} {key}: {np.isnan(allout).any(axis=1).sum()} non-finite robots"
+
+
+def test_two_robot_types_in_one_grid():
+    """rmp2_step_pair: the TwoJoint and the Panda part of a mixed shard as ONE grid (the first blocks run the TwoJoint
+    program, the rest the Panda's).  Same template bodies as the two separate launches: the results must be identical bit
+    for bit, and right against the oracle; shards whose parts are small keep two launches."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle as O
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    fused = MixedFleetShard.synthetic(40000, 1, 0, 0)               # 20 000 + 20 000 robots
+    plain = MixedFleetShard.synthetic(40000, 1, 0, 0, fused=False)
+    assert fused._fused and "pair" in fused.parts["panda"]["engine"].last_kernel()
+    assert not plain._fused
+    for _ in range(2):
+        fused.step()
+        plain.step()
+    torch.cuda.synchronize()
+    for key in ("two_joint", "panda"):
+        a, b = fused.parts[key]["out"], plain.parts[key]["out"]
+        assert torch.equal(a, b) or torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), f"{key}: fused grid differs from the two launches"
+        part = fused.parts[key]
+        q, qd, goal, _ = part["keep"]
+        h = part["host"]
+        n = 128
+        off = h["csr_offset"][: n + 1]
+        ref = O.step(part["desc"], q[:n].cpu().numpy(), qd[:n].cpu().numpy(), goal[:n].cpu().numpy(),
+                     spheres=h["spheres"], csr_offset=off, csr_index=h["csr_index"][: off[-1]])
+        err = np.abs(a[:n].cpu().numpy() - ref["qdd64"]).max(axis=1)
+        ok = (err <= 1e-5 * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))) | (err <= 1e-3 * np.abs(ref["qdd64"]).max(axis=1)) | \
+            (np.linalg.cond(ref["M"]) > 100)
+        assert ok.mean() >= 0.97, f"{key}: worst {err.max():.3e}"
+    small = MixedFleetShard.synthetic(4096, 1, 0, 0)
+    assert not small._fused                                          # 2 048 + 2 048 robots: two launches (hex mapping)
