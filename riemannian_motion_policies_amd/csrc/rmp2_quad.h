@@ -29,6 +29,9 @@
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
 
+#ifndef RMP2_EXPLICIT_LOCAL
+#define RMP2_EXPLICIT_LOCAL 1  // explicit pairs: every lane evaluates the pairs it loaded (0: compacted + re-fetched; A/B)
+#endif
 #ifndef RMP2_IDENT_FIRST
 #define RMP2_IDENT_FIRST 0  // measured: no gain (43.7 vs 43.6 us at 65 536 robots, 163.1 vs 160.2 at 262 144; tools/experiments/README.md)
 #endif
@@ -463,6 +466,9 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
 //           32 pairs;
 //   pass 2  the set bits are dealt round-robin to the quad's lanes, which fetch their pair again (an L1 / L2 hit: the
 //           lines were read a few hundred cycles ago) and run the transcendental chain on it.
+// FULL CHUNKS (32 pairs, the usual leaf) do not take the two passes: every lane evaluates the eight pairs it loaded, slot by
+// slot, out of its own registers (RMP2_EXPLICIT_LOCAL) -- the dealt pair's second fetch is an L2 round trip per trip on the
+// wave's critical path, and this mode is bound by latency, not by issue slots: 132 -> 104 us per step at 65 536 robots.
 struct F3 { float x, y, z; };
 __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const float* po, int count, int sub,
                                                           const float P3[3], const float V3[3], const float A3[3],
@@ -481,14 +487,48 @@ __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const
     if (base + 32 <= count) {
       // full chunk (the usual case: 32 pairs per leaf): all sixteen loads are issued before the first test -- a guarded
       // loop pays one memory round trip per slot (measured: 163 us per step at 65 536 robots, latency bound)
-      // (holding the NEXT leaf's 48 registers through the pull-back as a prefetch was tried: the 256-register build then
-      // spills 40 dwords in the frame loop -- 184 us per step against 124; tools/experiments/README.md)
+      // (loading the NEXT leaf's pairs early -- 48 registers held through the quad sums and the pull-back -- was tried twice,
+      // on the compacted loop and on this one: 184 us against 124 and 171 against 104 per step; tools/experiments/README.md)
       F3 a[8], o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int pos = base + sub + kQuad * i;
         a[i] = *reinterpret_cast<const F3*>(pl + 3 * pos);
         o[i] = *reinterpret_cast<const F3*>(po + 3 * pos);
+      }
+      if (RMP2_EXPLICIT_LOCAL) {
+        // Every lane evaluates the pairs it LOADED, slot by slot, out of its own registers: no dealing across the quad and
+        // no second fetch.  More instructions (eight masked trips per chunk instead of ~2.5 compacted ones; a slot no lane
+        // of the wave has in range is skipped), but none of them waits for memory: the compacted loop's trips each paid an
+        // L2 round trip for the pair they were dealt, and this mode is bound by latency, not by issue slots.
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float diff[3] = {(P3[0] + (a[i].x - P3[0])) - o[i].x, (P3[1] + (a[i].y - P3[1])) - o[i].y,
+                                 (P3[2] + (a[i].z - P3[2])) - o[i].z};
+          const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+          const bool on = !(d2 > thr2);
+          if (!__any(on)) continue;
+          const float inv = rsq0(d2);
+          const float d = d2 * inv;
+          const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+          const float xdot = dot3(nh, V3);
+          const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+          float acc, met;
+          obstacle_pair(P, IP, d, xdot, acc, met);
+          if (!on) met = 0.f;
+          const float wgt = met * (acc - cd);
+          const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+          S[0] = fmaf(mn[0], nh[0], S[0]);
+          S[1] = fmaf(mn[0], nh[1], S[1]);
+          S[2] = fmaf(mn[0], nh[2], S[2]);
+          S[3] = fmaf(mn[1], nh[1], S[3]);
+          S[4] = fmaf(mn[1], nh[2], S[4]);
+          S[5] = fmaf(mn[2], nh[2], S[5]);
+          h[0] = fmaf(wgt, nh[0], h[0]);
+          h[1] = fmaf(wgt, nh[1], h[1]);
+          h[2] = fmaf(wgt, nh[2], h[2]);
+        }
+        continue;  // (next chunk)
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
