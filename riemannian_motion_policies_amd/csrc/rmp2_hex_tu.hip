@@ -8,7 +8,9 @@ namespace {
 constexpr size_t kLdsDefault = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function attribute
 
 template <int N, int WAVES, bool ROLL>
-void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
+// false: the launch could not be prepared (the function attribute for more than 64 KiB of dynamic LDS was refused) -- nothing was
+// launched and the caller falls back to the quad mapping instead of meeting a generic launch error later
+bool launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,
                   const OutArgs& out, const RolloutArgs& ro, int R, hipStream_t s) {
   const int per_block = kHexRobots * WAVES;
   const int blocks = (R + per_block - 1) / per_block;
@@ -25,8 +27,11 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
 #define RMP2_HEX_LAUNCH(CAP, PT)                                                                                          \
   do {                                                                                                                    \
     auto kern = rmp2_step_hex_kernel<N, CAP, WAVES, ROLL, PT>;                                                            \
-    if (bytes > kLdsDefault)                                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+    if (bytes > kLdsDefault &&                                                                                             \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                             \
+      return false;                                                                                                        \
+    }                                                                                                                      \
     RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
                      ro, R);                                                                                              \
   } while (0)
@@ -37,6 +42,7 @@ void launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   else
     RMP2_HEX_LAUNCH(false, false);
 #undef RMP2_HEX_LAUNCH
+  return true;
 }
 
 // A launch may ask for up to 64 KiB of dynamic LDS as it is; beyond that (up to the CU's 160 KiB) the function attribute is
@@ -59,14 +65,12 @@ bool launch_hex(const rmp2_handle* h, const float* q, const float* qd, const flo
   // four-wave blocks while at least two of them fit a CU (the block shares one staged program); one-wave blocks beyond
   if (h->hex_waves != 1 && hex_bytes<N>(h, o, 4) <= kLdsLimit / 2) {
     if (rollout)
-      launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
+      return launch_hex_w<N, 4, true>(h, q, qd, goal, gs, o, out, ro, R, s);
     else
-      launch_hex_w<N, 4, false>(h, q, qd, goal, gs, o, out, ro, R, s);
-    return true;
+      return launch_hex_w<N, 4, false>(h, q, qd, goal, gs, o, out, ro, R, s);
   }
   if (!rollout && hex_bytes<N>(h, o, 1) <= kLdsLimit) {  // (the rollout build exists for four-wave blocks only)
-    launch_hex_w<N, 1, false>(h, q, qd, goal, gs, o, out, ro, R, s);
-    return true;
+    return launch_hex_w<N, 1, false>(h, q, qd, goal, gs, o, out, ro, R, s);
   }
   return false;
 }
