@@ -14,32 +14,48 @@ import numpy as np
 KEYS3 = ("pos_on_link_in_base_frame", "pos_on_obstacle_in_base_frame", "normal_vec", "relative_position")
 
 
+def _is_tensor(v):
+    return hasattr(v, "detach") and hasattr(v, "device")
+
+
 class ArrayVar:
-    """Mutable array holder with tf.Variable-like assign()."""
+    """Mutable array holder with tf.Variable-like assign().  The value is a host array or, when the device stages fill it
+    (RmpCore.update_distances / Datamanager.update_device), a torch tensor that stays where it is: numpy() copies it to the
+    host, as_tensor() hands it to the engine without a host hop."""
 
     def __init__(self, value):
-        self.value = np.asarray(value, dtype=np.float32)
+        self.assign(value)
 
     def assign(self, value):
-        self.value = np.asarray(value, dtype=np.float32)
+        self.value = value.detach() if _is_tensor(value) else np.asarray(value, dtype=np.float32)
         return self
 
     def numpy(self):
-        return self.value
+        return self.value.cpu().numpy() if _is_tensor(self.value) else self.value
 
     def __array__(self, dtype=None, copy=None):
-        return self.value if dtype is None else self.value.astype(dtype)
+        v = self.numpy()
+        return v if dtype is None else v.astype(dtype)
 
 
 def as_array(holder):
     """numpy view of an ArrayVar / ndarray / torch tensor / tf tensor."""
     if isinstance(holder, ArrayVar):
-        return holder.value
+        return holder.numpy()
     if hasattr(holder, "detach"):
         return holder.detach().cpu().numpy()
     if hasattr(holder, "numpy"):
         return np.asarray(holder.numpy(), dtype=np.float32)
     return np.asarray(holder, dtype=np.float32)
+
+
+def as_tensor(holder, device):
+    """fp32 torch tensor on `device` of an ArrayVar / ndarray / torch tensor: a tensor already there is not copied."""
+    import torch
+    v = holder.value if isinstance(holder, ArrayVar) else holder
+    if _is_tensor(v):
+        return v.detach().to(device=device, dtype=torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(as_array(v), dtype=np.float32)).to(device)
 
 
 class Datamanager:
@@ -71,3 +87,28 @@ class Datamanager:
             T = np.asarray(self.fkine.forward(np.asarray(q, dtype=np.float32)[None, :], frame))[0]
             p_link = np.stack([d[1] for d in rows]).astype(np.float32)
             st["relative_position"].assign((p_link - T[:3, 3][None, :]) @ T[:3, :3])
+
+    def update_device(self, core, q, primitives, link_capsules=None):
+        """The same five fields, filled on the device for a whole fleet without PyBullet and without a host hop: `core` is the
+        RmpCore whose distance leaves read this manager's holders; its closest-point stage (rmp2_closest_points_links) writes
+        pos_on_link / pos_on_obstacle for every (robot, leaf, primitive) pair, and distance, normal_vec and relative_position
+        follow from them (simulation.py:462-484 reports the same tuple; data_management.py:33-53 the relative position).
+        q: [R, n] tensor on the core's device; primitives: [K,4] spheres or [K,8] capsules; link_capsules: urdf.link_capsules(...)
+        rows in the order of the core's distance leaves, or None for the frame origins as control points."""
+        import torch
+        pairs = core.update_distances(q, primitives, link_capsules=link_capsules)
+        eng = core.engine_for(q)
+        qt = as_tensor(q, eng.device)
+        single = qt.dim() == 1
+        T = eng.forward_kinematics(qt[None] if single else qt)            # [R, F, 4, 4] on the device
+        for frame, (pl, po) in pairs.items():
+            st = self.state[frame]
+            st["pos_on_link_in_base_frame"].assign(pl)      # the same tensors when the leaves hold this manager's holders
+            st["pos_on_obstacle_in_base_frame"].assign(po)
+            diff = pl - po
+            dist = torch.linalg.norm(diff, dim=-1)
+            st["distance"].assign(dist)
+            st["normal_vec"].assign(diff / dist.clamp_min(1e-12).unsqueeze(-1))
+            Tf = T[:, self.fkine.table.frame_index(frame)]
+            rel = torch.einsum("rbk,rkj->rbj", (pl[None] if single else pl) - Tf[:, None, :3, 3], Tf[:, :3, :3])
+            st["relative_position"].assign(rel[0] if single else rel)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import descriptor as D
-from .data_management import as_array
+from .data_management import ArrayVar, as_array, as_tensor
 from .rmp2 import RiemannianMotionPolicy
 from .taskmap import IdentityTaskmap, TaskmapSphereDistance, classify
 from .urdf import KinematicTable
@@ -78,6 +78,7 @@ class RmpCore:
         table = fks[0].table if fks else _null_table(n_dof)
         if table.n_dof != n_dof:
             raise ValueError(f"q has {n_dof} entries, the robot has {table.n_dof} dof")
+        self._table = table
         specs = [rmp.leaf_spec(lambda fk: table.frame_index(fk.frame)) for rmp in self.rmps.values()]
         sig = (id(table), self.solve, tuple(s.signature() for s in specs))
         if sig != self._signature:
@@ -88,8 +89,119 @@ class RmpCore:
             self._signature = sig
         return self._engine
 
+    def engine_for(self, q):
+        """The compiled engine of the current policy set for joint vectors shaped like `q` ([n] or [R, n])."""
+        return self._compile(int(q.shape[-1]))
+
+    def _pair_leaves(self):
+        pair_rmps = [(rmp, classify(rmp.taskmap)) for rmp in self.rmps.values()]
+        return [(rmp, kind, last) for rmp, (kind, _, last) in pair_rmps if kind in (D.TASKMAP_FK_DISTANCE, D.TASKMAP_FK_POINT)]
+
+    def update_distances(self, q, primitives, link_capsules=None):
+        """The closest-point preprocessing stage on the device (simulation.py:462-484 calculate_distances followed by
+        data_management.py:16-31 update): for every TaskmapJointFrame4x4ToDistance leaf and every obstacle primitive
+        ([K,4] spheres or [K,8] capsules) the nearest points of the link (its capsule from `link_capsules`, rows in leaf order;
+        None: the frame origin) and the obstacle, written into the leaves' holders as device tensors [R,K,3] ([K,3] for one
+        robot) that the next evaluate(q, ...) reads in place.  Returns {frame name: (p_link, p_obs)}."""
+        single = q.dim() == 1 if isinstance(q, torch.Tensor) else np.ndim(q) == 1
+        eng = self.engine_for(q)
+        qt = as_tensor(q, eng.device)
+        qt = qt[None] if single else qt
+        leaves = [(rmp, last) for rmp, kind, last in self._pair_leaves() if kind == D.TASKMAP_FK_DISTANCE
+                  and not isinstance(last, TaskmapSphereDistance)]
+        if not leaves:
+            raise ValueError("update_distances: the policy set has no TaskmapJointFrame4x4ToDistance leaf")
+        dist_idx = [i for i in range(eng.desc.n_leaves) if eng.desc.leaves[i].taskmap == D.TASKMAP_FK_DISTANCE]
+        if len(leaves) != len(dist_idx):
+            raise NotImplementedError("mixing explicit-pair and sphere distance task maps in one core")
+        if len(dist_idx) != len(eng._dist_leaves):
+            raise NotImplementedError("update_distances: attached-point leaves (TaskmapRelative4x4) carry their own pair data")
+        table = eng.obstacles(spheres=as_tensor(primitives, eng.device))
+        K = int(table.n_spheres)
+        pl, po = eng.closest_points(qt, table, link_capsules=None if link_capsules is None else as_tensor(link_capsules, eng.device))
+        self._pairs_cache = (pl, po, [K] * len(leaves))
+        out = {}
+        names = self._table.frame_names
+        for i, (rmp, last) in enumerate(leaves):
+            a, b = pl[:, i * K:(i + 1) * K], po[:, i * K:(i + 1) * K]
+            a, b = (a[0], b[0]) if single else (a, b)
+            for attr, v in (("pos_on_link_in_base_frame", a), ("pos_on_obstacle_in_base_frame", b)):
+                h = getattr(last, attr)
+                if isinstance(h, ArrayVar):
+                    h.assign(v)
+                else:
+                    setattr(last, attr, v)
+            out[names[eng.desc.leaves[dist_idx[i]].frame]] = (a, b)
+        return out
+
+    def _evaluate_device(self, q, qd, spheres):
+        """evaluate() for tensors that already live on the engine's device: nothing goes through the host, the result is a
+        device tensor on the caller's stream.  Same gathering rules as below."""
+        single = q.dim() == 1
+        eng = self.engine_for(q)
+        dev = eng.device
+        q2, qd2 = (q[None] if single else q), (as_tensor(qd, dev)[None] if single else as_tensor(qd, dev))
+        R = q2.shape[0]
+        goals = [as_tensor(g, dev) for g in (rmp._goal() for rmp in self.rmps.values()) if g is not None]
+        goal = None
+        if goals:
+            goal = torch.cat([g if g.dim() == 2 else g.expand(R, g.shape[0]) for g in goals], dim=1) \
+                if any(g.dim() == 2 for g in goals) else torch.cat(goals)
+        obstacles = None
+        pair_rmps = self._pair_leaves()
+        if pair_rmps:
+            if all(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
+                sp = spheres if spheres is not None else self.spheres
+                if sp is None:
+                    raise ValueError("TaskmapSphereDistance leaves need evaluate(..., spheres=[K,4])")
+                obstacles = eng.obstacles(spheres=as_tensor(sp, dev))
+            elif not any(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
+                def fleet(a, nd):
+                    a = as_tensor(a, dev)
+                    return a if a.dim() == nd else a.expand((R,) + tuple(a.shape))
+                pl, po, dd = [], [], []
+                for rmp, kind, last in pair_rmps:
+                    if kind == D.TASKMAP_FK_DISTANCE:
+                        pl.append(fleet(last.pos_on_link_in_base_frame, 3))
+                        po.append(fleet(last.pos_on_obstacle_in_base_frame, 3))
+                        dd.append(None)
+                    else:
+                        pl.append(fleet(last.relative_pos, 3))
+                        po.append(fleet(rmp.vec, 3))
+                        dd.append(fleet(rmp.d, 2))
+                    if pl[-1].shape != po[-1].shape or (dd[-1] is not None and dd[-1].shape != pl[-1].shape[:2]):
+                        raise ValueError(f"{rmp.name}: pair arrays disagree in shape")
+                has_point = any(d is not None for d in dd)
+                dd = [d if d is not None else torch.zeros(a.shape[:2], dtype=torch.float32, device=dev) for d, a in zip(dd, pl)]
+                counts = [a.shape[1] for a in pl]
+                whole = self._whole_pair_arrays(pl, po, counts) if not has_point else None
+                p_link, p_obs = whole if whole is not None else (torch.cat(pl, dim=1), torch.cat(po, dim=1))
+                obstacles = eng.obstacles(p_link=p_link, p_obs=p_obs, dist=torch.cat(dd, dim=1) if has_point else None,
+                                          pair_counts=counts)
+            else:
+                raise NotImplementedError("mixing explicit-pair and sphere distance task maps in one core")
+        out = eng.step(q2, qd2, goal=goal, obstacles=obstacles)
+        return out[0] if single else out
+
+    def _whole_pair_arrays(self, pl, po, counts):
+        """The holders are usually the per-leaf views update_distances handed out: then the arrays it wrote ARE the kernel's
+        [R,P,3] input and nothing is gathered."""
+        cache = getattr(self, "_pairs_cache", None)
+        if cache is None or cache[2] != counts or pl[0].shape[0] != cache[0].shape[0]:
+            return None
+        off = 0
+        for a, b, k in zip(pl, po, counts):
+            wa, wb = cache[0][:, off:off + k], cache[1][:, off:off + k]
+            if a.data_ptr() != wa.data_ptr() or b.data_ptr() != wb.data_ptr() or a.stride() != wa.stride() or b.stride() != wb.stride():
+                return None
+            off += k
+        return cache[0], cache[1]
+
     def evaluate(self, q, qd, spheres=None):
-        """q, qd: [n] (one robot, as in the reference) or [R, n].  Returns qdd of the same shape."""
+        """q, qd: [n] (one robot, as in the reference) or [R, n].  Returns qdd of the same shape: a QddResult (host array) for
+        host inputs, a device tensor -- no host hop anywhere -- when q is a tensor on the engine's device."""
+        if isinstance(q, torch.Tensor) and q.is_cuda:
+            return self._evaluate_device(q, qd, spheres)
         single = np.ndim(q) == 1
         q2 = np.atleast_2d(np.asarray(as_array(q), dtype=np.float32))
         qd2 = np.atleast_2d(np.asarray(as_array(qd), dtype=np.float32))
@@ -110,9 +222,7 @@ class RmpCore:
                 if per_robot else np.concatenate(goals)
         # obstacle data: gather the holders of all pair-consuming leaves (leaf order)
         obstacles = None
-        pair_rmps = [(rmp, classify(rmp.taskmap)) for rmp in self.rmps.values()]
-        pair_rmps = [(rmp, kind, last) for rmp, (kind, _, last) in pair_rmps
-                     if kind in (D.TASKMAP_FK_DISTANCE, D.TASKMAP_FK_POINT)]
+        pair_rmps = self._pair_leaves()
         if pair_rmps:
             if all(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
                 sp = spheres if spheres is not None else self.spheres

@@ -21,6 +21,8 @@ class LeafResult(np.ndarray):
 
 def as_plain(v):
     """Array view of a goal / data holder (list, ndarray, or a Datamanager-style holder with .numpy())."""
+    if hasattr(v, "detach"):
+        return v.detach().cpu().numpy()
     return v.numpy() if hasattr(v, "numpy") else v
 
 
@@ -98,7 +100,7 @@ class RiemannianMotionPolicy:
         va, vb = self._vectors()
         g = self._goal()
         return D.LeafSpec(self.KIND, kind, frame, self._params(), va, vb,
-                          goal_len=0 if g is None else int(np.asarray(g).shape[-1]), name=self.name)
+                          goal_len=0 if g is None else int(g.shape[-1] if hasattr(g, 'shape') else np.asarray(g).shape[-1]), name=self.name)
 
 
 class TargetAttractor(RiemannianMotionPolicy):

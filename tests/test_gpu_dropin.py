@@ -21,12 +21,10 @@ def _import_compat():
     return rmp, rmp2, taskmap, kinematics, data_management
 
 
-def test_experiment06_style_script(golden_dir, hip_lib):
-    """experiments/franka_panda/06_cluttered_environment.py:55-131 written against the compat modules,
-    fed with the golden config-3 closest-point pairs through the Datamanager holders."""
-    rmp, rmp2, taskmap, kinematics, data_management = _import_compat()
+def _experiment06_core(mods):
+    """The policy set of experiments/franka_panda/06_cluttered_environment.py:55-118, built with the reference's names."""
+    rmp, rmp2, taskmap, kinematics, data_management = mods
     from riemannian_motion_policies_amd import configs as Cf, urdf
-    g = np.load(os.path.join(golden_dir, "config3.npz"))
     fkine = kinematics.UrdfForwardKinematic(urdf_filepath=urdf.PANDA_URDF, order=urdf.PANDA_ORDER)
     data_manager = data_management.Datamanager(fkine)
     core = rmp.RmpCore()
@@ -52,6 +50,16 @@ def test_experiment06_style_script(golden_dir, hip_lib):
                                             repulsion_std_dev=0.01, metric_modulation_radius=0.5, metric_scalar=1,
                                             metric_exploder_std_dev=0.02, metric_exploder_eps=0.001, taskmap=tm,
                                             name=f'collision_avoidance_for_{frame}'))
+    return fkine, data_manager, core, target_rmp, ee
+
+
+def test_experiment06_style_script(golden_dir, hip_lib):
+    """experiments/franka_panda/06_cluttered_environment.py:55-131 written against the compat modules,
+    fed with the golden config-3 closest-point pairs through the Datamanager holders."""
+    mods = _import_compat()
+    from riemannian_motion_policies_amd import configs as Cf
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    fkine, data_manager, core, target_rmp, ee = _experiment06_core(mods)
     pl, po = Cf.pairs_from_spheres(g["origins"], g["spheres"])
     K = len(g["spheres"])
     for r in range(4):  # one robot per call, exactly like the reference's control loop
@@ -69,6 +77,64 @@ def test_experiment06_style_script(golden_dir, hip_lib):
     assert np.abs(x - O.forward_kinematics(d3, g["q"][:1])[0, 11, :3, 3]).max() < 1e-6
     xx, xd, J, c = ee.differentiate(g["q"][:1], g["qd"][:1])
     assert xx.shape == (1, 3) and J.shape == (1, 3, 9) and np.abs(xx[0] - x).max() < 1e-6
+
+
+def test_experiment06_loop_stays_on_the_device(golden_dir, hip_lib):
+    """The whole control-loop body of 06_cluttered_environment.py:120-131 for a fleet without a host hop: the closest-point
+    stage fills the Datamanager's holders on the device (Datamanager.update_device, in place of PyBullet's getClosestPoints +
+    Datamanager.update), RmpCore.evaluate reads them there and returns a device tensor.
+    (i) frame origins as control points reproduce the golden config-3 accelerations; (ii) the five Datamanager fields agree
+    with the host update() fed the same tuples; (iii) with the links' capsules the result equals the oracle's on the fp64
+    closed-form pairs."""
+    import torch
+    import oracle as O
+    mods = _import_compat()
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf as U
+    g = np.load(os.path.join(golden_dir, "config3.npz"))
+    fkine, data_manager, core, target_rmp, ee = _experiment06_core(mods)
+    dev = torch.device("cuda", 0)
+    q, qd = torch.from_numpy(g["q"]).to(dev), torch.from_numpy(g["qd"]).to(dev)
+    spheres = torch.from_numpy(g["spheres"]).to(dev)
+    target_rmp.goal = torch.from_numpy(g["goal"]).to(dev)
+    R, K = q.shape[0], spheres.shape[0]
+    data_manager.update_device(core, q, spheres)
+    qdd = core.evaluate(q, qd)
+    assert isinstance(qdd, torch.Tensor) and qdd.is_cuda and qdd.shape == (R, 9)
+    err = np.abs(qdd.cpu().numpy() - g["qdd"]).max(axis=1)
+    assert (err <= ATOL * np.maximum(1.0, np.abs(g["qdd"]).max(axis=1))).all()
+    # the holders the leaves read ARE the stage's output: nothing was gathered or copied
+    first = data_manager[Cf.CONTROL_POINT_FRAMES[0]]['pos_on_link_in_base_frame'].value
+    assert first.is_cuda and first.data_ptr() == core._pairs_cache[0].data_ptr()
+    # (ii) the same fields as the host path fills for robot 0
+    pl, po = Cf.pairs_from_spheres(g["origins"], g["spheres"])
+    host = mods[4].Datamanager(fkine)
+    diff = pl[0] - po[0]
+    dist = np.linalg.norm(diff, axis=-1)
+    host.update(g["q"][0], [(fr, pl[0, c * K + b], po[0, c * K + b], diff[c * K + b] / dist[c * K + b], dist[c * K + b], "")
+                            for c, fr in enumerate(Cf.CONTROL_POINT_FRAMES) for b in range(K)])
+    for fr in Cf.CONTROL_POINT_FRAMES:
+        for key in ("pos_on_link_in_base_frame", "pos_on_obstacle_in_base_frame", "normal_vec", "distance", "relative_position"):
+            a, b = data_manager[fr][key].numpy()[0], host[fr][key].numpy()
+            assert a.shape == b.shape and np.abs(a - b).max() < 5e-6, (fr, key)
+    # one robot, as the reference's loop calls it
+    data_manager.update_device(core, q[1], spheres)
+    target_rmp.goal = g["goal"][1]
+    one = core.evaluate(q[1], qd[1])
+    assert one.shape == (9,) and np.abs(one.cpu().numpy() - g["qdd"][1]).max() <= ATOL * max(1.0, np.abs(g["qdd"][1]).max())
+    # (iii) link capsules, obstacles lifted clear of contact
+    lc = U.link_capsules(U.PANDA_URDF, fkine.table, Cf.CONTROL_POINT_FRAMES)
+    tab = g["spheres"].copy()
+    tab[:, 2] += np.float32(0.9)
+    target_rmp.goal = torch.from_numpy(g["goal"]).to(dev)
+    data_manager.update_device(core, q, torch.from_numpy(tab).to(dev), link_capsules=lc)
+    qdd = core.evaluate(q, qd)
+    _, d3 = Cf.config3()
+    T = O.forward_kinematics(d3, g["q"], precision="f64")
+    frames = [d3.leaves[i].frame for i in D.distance_leaf_indices(d3)]
+    pl_ref, po_ref = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
+    ref = O.step(d3, g["q"], g["qd"], g["goal"], p_link=pl_ref.astype(np.float32), p_obs=po_ref.astype(np.float32))["qdd64"]
+    err = np.abs(qdd.cpu().numpy() - ref).max(axis=1)
+    assert (err <= 2e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))).all(), err.max()
 
 
 def test_two_joint_script_and_fleet_evaluate(golden_dir, hip_lib):
