@@ -213,7 +213,8 @@ int rmp2_validate(const rmp2_desc *desc);
 /* Environment variables read by rmp2_create (and by nothing else).  They are DIAGNOSTIC overrides of the per-call kernel
  * dispatch, used by the parity tests and the profiling tools to force every mapping over the same inputs; all choices
  * produce the same numbers to fp32 rounding, none is needed for correctness, and an unset variable means "by fleet size":
- *   RMP2_KERNEL     = hex | quad | lane   mapping of robots to lanes (16 / 4 / 1 lanes per robot)
+ *   RMP2_KERNEL     = hex | quad | lane   mapping of robots to lanes (16 / 4 / 1 lanes per robot);
+ *                                         lane also selects the lane-per-robot form of the closest-point stage
  *   RMP2_QUAD_MINW  = 2 | 3 | 4           register cap of the quad mapping's throughput build (waves per SIMD it leaves room for)
  *   RMP2_QUAD_SYM   = 0                   general (full-matrix) form of the quad mapping for sets that qualify for the symmetric one
  *   RMP2_EXCHANGE_THROTTLE_US = n         (rmp2_exchange_create) bound of the host throttle of rmp2_exchange_step, 0 = free-running

@@ -674,6 +674,118 @@ rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict
   }
 }
 
+// The same stage with coalesced output (the arrays are the whole cost: 24 B per pair, 6 KB per robot at 8 x 32 pairs).
+// One wave per kClosestRobots robots.  Phase 1, a lane per robot: FK, and each distance leaf's link segment in world
+// coordinates (A, r_link, B -- A = B = the frame origin, r_link = 0 without link geometry) into LDS.  Phase 2, a lane per PAIR:
+// the lane keeps its obstacle primitive in registers and walks the wave's robots; the 64 lanes of a chunk write 64 consecutive
+// pairs of one robot, 768 contiguous bytes per array and store, past the cache (written once, read by a later kernel).  The
+// lane-per-robot kernel above writes 4 bytes per lane at a 3 KB stride: 1.2 TB/s, 325 us for 65 536 robots x 256 pairs; this
+// one 4.1-4.9 TB/s, 82-98 us (a memset of the same bytes: 6.5 TB/s).  Same closed forms; the unit normal is scaled by one
+// reciprocal instead of three divisions, and a sphere obstacle takes the point-segment form of segment_segment.
+constexpr int kClosestRobots = 16;
+typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+
+template <int SLOTS, bool LINK, bool CAPS>
+__global__ void __launch_bounds__(kWave)
+rmp2_closest_wave_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q, const ObsArgs obs,
+                         const float* __restrict__ link_caps, int n_dist, float* __restrict__ p_link, float* __restrict__ p_obs,
+                         int R) {
+  extern __shared__ float4 seg[];  // [kClosestRobots][n_dist][2] = (A, r_link), (B, -)
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * kClosestRobots;
+  const int robot = r0 + lane;
+  if (lane < kClosestRobots && robot < R) {
+    const float* my_q = q + (size_t)robot * prog->n_dof;
+    FrameState cur;
+    FrameState slot[SLOTS > 0 ? SLOTS : 1];
+    for (int k = 0; k < prog->n_ops; ++k) {
+      const DevOp& op = prog->ops[k];
+      if (SLOTS > 0 && op.restore >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.restore == s) cur = slot[s];
+      }
+      float z[3];
+      visit_frame<false>(cur, op, op.qidx >= 0 ? my_q[op.qidx] : 0.f, 0.f, op.restore == -2, z);
+      if (SLOTS > 0 && op.save >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if (op.save == s) slot[s] = cur;
+      }
+      for (int li = 0; li < op.leaf_count; ++li) {
+        const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
+        if (lf.taskmap != RMP2_TASKMAP_FK_DISTANCE) continue;
+        const int ord = obs.pair_begin[lf.index] / obs.n_spheres;  // ordinal of the distance leaf
+        float4 a = make_float4(cur.p[0], cur.p[1], cur.p[2], 0.f), b = a;
+        if (LINK) {
+          const float* lc = link_caps + 8 * ord;
+          float A[3], B[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            A[i] = cur.p[i] + cur.R[3 * i] * lc[0] + cur.R[3 * i + 1] * lc[1] + cur.R[3 * i + 2] * lc[2];
+            B[i] = cur.p[i] + cur.R[3 * i] * lc[4] + cur.R[3 * i + 1] * lc[5] + cur.R[3 * i + 2] * lc[6];
+          }
+          a = make_float4(A[0], A[1], A[2], lc[3]);
+          b = make_float4(B[0], B[1], B[2], 0.f);
+        }
+        seg[(lane * n_dist + ord) * 2] = a;
+        seg[(lane * n_dist + ord) * 2 + 1] = b;
+      }
+    }
+  }
+  __syncthreads();
+  const int n_live = min(kClosestRobots, R - r0);
+  const int P = obs.n_pairs, K = obs.n_spheres;
+  for (int p0 = 0; p0 < P; p0 += kWave) {
+    const int p = p0 + lane;
+    const bool ok = p < P;
+    const int pp = ok ? p : 0;
+    const int leaf = pp / K, bi = pp - leaf * K;
+    float4 ca, cb;
+    if (CAPS) {
+      ca = reinterpret_cast<const float4*>(obs.spheres)[2 * bi];
+      cb = reinterpret_cast<const float4*>(obs.spheres)[2 * bi + 1];
+    } else {
+      ca = cb = reinterpret_cast<const float4*>(obs.spheres)[bi];
+    }
+    const float r_obs = ca.w;
+    size_t off = ((size_t)r0 * P + p) * 3;
+    for (int r = 0; r < n_live; ++r, off += (size_t)P * 3) {
+      const float4 sa = seg[(r * n_dist + leaf) * 2];
+      float X[3] = {sa.x, sa.y, sa.z}, Y[3] = {ca.x, ca.y, ca.z};  // nearest points of the two axes
+      if (LINK) {
+        const float4 sb = seg[(r * n_dist + leaf) * 2 + 1];
+        const float A[3] = {sa.x, sa.y, sa.z}, B[3] = {sb.x, sb.y, sb.z};
+        const float C[3] = {ca.x, ca.y, ca.z}, D[3] = {cb.x, cb.y, cb.z};
+        float sl, to = 0.f;
+        if (CAPS) {
+          segment_segment(A, B, C, D, sl, to);
+        } else {  // (segment_segment with a point as the second segment)
+          const float d1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+          const float rr[3] = {A[0] - C[0], A[1] - C[1], A[2] - C[2]};
+          const float aa = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+          const float cc = d1[0] * rr[0] + d1[1] * rr[1] + d1[2] * rr[2];
+          sl = aa > 0.f ? fminf(fmaxf(-cc / aa, 0.f), 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          X[c] = A[c] + sl * (B[c] - A[c]);
+          if (CAPS) Y[c] = C[c] + to * (D[c] - C[c]);
+        }
+      } else if (CAPS) {
+        capsule_centre(ca, cb, X, Y);
+      }
+      const float n[3] = {X[0] - Y[0], X[1] - Y[1], X[2] - Y[2]};
+      const float inv = 1.0f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (ok) {
+        const float wl = LINK ? sa.w * inv : 0.f, wo = r_obs * inv;
+        __builtin_nontemporal_store(f32x3{X[0] - wl * n[0], X[1] - wl * n[1], X[2] - wl * n[2]}, reinterpret_cast<f32x3*>(p_link + off));
+        __builtin_nontemporal_store(f32x3{Y[0] + wo * n[0], Y[1] + wo * n[1], Y[2] + wo * n[2]}, reinterpret_cast<f32x3*>(p_obs + off));
+      }
+    }
+  }
+}
+
 // x = vec(T_frame), xd = J qd, J = d vec(T)/dq, c = Jdot qd   (kinematics.py:250-270)
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave)
@@ -1950,6 +2062,30 @@ int rmp2_closest_points_links(rmp2_handle* h, const float* q, const rmp2_obstacl
   o.capsule = table->primitive == RMP2_PRIM_CAPSULE ? 1 : 0;
   o.spheres = table->spheres;
   o.pair_begin = h->d_pair_begin;
+  const int n_dist = acc / table->n_spheres;
+  const size_t seg_bytes = sizeof(float4) * 2 * kClosestRobots * n_dist;
+  if (seg_bytes <= 64 * 1024 && h->kernel_choice != 1) {  // (more distance leaves than that, or RMP2_KERNEL=lane: a lane per robot)
+    const int wblocks = (R + kClosestRobots - 1) / kClosestRobots;
+#define RMP2_CLOSEST_WAVE_(SLOTS_, LINK_, CAPS_)                                                                        \
+    hipLaunchKernelGGL((rmp2_closest_wave_kernel<SLOTS_, LINK_, CAPS_>), dim3(wblocks), dim3(kWave), seg_bytes, s, h->d_prog, q, o, \
+                       link_capsules, n_dist, p_link, p_obs, R)
+#define RMP2_CLOSEST_WAVE(SLOTS_)                                                                                       \
+    do {                                                                                                                \
+      if (link_capsules && o.capsule) RMP2_CLOSEST_WAVE_(SLOTS_, true, true);                                           \
+      else if (link_capsules) RMP2_CLOSEST_WAVE_(SLOTS_, true, false);                                                  \
+      else if (o.capsule) RMP2_CLOSEST_WAVE_(SLOTS_, false, true);                                                      \
+      else RMP2_CLOSEST_WAVE_(SLOTS_, false, false);                                                                    \
+    } while (0)
+    switch (h->n_slots) {
+      case 0: RMP2_CLOSEST_WAVE(0); break;
+      case 1: RMP2_CLOSEST_WAVE(1); break;
+      default: RMP2_CLOSEST_WAVE(2); break;
+    }
+#undef RMP2_CLOSEST_WAVE
+#undef RMP2_CLOSEST_WAVE_
+    HIP_TRY(h, hipGetLastError());
+    return RMP2_OK;
+  }
   const int blocks = (R + kWave - 1) / kWave;
   switch (h->n_slots) {
     case 0: hipLaunchKernelGGL((rmp2_closest_kernel<0>), dim3(blocks), dim3(kWave), 0, s, h->d_prog, q, o, link_capsules, p_link, p_obs, R); break;

@@ -101,6 +101,20 @@ def test_ragged_capsules_vs_oracle(torch_mod):
     _gate(qdd, ref["qdd64"], clr_all, "ragged capsules")
 
 
+def _engine_with(desc, kernel):
+    """Engine created under RMP2_KERNEL=kernel (read at rmp2_create)."""
+    from riemannian_motion_policies_amd.engine import Engine
+    old = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel
+    try:
+        return Engine(desc, 0)
+    finally:
+        if old is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old
+
+
 @pytest.mark.parametrize("prim", ["sphere", "capsule"])
 def test_closest_point_stage_feeds_explicit_pairs(torch_mod, prim):
     """rmp2_closest_points writes exactly the arrays the reference's Datamanager holds; (i) they match an
@@ -123,6 +137,9 @@ def test_closest_point_stage_feeds_explicit_pairs(torch_mod, prim):
     assert p_link.shape == (R, 8 * K, 3)
     assert np.abs(p_link.cpu().numpy() - pl_ref).max() < 2e-6
     assert np.abs(p_obs.cpu().numpy() - po_ref).max() < 2e-6
+    # the lane-per-robot form of the stage (RMP2_KERNEL=lane; the fallback beyond 32 distance leaves) writes the same arrays
+    pl1, po1 = _engine_with(desc, "lane").closest_points(torch.from_numpy(s["q"]), tab)
+    assert (pl1 - p_link).abs().max().item() == 0.0 and (po1 - p_obs).abs().max().item() < 1e-6
     fused, _ = _step(torch, eng, s, spheres=table)
     o = eng.obstacles(p_link=p_link, p_obs=p_obs)
     fed = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=o)
@@ -193,6 +210,8 @@ def test_closest_points_with_link_geometry(torch_mod, prim, robot):
     frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
     pl_ref, po_ref = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
     assert np.abs(pl.cpu().numpy() - pl_ref).max() < 2e-6 and np.abs(po.cpu().numpy() - po_ref).max() < 2e-6
+    pl1, po1 = _engine_with(desc, "lane").closest_points(torch.from_numpy(s["q"]), t_dev, link_capsules=torch.from_numpy(lc))
+    assert (pl1 - pl).abs().max().item() < 1e-6 and (po1 - po).abs().max().item() < 1e-6   # lane-per-robot form of the stage
     # the control points really differ from the frame origins, pair by pair
     pl0, _ = eng.closest_points(torch.from_numpy(s["q"]), t_dev)
     assert (pl - pl0).abs().max().item() > 0.03
