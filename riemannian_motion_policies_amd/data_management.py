@@ -54,6 +54,8 @@ def as_tensor(holder, device):
     import torch
     v = holder.value if isinstance(holder, ArrayVar) else holder
     if _is_tensor(v):
+        if v.device == device and v.dtype == torch.float32:
+            return v.detach() if v.requires_grad else v
         return v.detach().to(device=device, dtype=torch.float32)
     return torch.from_numpy(np.ascontiguousarray(as_array(v), dtype=np.float32)).to(device)
 
@@ -73,19 +75,25 @@ class Datamanager:
     def update(self, q, distance_data):
         """distance_data: tuples (frame_name, p_link[3], p_obs[3], normal[3], distance, descr)
         as produced by the reference's Simulation.calculate_distances (simulation.py:462-484)."""
+        by_frame = {}
+        for d in distance_data:
+            by_frame.setdefault(d[0], []).append(d)
+        T_all = None
         for frame in self.fkine.frame_names:
-            rows = [d for d in distance_data if d[0] == frame]
+            rows = by_frame.get(frame)
             if not rows:
                 continue
             st = self.state[frame]
-            st["pos_on_link_in_base_frame"].assign(np.stack([d[1] for d in rows]))
-            st["pos_on_obstacle_in_base_frame"].assign(np.stack([d[2] for d in rows]))
-            st["normal_vec"].assign(np.stack([d[3] for d in rows]))
+            p_link = np.asarray([d[1] for d in rows], dtype=np.float32)
+            st["pos_on_link_in_base_frame"].assign(p_link)
+            st["pos_on_obstacle_in_base_frame"].assign(np.asarray([d[2] for d in rows], dtype=np.float32))
+            st["normal_vec"].assign(np.asarray([d[3] for d in rows], dtype=np.float32))
             st["distance"].assign(np.asarray([d[4] for d in rows], dtype=np.float32))
             # data_management.py:33-53 preprocess/_get_relative_pos: the point on the link expressed in the joint
-            # frame, rel = R_base_joint^T (p_link - p_joint); one device FK per frame instead of one per tuple
-            T = np.asarray(self.fkine.forward(np.asarray(q, dtype=np.float32)[None, :], frame))[0]
-            p_link = np.stack([d[1] for d in rows]).astype(np.float32)
+            # frame, rel = R_base_joint^T (p_link - p_joint); ONE device FK for all frames instead of one per tuple
+            if T_all is None:
+                T_all = np.asarray(self.fkine.forward_all(np.asarray(q, dtype=np.float32)[None, :]))[0]
+            T = T_all[self.fkine.table.frame_index(frame)]
             st["relative_position"].assign((p_link - T[:3, 3][None, :]) @ T[:3, :3])
 
     def update_device(self, core, q, primitives, link_capsules=None):
@@ -101,14 +109,23 @@ class Datamanager:
         qt = as_tensor(q, eng.device)
         single = qt.dim() == 1
         T = eng.forward_kinematics(qt[None] if single else qt)            # [R, F, 4, 4] on the device
-        for frame, (pl, po) in pairs.items():
+        # the stage's whole output at once (the per-frame holders are views of it): a handful of launches, not five per frame
+        pl_all, po_all = core._pairs_cache[0], core._pairs_cache[1]      # [R, L * K, 3]
+        frames = list(pairs)
+        L = len(frames)
+        K = pl_all.shape[1] // L
+        diff = pl_all - po_all
+        dist = torch.linalg.norm(diff, dim=-1)
+        nvec = diff / dist.clamp_min(1e-12).unsqueeze(-1)
+        idx = torch.as_tensor([self.fkine.table.frame_index(f) for f in frames], device=eng.device)
+        Tf = T.index_select(1, idx)                                        # [R, L, 4, 4]
+        rel = torch.einsum("rlbk,rlkj->rlbj", pl_all.view(-1, L, K, 3) - Tf[:, :, None, :3, 3], Tf[:, :, :3, :3])
+        for i, frame in enumerate(frames):
             st = self.state[frame]
+            pl, po = pairs[frame]
             st["pos_on_link_in_base_frame"].assign(pl)      # the same tensors when the leaves hold this manager's holders
             st["pos_on_obstacle_in_base_frame"].assign(po)
-            diff = pl - po
-            dist = torch.linalg.norm(diff, dim=-1)
-            st["distance"].assign(dist)
-            st["normal_vec"].assign(diff / dist.clamp_min(1e-12).unsqueeze(-1))
-            Tf = T[:, self.fkine.table.frame_index(frame)]
-            rel = torch.einsum("rbk,rkj->rbj", (pl[None] if single else pl) - Tf[:, None, :3, 3], Tf[:, :3, :3])
-            st["relative_position"].assign(rel[0] if single else rel)
+            sl = slice(i * K, (i + 1) * K)
+            st["distance"].assign(dist[0, sl] if single else dist[:, sl])
+            st["normal_vec"].assign(nvec[0, sl] if single else nvec[:, sl])
+            st["relative_position"].assign(rel[0, i] if single else rel[:, i])

@@ -37,6 +37,12 @@ class UrdfForwardKinematic:
 
     __call__ = forward
 
+    def forward_all(self, q):
+        """q [R,n] -> T [R, n_frames, 4, 4] of every frame (order of .frame_names) from one launch."""
+        q2 = np.atleast_2d(np.asarray(q, dtype=np.float32)) if not isinstance(q, torch.Tensor) else q
+        T = self._fk_engine().forward_kinematics(q2)
+        return T if isinstance(q, torch.Tensor) else T.cpu().numpy()
+
     def differentiate(self, q, qd, frame):
         """-> x[R,16], xd[R,16], J[R,16,n], c[R,16] of vec(T_frame) (kinematics.py:250-270)."""
         as_np = not isinstance(q, torch.Tensor)

@@ -24,6 +24,23 @@ class QddResult(np.ndarray):
         return np.asarray(self)
 
 
+def _stage_together(arrays, device, limit_floats: int = 1 << 22):
+    """Host arrays -> fp32 device tensors of the same shapes through ONE host-to-device copy (each at a 16-byte multiple of a
+    common buffer); beyond `limit_floats` in total the copies are made one by one (nothing to gain, one host pass more)."""
+    arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+    if sum(a.size for a in arrays) > limit_floats:
+        return [torch.from_numpy(a).to(device) for a in arrays]
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.size + 3) & ~3
+    buf = np.empty(total, dtype=np.float32)
+    for a, o in zip(arrays, offs):
+        buf[o:o + a.size] = a.reshape(-1)
+    dev = torch.from_numpy(buf).to(device)
+    return [dev[o:o + a.size].view(a.shape) for a, o in zip(arrays, offs)]
+
+
 def _null_table(n_dof: int) -> KinematicTable:
     """Robot with no frames: identity-task-map-only sets (e.g. experiments/two_joint_robot/03)."""
     z = np.zeros
@@ -49,6 +66,8 @@ class RmpCore:
         self.spheres = None  # shared sphere table [K,4] for TaskmapSphereDistance leaves
         self._engine = None
         self._signature = None
+        self._quick = None
+        self._pairs = []
 
     def __str__(self):
         out = ''
@@ -67,7 +86,25 @@ class RmpCore:
         self.rmps.pop(name)
 
     # ------------------------------------------------------------------------------
+    def _quick_signature(self, n_dof):
+        """What decides the compiled program, read from the leaves without building their specs: identities of the policy
+        and task-map objects, scalar parameters, constant vectors.  (Goals and obstacle data are per-call inputs.)"""
+        sig = [n_dof, self.solve]
+        for rmp in self.rmps.values():
+            va, vb = rmp._vectors()
+            g = rmp._goal()
+            sig.append((id(rmp), type(rmp).__name__, id(rmp.taskmap), tuple(rmp._params()),
+                        None if va is None else np.asarray(va, dtype=np.float64).tobytes(),
+                        None if vb is None else np.asarray(vb, dtype=np.float64).tobytes(),
+                        None if g is None else int(g.shape[-1] if hasattr(g, "shape") else len(g)),
+                        tuple((id(st), type(st).__name__, id(getattr(st, "fkine", None)), getattr(st, "frame", None))
+                              for st in rmp.taskmap.stages())))
+        return tuple(sig)
+
     def _compile(self, n_dof):
+        quick = self._quick_signature(n_dof)
+        if self._engine is not None and quick == self._quick:
+            return self._engine
         fks = []
         for rmp in self.rmps.values():
             _, fk, _ = classify(rmp.taskmap)
@@ -87,6 +124,9 @@ class RmpCore:
                 self._engine.close()
             self._engine = Engine(D.build_desc(table, specs, self.solve), self.device)
             self._signature = sig
+        self._quick = quick
+        self._pairs = [(rmp, kind, last) for rmp, (kind, _, last) in ((r, classify(r.taskmap)) for r in self.rmps.values())
+                       if kind in (D.TASKMAP_FK_DISTANCE, D.TASKMAP_FK_POINT)]
         return self._engine
 
     def engine_for(self, q):
@@ -94,8 +134,9 @@ class RmpCore:
         return self._compile(int(q.shape[-1]))
 
     def _pair_leaves(self):
-        pair_rmps = [(rmp, classify(rmp.taskmap)) for rmp in self.rmps.values()]
-        return [(rmp, kind, last) for rmp, (kind, _, last) in pair_rmps if kind in (D.TASKMAP_FK_DISTANCE, D.TASKMAP_FK_POINT)]
+        """(policy, task-map kind, last stage) of the leaves that consume per-pair obstacle data, in leaf order (as of the last
+        _compile: every entry point compiles first)."""
+        return self._pairs
 
     def update_distances(self, q, primitives, link_capsules=None):
         """The closest-point preprocessing stage on the device (simulation.py:462-484 calculate_distances followed by
@@ -172,7 +213,8 @@ class RmpCore:
                     if pl[-1].shape != po[-1].shape or (dd[-1] is not None and dd[-1].shape != pl[-1].shape[:2]):
                         raise ValueError(f"{rmp.name}: pair arrays disagree in shape")
                 has_point = any(d is not None for d in dd)
-                dd = [d if d is not None else torch.zeros(a.shape[:2], dtype=torch.float32, device=dev) for d, a in zip(dd, pl)]
+                if has_point:
+                    dd = [d if d is not None else torch.zeros(a.shape[:2], dtype=torch.float32, device=dev) for d, a in zip(dd, pl)]
                 counts = [a.shape[1] for a in pl]
                 whole = self._whole_pair_arrays(pl, po, counts) if not has_point else None
                 p_link, p_obs = whole if whole is not None else (torch.cat(pl, dim=1), torch.cat(po, dim=1))
@@ -246,8 +288,16 @@ class RmpCore:
                     if not (pl[-1].shape == po[-1].shape and dd[-1].shape == pl[-1].shape[:2]):
                         raise ValueError(f"{rmp.name}: pair arrays disagree in shape")
                 has_point = any(kind == D.TASKMAP_FK_POINT for _, kind, _ in pair_rmps)
-                obstacles = eng.obstacles(p_link=np.concatenate(pl, axis=1), p_obs=np.concatenate(po, axis=1),
-                                          dist=np.concatenate(dd, axis=1) if has_point else None,
+                # one staging copy for everything the step reads (q, qd, goal, pair arrays): at R = 1 -- the reference's own
+                # calling pattern -- five separate host-to-device copies cost more than the kernel
+                parts = [q2, qd2] + ([goal] if goal is not None else []) + \
+                        [np.concatenate(pl, axis=1), np.concatenate(po, axis=1)] + ([np.concatenate(dd, axis=1)] if has_point else [])
+                dev_parts = _stage_together(parts, eng.device)
+                q2, qd2 = dev_parts[0], dev_parts[1]
+                k = 2
+                if goal is not None:
+                    goal, k = dev_parts[2], 3
+                obstacles = eng.obstacles(p_link=dev_parts[k], p_obs=dev_parts[k + 1], dist=dev_parts[k + 2] if has_point else None,
                                           pair_counts=[a.shape[1] for a in pl])
             else:
                 raise NotImplementedError("mixing explicit-pair and sphere distance task maps in one core")

@@ -147,6 +147,51 @@ def test_exp05_object_graph_compiles_to_attached_point_leaves():
     assert np.allclose(out[:, :3, 3], [[1, 2.1, 3], [0.8, 2, 3]]) and np.allclose(out[:, :3, :3], T[:3, :3])
 
 
+def test_rmpcore_quick_signature_sees_every_mutation_that_changes_the_program():
+    """RmpCore.evaluate recompiles when the policy set changes (rmp.py:127-131 registry; leaf parameters are plain mutable
+    attributes in the reference).  The per-call check is a cheap signature: it must change with parameters, constant vectors,
+    the task map, the FK frame and the registry -- and must NOT change with goals or obstacle data (per-call inputs)."""
+    from riemannian_motion_policies_amd import rmp, rmp2, taskmap, urdf
+    from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
+    fk = UrdfForwardKinematic(urdf.PANDA_URDF, urdf.PANDA_ORDER)
+    core = rmp.RmpCore()
+    fkm = taskmap.TaskmapByForwardKinematic(fk, frame='panda_grasptarget_hand')
+    ee = taskmap.chain_taskmaps([fkm, taskmap.TaskmapFrom4x4ToPosition()])
+    target = rmp2.TargetAttractor(goal=[0.2, -0.2, 0.5], accel_p_gain=0.3, accel_d_gain=0.6, accel_norm_eps=0.075,
+                                  metric_alpha_length_scale=0.05, min_metric_alpha=0.03, max_metric_scalar=1,
+                                  min_metric_scalar=0.5, proximity_metric_boost_scalar=1.,
+                                  proximity_metric_boost_length_scale=0.02, taskmap=ee, name='attractor')
+    damp = rmp2.JointDamping(accel_d_gain=1, metric_scalar=0.005, inertia=0.3)
+    bias = rmp2.CSpaceBiasing(goal=Cf.CSPACE_BIASING_GOAL, metric_scalar=0.005, position_gain=1, damping_gain=2,
+                              robust_position_term_thresh=0.5, inertia=0.0001)
+    for r in (target, damp, bias):
+        core.add_rmp(r)
+    s0 = core._quick_signature(9)
+    assert core._quick_signature(9) == s0
+    target.goal = np.array([0.5, 0.1, 0.4], np.float32)            # a goal is an input, not part of the program
+    assert core._quick_signature(9) == s0
+    seen = {s0}
+
+    def changed():
+        s = core._quick_signature(9)
+        fresh = s not in seen
+        seen.add(s)
+        return fresh
+    damp.inertia = 0.31
+    assert changed()
+    bias.goal = np.asarray(Cf.CSPACE_BIASING_GOAL, np.float32) + np.float32(0.01)   # CSpaceBiasing's goal IS a constant vector
+    assert changed()
+    fkm.frame = 'panda_hand_joint'
+    assert changed()
+    target.taskmap = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fk, frame='panda_joint7'), taskmap.TaskmapFrom4x4ToPosition()])
+    assert changed()
+    core.remove_rmp_by_name(damp.name)
+    assert changed()
+    core.solve = "pinv"
+    assert changed()
+    assert core._quick_signature(7) not in seen
+
+
 def test_unsupported_chains_raise():
     from riemannian_motion_policies_amd import rmp, taskmap, urdf
     from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
