@@ -525,14 +525,17 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     if (lane < ng) s_goal[g_rr * 16 + g_jj] = gv;
     if (fastq) {
       if (lane < tile) {
+        quarantine(qa, qb);  // (rmp2_device.h: a non-finite joint position moves into the joint's velocity)
         wl[HexLds<N>::kQ + lane] = qa;
         wl[HexLds<N>::kQd + lane] = qb;
       }
     } else {
       for (int i = lane; i < tile; i += kWave) {
         const int rr = i / n_dof, jj = i - rr * n_dof;
-        wl[HexLds<N>::kQ + rr * N + jj] = gq[i];
-        wl[HexLds<N>::kQd + rr * N + jj] = gqd[i];
+        float qv = gq[i], qdv = gqd[i];
+        quarantine(qv, qdv);
+        wl[HexLds<N>::kQ + rr * N + jj] = qv;
+        wl[HexLds<N>::kQd + rr * N + jj] = qdv;
       }
       if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
         const int pad = N - n_dof;
@@ -1087,6 +1090,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         qdi2 = fmaf(ro.dt, acc, qdi2);
         qi2 = fmaf(ro.dt, qdi2, qi2);
       }
+      quarantine(qi2, qdi2);
       *qw = qi2;
       *qdw = qdi2;
     }
@@ -1110,8 +1114,9 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const int count = n_live * n_dof;
     for (int i = lane; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
-      ro.q_out[(size_t)r0 * n_dof + i] = wl[HexLds<N>::kQ + rr * N + jj];
-      ro.qd_out[(size_t)r0 * n_dof + i] = wl[HexLds<N>::kQd + rr * N + jj];
+      const float qdv = wl[HexLds<N>::kQd + rr * N + jj];
+      ro.q_out[(size_t)r0 * n_dof + i] = (qdv != qdv) ? qdv : wl[HexLds<N>::kQ + rr * N + jj];  // (quarantined joints)
+      ro.qd_out[(size_t)r0 * n_dof + i] = qdv;
     }
   }
   if (out.status && live && s == 0) out.status[robot] = status;

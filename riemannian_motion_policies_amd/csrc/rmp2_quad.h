@@ -788,8 +788,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     const float* gqd = qd + (size_t)r0 * n_dof;
     for (int i = lane; i < tile; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
-      lds[QuadLds<N>::kQ + rr * N + jj] = gq[i];
-      lds[QuadLds<N>::kQd + rr * N + jj] = gqd[i];
+      float qv = gq[i], qdv = gqd[i];
+      quarantine(qv, qdv);
+      lds[QuadLds<N>::kQ + rr * N + jj] = qv;
+      lds[QuadLds<N>::kQd + rr * N + jj] = qdv;
     }
     if (n_dof < N) {  // padding dofs of the template read as q = qd = 0
       const int pad = N - n_dof;
@@ -1806,6 +1808,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           qdi = fmaf(ro.dt, acc, qdi);
           qi_ = fmaf(ro.dt, qdi, qi_);
         }
+        quarantine(qi_, qdi);
         qw[i] = qi_;
         qdw[i] = qdi;
       }
@@ -1821,8 +1824,9 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     const int count = n_live * n_dof;
     for (int i = lane_o; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
-      ro.q_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQ + rr * N + jj];
-      ro.qd_out[(size_t)r0 * n_dof + i] = lds[QuadLds<N>::kQd + rr * N + jj];
+      const float qdv = lds[QuadLds<N>::kQd + rr * N + jj];
+      ro.q_out[(size_t)r0 * n_dof + i] = (qdv != qdv) ? qdv : lds[QuadLds<N>::kQ + rr * N + jj];  // (quarantine, rmp2_device.h)
+      ro.qd_out[(size_t)r0 * n_dof + i] = qdv;
     }
   }
   {

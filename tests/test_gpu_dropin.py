@@ -245,6 +245,62 @@ def test_fused_rollout_matches_step_loop(hip_lib, workload, kernel):
             assert (qf[ok] - q0[ok]).abs().max().item() > 1e-2  # the fleet actually moved
 
 
+@pytest.mark.parametrize("kernel", ["hex", "quad"])
+def test_dead_robots_resolve_to_nan_and_leave_their_neighbours_alone(hip_lib, kernel):
+    """A robot whose joint position is NaN or Inf (diverged in a rollout, or fed that way) resolves to NaN for every joint with
+    RMP2_STATUS_NONFINITE -- what the reference's pinv of a NaN matrix gives (rmp.py:153) -- in a step and through a rollout,
+    where its state comes back NaN; every other robot of its wave gets exactly the numbers it gets without the dead ones.
+    (The kernels move the non-finiteness from q_i to qd_i before FK, rmp2_device.h quarantine: the dead robot's range tests
+    then cost what a live robot's cost.)"""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config3()
+    old_env = os.environ.get("RMP2_KERNEL")
+    os.environ["RMP2_KERNEL"] = kernel
+    try:
+        eng = Engine(desc, 0)
+    finally:
+        if old_env is None:
+            del os.environ["RMP2_KERNEL"]
+        else:
+            os.environ["RMP2_KERNEL"] = old_env
+    R = 203
+    rng = np.random.default_rng(21)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += 1.5
+    obs = eng.obstacles(spheres=torch.from_numpy(sph))
+    goal = torch.from_numpy(s["goal"]).cuda()
+    q0, qd0 = torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda()
+    dead = [5, 64, 65, 130, 202]
+    qb = q0.clone()
+    qb[5, 2] = float("nan")
+    qb[64, 0] = float("inf")
+    qb[65, 8] = float("-inf")
+    qb[130, :] = float("nan")
+    qb[202, 6] = float("nan")
+    alive = torch.ones(R, dtype=torch.bool, device="cuda")
+    alive[dead] = False
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    clean = eng.step(q0, qd0, goal, obstacles=obs)
+    got = eng.step(qb, qd0, goal, obstacles=obs, status=st)
+    torch.cuda.synchronize()
+    assert torch.isnan(got[~alive]).all() and ((st[~alive] & 1) == 1).all()
+    assert torch.equal(got[alive], clean[alive]) and ((st[alive] & 1) == 0).all()
+    # through a rollout: the dead robots' state comes back NaN, the others' exactly as without them
+    K, sub, dt = 4, 10, 0.01
+    qc, qdc = q0.clone(), qd0.clone()
+    eng.rollout(qc, qdc, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt)
+    qf, qdf = qb.clone(), qd0.clone()
+    st.zero_()
+    last = eng.rollout(qf, qdf, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt, status=st)
+    torch.cuda.synchronize()
+    assert torch.isnan(qf[~alive]).all() and torch.isnan(qdf[~alive]).all() and torch.isnan(last[~alive]).all()
+    assert ((st[~alive] & 1) == 1).all()
+    assert torch.equal(qf[alive], qc[alive]) and torch.equal(qdf[alive], qdc[alive])
+
+
 def _oracle_rollout(desc, q, qd, goal, K, sub, dt, precision="f32", **obs):
     """The reference's control loop (06_cluttered_environment.py:120-131: RMP at 10 Hz, plant at 100 Hz tracking qdd) with
     the CPU oracle as the controller: K x (qdd = oracle step; `sub` ticks of qd = fma(dt, qdd, qd); q = fma(dt, qd, q)), the
