@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RMP2_ABI_VERSION 2
+#define RMP2_ABI_VERSION 3
 
 #define RMP2_MAX_FRAMES 32  /* frames (= URDF joints) per robot type                    */
 #define RMP2_MAX_DOF 16     /* actuated joints per robot type                            */
@@ -171,6 +171,13 @@ typedef struct rmp2_obstacles {
   const int32_t *csr_offset;               /* device [R+1]                                   */
   const int32_t *csr_index;                /* device [csr_offset[R]]                         */
   const float *dist;                       /* device [R][P], FK_POINT leaves only (else NULL) */
+  const float *link_capsules;              /* device [n_distance_leaves][8] = (a, radius, b, -) in each distance leaf's FRAME
+                                              coordinates (leaf order), or NULL.  SHARED_SPHERES only, at most 256 primitives:
+                                              the control point of a pair is the nearest point of the LINK's capsule to the
+                                              obstacle, formed inside the step -- the fused form of rmp2_closest_points_links +
+                                              EXPLICIT_PAIRS (same value d = |p_link - p_obs| and unit normal; as there, the
+                                              derivative moves the point with the frame origin, taskmap.py:124-129).  Robots
+                                              with at most 9 dofs, AUTO resolve. */
 } rmp2_obstacles;
 
 /* ---- outputs ----------------------------------------------------------------------- */

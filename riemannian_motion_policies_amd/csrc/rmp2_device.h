@@ -47,7 +47,8 @@ struct DevLeaf {
   float va[RMP2_MAX_DOF];
   float vb[RMP2_MAX_DOF];
   int32_t index;  // leaf index in the caller's descriptor (pair_begin is indexed by it)
-  int32_t pad_[3];  // 208 bytes
+  int32_t dist_ordinal;  // FK_DISTANCE leaves: how many distance leaves precede it (row of rmp2_obstacles.link_capsules)
+  int32_t pad_[2];  // 208 bytes
 };
 // the 64-byte head of a leaf / the 32-byte control block of an op, as value types: copying
 // them makes the compiler issue one wide scalar load instead of one dependent s_load per field
@@ -121,6 +122,7 @@ struct ObsArgs {
   const int32_t* __restrict__ csr_index;
   const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
   const float* __restrict__ dist;          // [R][P] distances of the attached-point leaves
+  const float* __restrict__ link_caps;     // [n_distance_leaves][8] link capsules in frame coordinates (table modes), or null
 };
 
 // Nearest point of the segment a-b (capsule axis) to the control point p: the point-vs-capsule case of the

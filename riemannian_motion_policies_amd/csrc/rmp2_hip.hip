@@ -1227,7 +1227,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     return err = "unknown solve_mode", RMP2_ERR_INVALID_ARGUMENT;
 
   // leaves: validate, copy, bucket by task map
-  int nfk = 0, nid = 0;
+  int nfk = 0, nid = 0, n_dist = 0;
   for (int l = 0; l < d.n_leaves; ++l) {
     const rmp2_leaf& s = d.leaves[l];
     DevLeaf& t = P.leaves[l];
@@ -1236,6 +1236,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     t.frame = s.frame;
     t.goal_offset = s.goal_offset;
     t.index = l;
+    t.dist_ordinal = s.taskmap == RMP2_TASKMAP_FK_DISTANCE ? n_dist++ : -1;
     std::memcpy(t.P, s.params, sizeof(t.P));
     std::memcpy(t.va, s.vec_a, sizeof(t.va));
     std::memcpy(t.vb, s.vec_b, sizeof(t.vb));
@@ -1364,7 +1365,7 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //    pseudo-inverse (register-resident Jacobi) and attached-point leaves at any fleet size.
   // hex carries every leaf kind and both resolves (strict: the pseudo-inverse on every robot through its careful path;
   // slower than the lane kernel's register-resident Jacobi, so that path is taken on request / for n_dof > 9 only)
-  const bool hex_ok = h->goal_floats <= 16 && !(h->has_point && rollout);
+  const bool hex_ok = h->goal_floats <= 16 && !(h->has_point && rollout) && !o.link_caps;  // (link geometry: quad mapping only)
   // measured (bench.py, us per step, round 2 kernels; profiles/r02_dispatch_sweep.txt):
   //   cluttered set (config 3)   R:  4096   8192  10240  16384  20480  32768
   //     hex                         19.0   22.2   36.6   42.2   55.4   81.3
@@ -1395,7 +1396,7 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
     return RMP2_OK;
   if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (the quad mapping's resolve is AUTO: never a silent change of semantics)
   // (attached-point leaves: hex up to 20 480 robots, the quad mapping beyond -- round 3; the lane mapping on request)
-  const bool lane = !rollout && (h->kernel_choice == 1 ||
+  const bool lane = !rollout && !o.link_caps && (h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && !h->has_point && R > 32768));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
@@ -1724,6 +1725,16 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
     o.csr_index = obs->csr_index;
     o.dist = obs->dist;
     o.pair_begin = h->d_pair_begin;
+    if (obs->link_capsules) {
+      // link geometry inside the step (quad mapping, attached-record builds): see include/rmp2.h rmp2_obstacles
+      if (o.mode != RMP2_OBS_SHARED_SPHERES || obs->n_spheres > kLdsSpheres)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: SHARED_SPHERES tables of at most 256 primitives "
+                                             "(otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
+      if (h->has_point || h->strict || (h->likely_singular && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: sets without attached-point leaves on robots with at most 9 dofs, "
+                                             "AUTO resolve with an inertia leaf (otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
+      o.link_caps = obs->link_capsules;
+    }
   }
   oa = OutArgs{out->qdd, out->status, out->M, out->f};
   return RMP2_OK;

@@ -456,6 +456,146 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
   }
 }
 
+// ---- link geometry in the table modes -----------------------------------------------------------------------------------
+// The control point of a pair is the nearest point of the LINK's capsule (world axis LA-LB, radius lr) to the obstacle, as
+// PyBullet reports it for the link's collision shape (simulation.py:462-484) -- what rmp2_closest_points_links writes out as
+// p_link / p_obs for the explicit-pair step, formed here per in-range pair instead: x = |X - Y| - lr - r, n = (X - Y) / |X - Y|
+// with X, Y the nearest points of the two axes (the obstacle's axis is a point for a sphere).  The derivative is the explicit
+// form's: the point moves with the frame ORIGIN (V3, A3; taskmap.py:124-129).
+// Range test: the staged records hold every primitive's bounding sphere (centre c = -xyz / 2; w = |c|^2 - slack (r + c0)^2);
+// the link enters as the SEGMENT it is: the nearest point X of the axis to c, then |X - c| <= r + c0 + lr.  Exact for sphere
+// tables, conservative for capsules (their bounding spheres): a pair beyond it is beyond metric_modulation_radius, where the
+// leaf's metric is exactly 0 (rmp2.py:191-195).  (The link's own bounding sphere instead of the segment -- the cheaper test --
+// keeps 2.7x the pairs: (0.5 + 0.2)^3 / 0.5^3 of the volume at the Panda's link lengths.)
+template <bool SKIP, bool CAPS>
+__device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int count, int sub, const float LA[3], const float LB[3],
+                                               float lr, float c0, const float V3[3], const float A3[3], const float* P,
+                                               const float* IP, float S[6], float h[3], const float* caps) {
+  constexpr int W = 4, kTests = 32 / W;
+  const float4* aux = reinterpret_cast<const float4*>(tab);
+  const float* rad = tab + 4 * n_tab;  // (sphere tables; a capsule table's records carry no radii)
+  const float vv = dot3(V3, V3);
+  const float d1[3] = {LB[0] - LA[0], LB[1] - LA[1], LB[2] - LA[2]};
+  const float aa = dot3(d1, d1);
+  const float inv_aa = aa > 0.f ? 1.0f / aa : 0.f;
+  for (int base = 0; base < count; base += 32) {  // wave-uniform (shared table)
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < kTests; ++i) {
+      if (SKIP && base + W * i >= count) continue;
+      const int pos = base + sub + W * i;
+      const bool valid = pos < count;
+      const int sidx = valid ? pos : 0;
+      const float4 a = aux[sidx];
+      const float c[3] = {-0.5f * a.x, -0.5f * a.y, -0.5f * a.z};
+      // r + c0 of the record: kept next to it for spheres, recovered from the record for capsules' bounding spheres
+      float thr;
+      if (CAPS) {
+        const float cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        thr = sqrtf(fmaxf(cc - a.w, 0.f)) * 1.00001f;  // (= sqrt(slack) (r + c0) up to rounding: widened, never under-covers)
+      } else {
+        thr = fmaxf(rad[sidx] + c0, 0.f);
+      }
+      const float w[3] = {c[0] - LA[0], c[1] - LA[1], c[2] - LA[2]};
+      const float sl = fminf(fmaxf(dot3(w, d1) * inv_aa, 0.f), 1.f);
+      const float xc[3] = {fmaf(-sl, d1[0], w[0]), fmaf(-sl, d1[1], w[1]), fmaf(-sl, d1[2], w[2])};  // c - X
+      const float lim = thr + lr;
+      const bool keep = valid && !(dot3(xc, xc) > kCullSlack * lim * lim);
+      m |= keep ? (1u << (W * i)) : 0u;
+    }
+    m <<= sub;
+    m |= dppu<kXor1>(m);
+    m |= dppu<kXor2>(m);
+    uint32_t rem = m;
+    rem = sub > 0 ? (rem & (rem - 1u)) : rem;
+    rem = sub > 1 ? (rem & (rem - 1u)) : rem;
+    rem = sub > 2 ? (rem & (rem - 1u)) : rem;
+    // next pair of this lane; a capsule's record comes from global memory and is fetched one trip ahead of its use
+    auto take = [&](bool& on_, int& sidx_) __attribute__((always_inline)) {
+      on_ = rem != 0u;
+      const int j = on_ ? (__builtin_ffs((int)rem) - 1) : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rem &= rem - 1u;
+      sidx_ = on_ ? base + j : 0;
+    };
+    bool on_n = false;
+    int sidx_n = 0;
+    float4 ca_n = make_float4(0.f, 0.f, 0.f, 0.f), cb_n = ca_n;
+    if (CAPS) {
+      take(on_n, sidx_n);
+      ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
+      cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+    }
+    while (true) {
+      bool on;
+      int sidx;
+      float4 ca, cb;
+      if (CAPS) {
+        on = on_n, sidx = sidx_n, ca = ca_n, cb = cb_n;
+      } else {
+        take(on, sidx);
+      }
+      if (!__any(on)) break;
+      float X[3], Y[3], r;
+      if (CAPS) {
+        take(on_n, sidx_n);
+        ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
+        cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+        // nearest points of the two axes: the clamped solution of the 2 x 2 normal equations (rmp2_device.h segment_segment,
+        // same cases), branch-free, on refined reciprocals
+        const float d2v[3] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
+        const float rr[3] = {LA[0] - ca.x, LA[1] - ca.y, LA[2] - ca.z};
+        const float ee = dot3(d2v, d2v), ff = dot3(d2v, rr), cc = dot3(d1, rr), bb = dot3(d1, d2v);
+        const float inv_e = ee > 0.f ? rcp1(ee) : 0.f;
+        const float den = fmaf(aa, ee, -bb * bb);
+        const float s0 = (den > 0.f && aa > 0.f) ? fminf(fmaxf(fmaf(bb, ff, -cc * ee) * rcp1(den), 0.f), 1.f) : 0.f;
+        const float t0 = fmaf(bb, s0, ff) * inv_e;
+        const float s_lo = fminf(fmaxf(-cc * inv_aa, 0.f), 1.f), s_hi = fminf(fmaxf((bb - cc) * inv_aa, 0.f), 1.f);
+        const float sl = (t0 < 0.f || !(ee > 0.f)) ? s_lo : (t0 > 1.f ? s_hi : s0);
+        const float to = fminf(fmaxf(t0, 0.f), 1.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[c] = fmaf(sl, d1[c], LA[c]);
+        Y[0] = fmaf(to, d2v[0], ca.x), Y[1] = fmaf(to, d2v[1], ca.y), Y[2] = fmaf(to, d2v[2], ca.z);
+        r = ca.w;
+      } else {
+        const float4 a = aux[sidx];
+        r = rad[sidx];
+        Y[0] = -0.5f * a.x, Y[1] = -0.5f * a.y, Y[2] = -0.5f * a.z;  // the centre, exactly
+        const float w[3] = {Y[0] - LA[0], Y[1] - LA[1], Y[2] - LA[2]};
+        const float sl = fminf(fmaxf(dot3(w, d1) * inv_aa, 0.f), 1.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[c] = fmaf(sl, d1[c], LA[c]);
+      }
+      const float diff[3] = {X[0] - Y[0], X[1] - Y[1], X[2] - Y[2]};
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const float inv0 = rsq0(d2);
+      // surface to surface along the axes' common normal.  The explicit form sees the two surface points only:
+      // x = |p_link - p_obs| and n = (p_link - p_obs) / x -- for overlapping capsules the points have crossed, the distance
+      // reads positive and the normal points the other way (taskmap.py:126-129 on PyBullet's points); same here.
+      const float sgap = d2 * inv0 - r - lr;
+      const float d = fabsf(sgap);
+      const float inv = copysignf(inv0, sgap);
+      const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+      const float xdot = dot3(nh, V3);
+      const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+      float acc, met;
+      obstacle_pair(P, IP, d, xdot, acc, met);
+      if (!on) met = 0.f;
+      const float wgt = met * (acc - cd);
+      const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+      S[0] = fmaf(mn[0], nh[0], S[0]);
+      S[1] = fmaf(mn[0], nh[1], S[1]);
+      S[2] = fmaf(mn[0], nh[2], S[2]);
+      S[3] = fmaf(mn[1], nh[1], S[3]);
+      S[4] = fmaf(mn[1], nh[2], S[4]);
+      S[5] = fmaf(mn[2], nh[2], S[5]);
+      h[0] = fmaf(wgt, nh[0], h[0]);
+      h[1] = fmaf(wgt, nh[1], h[1]);
+      h[2] = fmaf(wgt, nh[2], h[2]);
+    }
+  }
+}
+
 // ---- explicit closest-point pairs (the reference's Datamanager layout, data_management.py:8-37), culled ---------------
 // Interface B is the HBM-bound variant of the step (24 B per pair: 6 264 B per robot-step against 120 B with a shared
 // table), so what the lanes do per byte decides whether the loads or the ALUs set the time.  ObstacleAvoidance's metric is
@@ -688,7 +828,10 @@ constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
 // PT: the set carries attached-point leaves ([FK, TaskmapRelative4x4, 4x4 -> position] + CollisionAvoidance, taskmap.py:79-99,
 // rmp.py:264-315): every frame additionally leaves its world rotation, angular velocity and angular bias acceleration in LDS
 // (16 floats per robot and frame behind the other regions).
-constexpr int kPtSlot = 16;
+constexpr int kPtSlot = 16;      // per-frame record of the attached-point builds: rows of the world rotation (9), w (3), alpha (3)
+constexpr int kPtSlotLink = 12;  // link geometry needs the rotation only: 9 + 3 of padding -- with it a wave's LDS stays under
+                                 // 20 KB for the Panda and eight waves share a CU (16-float records: seven, i.e. three rounds
+                                 // instead of two for 65 536 robots)
 template <int N, int SLOTS, int MINW, bool STAGE, bool CAP, bool SYM = false, int OBS = kObsAny, int FLAVOR = kGeneral,
           bool PT = false>
 __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ prog, const QuadHdr& hdr,
@@ -705,7 +848,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   if (LEAN) out.M = nullptr, out.f = nullptr;
 #endif
   constexpr int ROWS = (N + kQuad - 1) / kQuad;  // local rows of the n x n system per lane
-  static_assert(!PT || (MINW < 4 && !CAP && FLAVOR == kGeneral), "attached-point leaves: general flavour, row records in registers");
+  static_assert(!PT || (MINW < 4 && FLAVOR == kGeneral), "attached-point leaves / link geometry: general flavour, row records in registers");
   constexpr bool kIdentFirst = SYM && PLAIN && MINW >= 3 && RMP2_IDENT_FIRST;  // (see "Phase order per wave" below)
   // dynamic LDS: [QuadLds<N>::kFloats floats | frame slots 16 robots x max(n_ops, 1) x 12 floats |
   //               sphere table min(K, 256) x 4 |
@@ -757,6 +900,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   float* const s_goal = reinterpret_cast<float*>(s_lo + kMaxOps);
   // attached-point builds: [16 robots][n_ops][16] = rows of the world rotation (9), w (3), alpha (3), behind everything else
   float* const pt_base = STAGE ? s_goal + 16 * kRobotsPerWave : stage_base;
+  const int pt_slot = (PT && obs.link_caps) ? kPtSlotLink : kPtSlot;  // (wave-uniform)
   const DevOp* const ops = STAGE ? s_ops : prog->ops;
   const DevLeaf* const leaves = STAGE ? s_leaves : prog->leaves;
   const int32_t* const fk_list = STAGE ? s_fk : prog->fk_leaves;
@@ -1230,12 +1374,14 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         fr[6 + sub] = an;
         fr[9 + sub] = z;
         if (PT) {  // row `sub` of the world rotation and component `sub` of w and alpha, for the attached-point leaves
-          float* pr = pt_base + (g * n_ops + k) * kPtSlot;
+          float* pr = pt_base + (g * n_ops + k) * pt_slot;
           pr[3 * sub] = Rn[0];
           pr[3 * sub + 1] = Rn[1];
           pr[3 * sub + 2] = Rn[2];
-          pr[9 + sub] = wn;
-          pr[12 + sub] = aln;
+          if (pt_slot == kPtSlot) {
+            pr[9 + sub] = wn;
+            pr[12 + sub] = aln;
+          }
         }
       }
       if (SLOTS > 0 && c_save >= 0) {
@@ -1420,7 +1566,21 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           h[0] = h[1] = h[2] = 0.f;
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
-          if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
+          if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
+            const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * kPtSlotLink);
+            const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2];
+            const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+            const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
+            const float la[3] = {lc[0], lc[1], lc[2]}, lb[3] = {lc[4], lc[5], lc[6]};
+            float LA[3], LB[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              LA[c] = P3[c] + Rm[3 * c] * la[0] + Rm[3 * c + 1] * la[1] + Rm[3 * c + 2] * la[2];
+              LB[c] = P3[c] + Rm[3 * c] * lb[0] + Rm[3 * c + 1] * lb[1] + Rm[3 * c + 2] * lb[2];
+            }
+            pair_loop_link<(MINW >= 2), CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lc[3], hdr.cull_c0, V3, A3, lh.P, IP, S, h,
+                                             step_table);
+          } else if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds)
 #ifdef RMP2_STAMPS
               pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,

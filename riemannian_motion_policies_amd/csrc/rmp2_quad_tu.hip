@@ -13,7 +13,9 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
                             ? std::min(o.n_spheres, kLdsSpheres) : 0;
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
                                             quad_table_floats(o.capsule, n_sph_lds));
-  const size_t pt_bytes = h->has_point ? sizeof(float) * kPtSlot * kRobotsPerWave * quad_slots(h->n_ops_step) : 0;  // (rotation, w, alpha per frame)
+  const bool with_records = h->has_point || o.link_caps;  // attached-point leaves, link geometry: the builds with rotation records
+  const size_t pt_bytes = with_records ? sizeof(float) * (o.link_caps ? kPtSlotLink : kPtSlot) * kRobotsPerWave * quad_slots(h->n_ops_step)
+                                       : 0;  // (rotation, w, alpha per frame; link geometry: the rotation)
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
   const QuadHdr hdr = make_quad_hdr(h);
@@ -90,7 +92,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
       default: RMP2_QUAD_LAUNCH(MINW, false, false, SYM, RMP2_OBS_NONE, kPlainRollout); break;                          \
     }                                                                                                                   \
   } while (0)
-  const bool lean_rollout = !plain && !out.M && !out.f && !o.capsule && o.mode != RMP2_OBS_EXPLICIT_PAIRS && !latency;
+  const bool lean_rollout = !plain && !out.M && !out.f && !o.capsule && o.mode != RMP2_OBS_EXPLICIT_PAIRS && !latency && !with_records;
   if (lean_rollout) {
     if (minw == 3) minw = 2;  // (the lean rollout exists at two and four waves per SIMD)
     if (minw == 4) {
@@ -101,20 +103,28 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     return;
   }
 #undef RMP2_QUAD_ROLL_SYM
-  if (h->has_point) {
-    // attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance): the general flavour with the extra per-frame records
-    // (27 floats per frame instead of 12: two waves per SIMD at most)
+  if (with_records) {
+    // attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance) and link geometry in the table modes: the general
+    // flavour with the extra per-frame records (27 floats per frame instead of 12: two waves per SIMD at most)
     auto raise = [&](const void* kern) {
       if (bytes > 64 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     };
-#define RMP2_QUAD_PT(MINW, STAGE, SYM)                                                                                  \
+#define RMP2_QUAD_PT(MINW, STAGE, CAP, SYM)                                                                             \
     do {                                                                                                                \
-      raise(reinterpret_cast<const void*>(rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, false, SYM, kObsAny, kGeneral, true>)); \
-      RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, false, SYM, kObsAny, kGeneral, true>), dim3(blocks), \
+      raise(reinterpret_cast<const void*>(rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, kObsAny, kGeneral, true>)); \
+      RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, kObsAny, kGeneral, true>), dim3(blocks), \
                        dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);                          \
     } while (0)
-    if (latency) { if (symk) RMP2_QUAD_PT(1, true, (N == 9)); else RMP2_QUAD_PT(1, true, false); }
-    else { if (symk) RMP2_QUAD_PT(2, false, (N == 9)); else RMP2_QUAD_PT(2, false, false); }
+#define RMP2_QUAD_PT_SYM(MINW, STAGE, CAP)                                                                              \
+    do {                                                                                                                \
+      if (symk) RMP2_QUAD_PT(MINW, STAGE, CAP, (N == 9)); else RMP2_QUAD_PT(MINW, STAGE, CAP, false);                   \
+    } while (0)
+    if (o.capsule) {  // (capsule tables reach here with link geometry only: attached-point leaves take explicit pairs)
+      if (latency) RMP2_QUAD_PT_SYM(1, true, true); else RMP2_QUAD_PT_SYM(2, false, true);
+    } else {
+      if (latency) RMP2_QUAD_PT_SYM(1, true, false); else RMP2_QUAD_PT_SYM(2, false, false);
+    }
+#undef RMP2_QUAD_PT_SYM
 #undef RMP2_QUAD_PT
     return;
   }

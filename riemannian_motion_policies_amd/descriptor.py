@@ -14,7 +14,7 @@ import numpy as np
 
 from .urdf import KinematicTable
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_FRAMES = 32
 MAX_DOF = 16
 MAX_LEAVES = 48
@@ -101,6 +101,7 @@ class Obstacles(C.Structure):
         ("csr_offset", C.c_void_p),
         ("csr_index", C.c_void_p),
         ("dist", C.c_void_p),
+        ("link_capsules", C.c_void_p),
     ]
 
 

@@ -67,10 +67,22 @@ class Engine:
 
     # ------------------------------------------------------------------------------
     def obstacles(self, *, spheres=None, p_link=None, p_obs=None, pair_counts: Optional[Sequence[int]] = None,
-                  csr_offset=None, csr_index=None, dist=None):
-        """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result)."""
+                  csr_offset=None, csr_index=None, dist=None, link_capsules=None):
+        """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result).
+        link_capsules [n_distance_leaves, 8] = (a, radius, b, -) per distance leaf, in its frame's coordinates
+        (urdf.link_capsules), with a shared table `spheres`: the control point of a pair is the nearest point of the link's
+        capsule to the obstacle, formed inside the step (the fused form of closest_points(link_capsules=) + explicit pairs)."""
         o = D.Obstacles()
         keep = []
+        if link_capsules is not None:
+            if spheres is None or csr_offset is not None or p_link is not None:
+                raise ValueError("link_capsules go with a shared table: obstacles(spheres=..., link_capsules=...)")
+            link_capsules = _f32(link_capsules, self.device)
+            n_dist = sum(1 for i in range(self.desc.n_leaves) if self.desc.leaves[i].taskmap == D.TASKMAP_FK_DISTANCE)
+            if tuple(link_capsules.shape) != (n_dist, 8):
+                raise ValueError(f"link_capsules must be [{n_dist}, 8] (one capsule per distance leaf, in leaf order)")
+            o.link_capsules = link_capsules.data_ptr()
+            keep.append(link_capsules)
         if p_link is not None:
             p_link, p_obs = _f32(p_link, self.device), _f32(p_obs, self.device)
             if p_link.shape != p_obs.shape or p_link.dim() != 3 or p_link.shape[2] != 3:

@@ -175,7 +175,7 @@ class RmpCore:
             out[names[eng.desc.leaves[dist_idx[i]].frame]] = (a, b)
         return out
 
-    def _evaluate_device(self, q, qd, spheres):
+    def _evaluate_device(self, q, qd, spheres, link_capsules=None):
         """evaluate() for tensors that already live on the engine's device: nothing goes through the host, the result is a
         device tensor on the caller's stream.  Same gathering rules as below."""
         single = q.dim() == 1
@@ -195,7 +195,8 @@ class RmpCore:
                 sp = spheres if spheres is not None else self.spheres
                 if sp is None:
                     raise ValueError("TaskmapSphereDistance leaves need evaluate(..., spheres=[K,4])")
-                obstacles = eng.obstacles(spheres=as_tensor(sp, dev))
+                obstacles = eng.obstacles(spheres=as_tensor(sp, dev),
+                                          link_capsules=None if link_capsules is None else as_tensor(link_capsules, dev))
             elif not any(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
                 def fleet(a, nd):
                     a = as_tensor(a, dev)
@@ -239,11 +240,11 @@ class RmpCore:
             off += k
         return cache[0], cache[1]
 
-    def evaluate(self, q, qd, spheres=None):
+    def evaluate(self, q, qd, spheres=None, link_capsules=None):
         """q, qd: [n] (one robot, as in the reference) or [R, n].  Returns qdd of the same shape: a QddResult (host array) for
         host inputs, a device tensor -- no host hop anywhere -- when q is a tensor on the engine's device."""
         if isinstance(q, torch.Tensor) and q.is_cuda:
-            return self._evaluate_device(q, qd, spheres)
+            return self._evaluate_device(q, qd, spheres, link_capsules)
         single = np.ndim(q) == 1
         q2 = np.atleast_2d(np.asarray(as_array(q), dtype=np.float32))
         qd2 = np.atleast_2d(np.asarray(as_array(qd), dtype=np.float32))
@@ -270,7 +271,7 @@ class RmpCore:
                 sp = spheres if spheres is not None else self.spheres
                 if sp is None:
                     raise ValueError("TaskmapSphereDistance leaves need evaluate(..., spheres=[K,4])")
-                obstacles = eng.obstacles(spheres=as_array(sp) if not isinstance(sp, torch.Tensor) else sp)
+                obstacles = eng.obstacles(spheres=as_array(sp) if not isinstance(sp, torch.Tensor) else sp, link_capsules=link_capsules)
             elif not any(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
                 def fleet(a, nd):
                     a = np.asarray(as_array(a), np.float32)

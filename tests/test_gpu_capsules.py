@@ -224,3 +224,103 @@ def test_closest_points_with_link_geometry(torch_mod, prim, robot):
     err = np.abs(qdd.cpu().numpy() - ref["qdd64"]).max(axis=1)
     tol = 1e-5 * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
     assert (err[ok] <= tol[ok]).all() and ok.sum() > R // 3, f"worst {err[ok].max():.2e}"
+
+
+@pytest.mark.parametrize("prim", ["spheres", "capsules"])
+@pytest.mark.parametrize("robot,R", [("panda", 97), ("panda", 20000), ("two_joint", 333)])
+def test_link_geometry_fused_into_the_step(torch_mod, prim, robot, R):
+    """rmp2_obstacles.link_capsules: the closest points of every (link capsule, obstacle) pair are formed INSIDE the step (table
+    in LDS, in-range pairs only) instead of being written out by rmp2_closest_points_links and read back as explicit pairs.
+    Same numbers as that two-kernel flow and as the oracle on the fp64 closed-form pairs; small grids (latency build) and
+    fleets (two waves per SIMD), spheres and capsules, through a rollout as well."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf as U
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(123)
+    K = 32 if prim == "spheres" else 12   # (the capsules are half a metre long: a dozen of them is as crowded as the sphere clutter)
+    if robot == "panda":
+        table, desc = Cf.config3()
+        s = Cf.sample_panda_states(rng, R)
+        lc = U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)
+    else:
+        table, desc = Cf.config5_two_joint()
+        s = Cf.sample_two_joint_states(rng, R)
+        lc = U.link_capsules(U.TWO_JOINT_URDF, table, Cf.TWO_JOINT_CONTROL_POINT_FRAMES)
+    tab = Cf.sample_spheres(rng, K) if prim == "spheres" else Cf.sample_capsules(rng, K)
+    lift = np.float32(0.45 if prim == "spheres" else (0.85 if robot == "panda" else 0.35))   # partly above the arms: a mix of in-range and culled pairs, few contacts
+    tab[:, 2] += lift
+    if prim == "capsules":
+        tab[:, 6] += lift
+    eng = Engine(desc, 0)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    tab_t, lc_t = torch.from_numpy(tab).cuda(), torch.from_numpy(lc).cuda()
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    fused = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tab_t, link_capsules=lc_t), status=st)
+    assert "quad" in eng.last_kernel()
+    # the two-kernel flow on the GPU
+    pl, po = eng.closest_points(q, eng.obstacles(spheres=tab_t), link_capsules=lc_t)
+    two = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl, p_obs=po))
+    torch.cuda.synchronize()
+    fused_np, two_np = fused.cpu().numpy(), two.cpu().numpy()
+    # clearance of every pair (surface to surface): parity is asserted for robots clear of contact, as everywhere
+    clr = (torch.linalg.norm(pl - po, dim=-1)).min(dim=1).values.cpu().numpy()
+    ok = clr >= 0.05
+    n_chk = min(R, 512)
+    sub = np.arange(R)[ok][:n_chk]
+    assert len(sub) > n_chk // 4, f"only {len(sub)} robots clear of contact"
+    T = O.forward_kinematics(desc, s["q"][sub], precision="f64")
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    pl_ref, po_ref = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], p_link=pl_ref.astype(np.float32), p_obs=po_ref.astype(np.float32))
+    well = np.linalg.cond(ref["M"]) < 100 if robot == "two_joint" else np.ones(len(sub), bool)
+    mag = np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
+    err = np.abs(fused_np[sub] - ref["qdd64"]).max(axis=1)
+    assert (err[well] <= 3e-5 * mag[well]).all() and well.sum() > len(sub) // 4, f"vs oracle: worst {(err / mag)[well].max():.2e}"
+    magf = np.maximum(1.0, np.abs(two_np).max(axis=1))
+    okf = ok & np.isfinite(two_np).all(axis=1)
+    if robot == "two_joint":
+        okf[sub[~well]] = False
+        okf[np.setdiff1d(np.arange(R), sub)] = False
+    errf = np.abs(fused_np - two_np).max(axis=1)
+    assert (errf[okf] <= 5e-5 * magf[okf]).all(), f"vs stage + explicit pairs: worst {(errf / magf)[okf].max():.2e}"
+    assert ((st.cpu().numpy()[okf] & 1) == 0).all()
+    # the control points differ from the frame origins: the plain table mode gives other numbers
+    plain = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tab_t)).cpu().numpy()
+    assert np.abs(plain - fused_np)[okf].max() > 1e-3
+    # through the fused rollout (general flavour with the rotation records)
+    if R < 1000:
+        qa, qda = q.clone(), qd.clone()
+        for _ in range(3):
+            a = eng.step(qa, qda, goal, obstacles=eng.obstacles(spheres=tab_t, link_capsules=lc_t))
+            for _ in range(5):
+                qda = qda + 0.01 * a
+                qa = qa + 0.01 * qda
+        qb, qdb = q.clone(), qd.clone()
+        eng.rollout(qb, qdb, goal, obstacles=eng.obstacles(spheres=tab_t, link_capsules=lc_t), n_control_steps=3, substeps=5, dt=0.01)
+        torch.cuda.synchronize()
+        fin = torch.isfinite(qa).all(dim=1) & torch.isfinite(qb).all(dim=1) & torch.from_numpy(okf).cuda()
+        assert ((qa - qb).abs().max(dim=1).values[fin] < 1e-4).all()
+
+
+def test_link_geometry_argument_errors(torch_mod):
+    torch = torch_mod
+    from riemannian_motion_policies_amd import configs as Cf, urdf as U
+    from riemannian_motion_policies_amd import _native
+    from riemannian_motion_policies_amd.engine import Engine
+    table, desc = Cf.config3()
+    eng = Engine(desc, 0)
+    rng = np.random.default_rng(1)
+    s = Cf.sample_panda_states(rng, 8)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    lc = torch.from_numpy(U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)).cuda()
+    with pytest.raises(ValueError):
+        eng.obstacles(spheres=torch.zeros(4, 4), link_capsules=lc[:3])            # one capsule per distance leaf
+    with pytest.raises(ValueError):
+        eng.obstacles(p_link=torch.zeros(8, 8, 3), p_obs=torch.zeros(8, 8, 3), link_capsules=lc)
+    big = torch.from_numpy(Cf.sample_spheres(rng, 300)).cuda()                      # beyond the LDS-resident table
+    with pytest.raises(_native.Rmp2Error, match="link_capsules"):
+        eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=big, link_capsules=lc))
+    _, dpinv = Cf.config3("pinv")
+    with pytest.raises(_native.Rmp2Error, match="link_capsules"):
+        Engine(dpinv, 0).step(q, qd, goal, obstacles=Engine(dpinv, 0).obstacles(spheres=big[:8], link_capsules=lc))

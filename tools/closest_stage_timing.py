@@ -47,5 +47,9 @@ for prim, tab_np in (("spheres", Cf.sample_spheres(np.random.default_rng(7), Cf.
         out = torch.empty_like(q)
         launch, _ = eng.bind(q, qd, goal, obstacles=obst, out=out)
         us_step = timed(launch)
+        if caps is not None:   # the same pairs formed inside the step (rmp2_obstacles.link_capsules)
+            launch_f, _ = eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(tab_np).to(dev), link_capsules=caps), out=out)
+            us_f = timed(launch_f)
+            print(f"R={R} {prim:8s} link capsules, fused into the step: {us_f:7.1f} us = {R / us_f * 1e-3:6.3f} G robot steps/s   ({eng.last_kernel()})")
         print(f"R={R} {prim:8s} {name:14s}: stage {us:8.1f} us ({out_bytes / us / 1e6:6.2f} TB/s of pair arrays written)   "
               f"explicit-pair step {us_step:7.1f} us   stage + step {us + us_step:8.1f} us = {R / (us + us_step) * 1e-3:6.3f} G robot steps/s")
