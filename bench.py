@@ -49,6 +49,10 @@ WORKLOADS = {
     "config3c": dict(robots=65536, bytes=120, flops=66.0e3,
                      name="Franka Panda cluttered with CAPSULE obstacles (the reference's cylinders, simulation.py:495-500, as "
                           "capsules): 8 control points x 32 shared capsules, 65536 robots/GPU"),
+    "config3l": dict(robots=65536, bytes=120, flops=66.0e3,
+                     name="Franka Panda cluttered with LINK geometry: the control point of each of the 8 x 32 pairs is the nearest "
+                          "point of the link's capsule to the sphere (PyBullet's closest points on the link shape, "
+                          "simulation.py:462-484), formed inside the step (rmp2_obstacles.link_capsules), 65536 robots/GPU"),
     "config3b": dict(robots=65536, bytes=6264, flops=66.0e3, bound="hbm",
                      name="Franka Panda cluttered, interface B: 256 explicit closest-point pairs per robot (p_link, p_obs "
                           "[R, 256, 3], the reference's Datamanager layout), 65536 robots/GPU (BASELINE.md section 3 row 3-B)"),
@@ -381,6 +385,15 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
     spheres_np = Cf.sample_spheres(np.random.default_rng(7), K)   # same table on every rank
     if workload == "config3c":
         spheres_np = Cf.sample_capsules(np.random.default_rng(7), K)
+    if workload == "config3l":
+        from riemannian_motion_policies_amd import urdf as U
+        lc = U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)
+        tbl_t, lc_t = torch.from_numpy(spheres_np).to(dev), torch.from_numpy(lc).to(dev)
+        launch, _ = eng.bind(q, qd, goal, obstacles=eng.obstacles(spheres=tbl_t, link_capsules=lc_t), out=out)
+        # for the result check: the same pairs as explicit arrays (closest-point stage), which the oracle reads
+        p_link, p_obs = eng.closest_points(q[:256], eng.obstacles(spheres=tbl_t), link_capsules=lc_t)
+        keep += [p_link, p_obs]
+        return launch, eng, desc, table, s, spheres_np, keep
     if workload in ("config3", "config3c"):
         obstacles = eng.obstacles(spheres=torch.from_numpy(spheres_np).to(dev))
         launch, _ = eng.bind(q, qd, goal, obstacles=obstacles, out=out)
@@ -623,12 +636,12 @@ def worker(args) -> int:
     desc = table = s = None
     bound = "valu"
 
-    if workload in ("config2", "config3", "config3b", "config3c", "config4"):
+    if workload in ("config2", "config3", "config3b", "config3c", "config3l", "config4"):
         one_step, eng, desc, table, s, spheres_np, keep = build_config34(workload, args, dev, local_rank, rank, world, R)
         kern = timer.run(one_step, args.steps, args.warmup)
         # result check, outside the timed region: the buffers the timed steps wrote, against the oracle
         line_extra["result_check"] = check_against_oracle(desc, s, spheres_np, keep[3], what=workload,
-                                                          pairs=(keep[4], keep[5]) if workload == "config3b" else None)
+                                                          pairs=(keep[4], keep[5]) if workload in ("config3b", "config3l") else None)
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
         kernel_name = eng.last_kernel() + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)"

@@ -21,8 +21,9 @@ def _import_compat():
     return rmp, rmp2, taskmap, kinematics, data_management
 
 
-def _experiment06_core(mods):
-    """The policy set of experiments/franka_panda/06_cluttered_environment.py:55-118, built with the reference's names."""
+def _experiment06_core(mods, sphere_table=False):
+    """The policy set of experiments/franka_panda/06_cluttered_environment.py:55-118, built with the reference's names.
+    sphere_table: the distance leaves take the array-backed interface (TaskmapSphereDistance: pairs formed in the kernel)."""
     rmp, rmp2, taskmap, kinematics, data_management = mods
     from riemannian_motion_policies_amd import configs as Cf, urdf
     fkine = kinematics.UrdfForwardKinematic(urdf_filepath=urdf.PANDA_URDF, order=urdf.PANDA_ORDER)
@@ -40,11 +41,10 @@ def _experiment06_core(mods):
     core.add_rmp(rmp2.CSpaceBiasing(goal=Cf.CSPACE_BIASING_GOAL, metric_scalar=0.005, position_gain=1, damping_gain=2,
                                     robust_position_term_thresh=0.5, inertia=0.0001))
     for frame in Cf.CONTROL_POINT_FRAMES:
-        tm = taskmap.chain_taskmaps([
-            taskmap.TaskmapByForwardKinematic(fkine, frame),
-            taskmap.TaskmapJointFrame4x4ToDistance(
-                pos_on_link_in_base_frame=data_manager[frame]['pos_on_link_in_base_frame'],
-                pos_on_obstacle_in_base_frame=data_manager[frame]['pos_on_obstacle_in_base_frame'])])
+        last = taskmap.TaskmapSphereDistance() if sphere_table else taskmap.TaskmapJointFrame4x4ToDistance(
+            pos_on_link_in_base_frame=data_manager[frame]['pos_on_link_in_base_frame'],
+            pos_on_obstacle_in_base_frame=data_manager[frame]['pos_on_obstacle_in_base_frame'])
+        tm = taskmap.chain_taskmaps([taskmap.TaskmapByForwardKinematic(fkine, frame), last])
         core.add_rmp(rmp2.ObstacleAvoidance(margin=0., damping_gain=50, damping_std_dev=0.04, damping_robustness_eps=0.01,
                                             damping_velocity_gate_length_scale=0.01, repulsion_gain=800,
                                             repulsion_std_dev=0.01, metric_modulation_radius=0.5, metric_scalar=1,
@@ -135,6 +135,15 @@ def test_experiment06_loop_stays_on_the_device(golden_dir, hip_lib):
     ref = O.step(d3, g["q"], g["qd"], g["goal"], p_link=pl_ref.astype(np.float32), p_obs=po_ref.astype(np.float32))["qdd64"]
     err = np.abs(qdd.cpu().numpy() - ref).max(axis=1)
     assert (err <= 2e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))).all(), err.max()
+    # (iv) the same set on the array-backed interface: the link-capsule pairs are formed inside the step, no holders at all
+    _, _, core_a, target_a, _ = _experiment06_core(mods, sphere_table=True)
+    target_a.goal = torch.from_numpy(g["goal"]).to(dev)
+    fused = core_a.evaluate(q, qd, spheres=torch.from_numpy(tab).to(dev), link_capsules=lc)
+    assert fused.is_cuda
+    err = np.abs(fused.cpu().numpy() - ref).max(axis=1)
+    assert (err <= 3e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))).all(), err.max()
+    host = core_a.evaluate(g["q"], g["qd"], spheres=tab, link_capsules=lc)          # host arrays in, QddResult out
+    assert np.abs(host.numpy() - fused.cpu().numpy()).max() < 1e-6
 
 
 def test_two_joint_script_and_fleet_evaluate(golden_dir, hip_lib):

@@ -9,6 +9,7 @@ cp $S/bench_config3_pinv.json $O/r03_bench_config3_pinv.json
 cp $S/bench_config2.json $O/r03_bench_config2.json
 cp $S/bench_config3b.json $O/r03_bench_config3b_explicit_pairs.json
 cp $S/bench_config3c.json $O/r03_bench_config3c_capsules.json
+cp $S/bench_config3l.json $O/r03_bench_config3l_link_geometry.json
 cp $S/bench_config4.json $O/r03_bench_config4_world1.json
 cp $S/bench_config4_torch.json $O/r03_bench_config4_world1_torch_exchange.json
 cp $S/bench_config5.json $O/r03_bench_config5_world1.json
@@ -28,4 +29,8 @@ cp $S/rollout.txt $O/r03_rollout.txt
 cp $S/exchange_timing.txt $O/r03_exchange_timing.txt
 cp $S/pcie_inclusive.txt $O/r03_pcie_inclusive.txt
 cp $S/flag_tail.txt $O/r03_flag_tail.txt
+# (these three keep the hand-written header lines of the tracked file: "# ..." lines at its top)
+for f in closest_stage rollout_diag dropin_latency; do
+  { grep '^#' $O/r03_$f.txt || true; grep -v 'amdgpu.ids' $S/$f.txt; } > $O/r03_$f.txt.new && mv $O/r03_$f.txt.new $O/r03_$f.txt
+done
 echo copied

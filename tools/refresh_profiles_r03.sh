@@ -14,6 +14,7 @@ python bench.py --solve pinv --no-cpu-baseline --no-secondary > $O/bench_config3
 python bench.py --workload config2 --no-cpu-baseline > $O/bench_config2.json 2>/dev/null
 python bench.py --workload config3b --no-cpu-baseline > $O/bench_config3b.json 2>/dev/null
 python bench.py --workload config3c --no-cpu-baseline --no-secondary > $O/bench_config3c.json 2>/dev/null
+python bench.py --workload config3l --no-cpu-baseline --no-secondary > $O/bench_config3l.json 2>$O/bench_config3l.err
 python bench.py --workload config4 --no-cpu-baseline --no-secondary > $O/bench_config4.json 2>$O/bench_config4.err
 python bench.py --workload config4 --exchange torch --no-cpu-baseline --no-secondary > $O/bench_config4_torch.json 2>/dev/null
 python bench.py --workload config5 --no-cpu-baseline > $O/bench_config5.json 2>/dev/null
@@ -44,6 +45,9 @@ python tools/calibrate_costs.py > $O/cost_calibration.json 2>/dev/null
 python tools/fence_cost.py > $O/exchange_timing.txt 2>/dev/null
 (python tools/pcie_inclusive.py config2 4096; python tools/pcie_inclusive.py config3 65536) > $O/pcie_inclusive.txt 2>/dev/null
 python tools/flag_tail.py > $O/flag_tail.txt 2>/dev/null
+python tools/closest_stage_timing.py 65536 50 > $O/closest_stage.txt 2>/dev/null
+python tools/rollout_diag.py 65536 > $O/rollout_diag.txt 2>/dev/null
+(python tools/dropin_latency.py 7 300; python tools/dropin_latency.py 32 300) > $O/dropin_latency.txt 2>/dev/null
 rm -rf $O/kt*/*/*.db $O/f3 $O/w3 $O/f3b $O/w3b $O/f2 $O/w2 $O/sq1 $O/sq2
 # the contract line once more, now that the counter files of THESE kernels exist (the line then carries traffic + executed)
 cp $O/traffic_config2.json $O/traffic_config3.json $O/traffic_config3b.json $O/executed_config3.json profiles/
