@@ -227,7 +227,7 @@ def test_closest_points_with_link_geometry(torch_mod, prim, robot):
 
 
 @pytest.mark.parametrize("prim", ["spheres", "capsules"])
-@pytest.mark.parametrize("robot,R", [("panda", 97), ("panda", 20000), ("two_joint", 333)])
+@pytest.mark.parametrize("robot,R", [("panda", 97), ("panda", 65536), ("two_joint", 333), ("two_joint", 40000)])
 def test_link_geometry_fused_into_the_step(torch_mod, prim, robot, R):
     """rmp2_obstacles.link_capsules: the closest points of every (link capsule, obstacle) pair are formed INSIDE the step (table
     in LDS, in-range pairs only) instead of being written out by rmp2_closest_points_links and read back as explicit pairs.
