@@ -416,10 +416,17 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         # loop below costs ~50 us of host time per step -- more than the step kernel takes)
         from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
         if not isinstance(exch, NativeObstacleExchange):
+            err = None
             try:
                 exch = NativeObstacleExchange(K // world, dev, depth=args.exchange_depth)
             except Exception as e:   # (RCCL could not be bound / the communicator not built: the torch-driven exchange still works)
-                print(f"bench.py: native exchange unavailable on rank {rank} ({e!r}); falling back to --exchange torch", file=sys.stderr)
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+            if world > 1:   # every rank takes the same exchange: one rank falling back alone would leave the others in a collective
+                import torch.distributed as dist
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                print(f"bench.py: native exchange unavailable (rank {rank}: {err!r}); every rank falls back to --exchange torch", file=sys.stderr)
                 args.exchange = "torch"
                 return build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=seed_rank, exch=None)
         while exch.pending < exch.depth:   # (a reused exchange -- the emulation -- still holds the previous user's gathers)
