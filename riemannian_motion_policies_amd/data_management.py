@@ -21,17 +21,35 @@ def _is_tensor(v):
 class ArrayVar:
     """Mutable array holder with tf.Variable-like assign().  The value is a host array or, when the device stages fill it
     (RmpCore.update_distances / Datamanager.update_device), a torch tensor that stays where it is: numpy() copies it to the
-    host, as_tensor() hands it to the engine without a host hop."""
+    host, as_tensor() hands it to the engine without a host hop.  assign_lazy(fn) defers the value to its first read (the
+    device stage derives three of the five Datamanager fields from the other two; most policy sets read none of them)."""
 
     def __init__(self, value):
         self.assign(value)
 
     def assign(self, value):
-        self.value = value.detach() if _is_tensor(value) else np.asarray(value, dtype=np.float32)
+        self._thunk = None
+        self._value = value.detach() if _is_tensor(value) else np.asarray(value, dtype=np.float32)
         return self
 
+    def assign_lazy(self, fn):
+        self._thunk, self._value = fn, None
+        return self
+
+    @property
+    def value(self):
+        if self._thunk is not None:
+            fn, self._thunk = self._thunk, None
+            self.assign(fn())
+        return self._value
+
+    @value.setter
+    def value(self, v):
+        self.assign(v)
+
     def numpy(self):
-        return self.value.cpu().numpy() if _is_tensor(self.value) else self.value
+        v = self.value
+        return v.cpu().numpy() if _is_tensor(v) else v
 
     def __array__(self, dtype=None, copy=None):
         v = self.numpy()
@@ -108,24 +126,33 @@ class Datamanager:
         eng = core.engine_for(q)
         qt = as_tensor(q, eng.device)
         single = qt.dim() == 1
-        T = eng.forward_kinematics(qt[None] if single else qt)            # [R, F, 4, 4] on the device
-        # the stage's whole output at once (the per-frame holders are views of it): a handful of launches, not five per frame
+        # distance, normal_vec and relative_position follow from the stage's output: derived on their first read, for all
+        # frames at once (the exp-06 set reads none of them; at fleet size each is a pass over a 200 MB array)
         pl_all, po_all = core._pairs_cache[0], core._pairs_cache[1]      # [R, L * K, 3]
         frames = list(pairs)
         L = len(frames)
         K = pl_all.shape[1] // L
-        diff = pl_all - po_all
-        dist = torch.linalg.norm(diff, dim=-1)
-        nvec = diff / dist.clamp_min(1e-12).unsqueeze(-1)
-        idx = torch.as_tensor([self.fkine.table.frame_index(f) for f in frames], device=eng.device)
-        Tf = T.index_select(1, idx)                                        # [R, L, 4, 4]
-        rel = torch.einsum("rlbk,rlkj->rlbj", pl_all.view(-1, L, K, 3) - Tf[:, :, None, :3, 3], Tf[:, :, :3, :3])
+        table = self.fkine.table
+        memo = {}
+        q_then = (qt[None] if single else qt).clone()   # (the caller may advance q in place before a derived field is read)
+
+        def derived():
+            if not memo:
+                T = eng.forward_kinematics(q_then)                                 # [R, F, 4, 4] on the device
+                diff = pl_all - po_all
+                dist = torch.linalg.norm(diff, dim=-1)
+                memo["dist"] = dist
+                memo["nvec"] = diff / dist.clamp_min(1e-12).unsqueeze(-1)
+                idx = torch.as_tensor([table.frame_index(f) for f in frames], device=eng.device)
+                Tf = T.index_select(1, idx)                                        # [R, L, 4, 4]
+                memo["rel"] = torch.einsum("rlbk,rlkj->rlbj", pl_all.view(-1, L, K, 3) - Tf[:, :, None, :3, 3], Tf[:, :, :3, :3])
+            return memo
         for i, frame in enumerate(frames):
             st = self.state[frame]
             pl, po = pairs[frame]
             st["pos_on_link_in_base_frame"].assign(pl)      # the same tensors when the leaves hold this manager's holders
             st["pos_on_obstacle_in_base_frame"].assign(po)
             sl = slice(i * K, (i + 1) * K)
-            st["distance"].assign(dist[0, sl] if single else dist[:, sl])
-            st["normal_vec"].assign(nvec[0, sl] if single else nvec[:, sl])
-            st["relative_position"].assign(rel[0, i] if single else rel[:, i])
+            st["distance"].assign_lazy(lambda sl=sl: derived()["dist"][0, sl] if single else derived()["dist"][:, sl])
+            st["normal_vec"].assign_lazy(lambda sl=sl: derived()["nvec"][0, sl] if single else derived()["nvec"][:, sl])
+            st["relative_position"].assign_lazy(lambda i=i: derived()["rel"][0, i] if single else derived()["rel"][:, i])

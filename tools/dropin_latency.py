@@ -103,3 +103,42 @@ print(f"experiment-06 set, R = 1, {len(Cf.CONTROL_POINT_FRAMES)} frames x {K} ob
 print(f"  host tuples : Datamanager.update + evaluate + .numpy()   {us_host:8.1f} us per control step = {1e6 / us_host:7.0f} steps/s   (evaluate alone {us_host_eval:7.1f} us)")
 print(f"  device      : update_device + evaluate + .cpu()          {us_dev:8.1f} us per control step = {1e6 / us_dev:7.0f} steps/s   (evaluate alone {us_dev_eval:7.1f} us)")
 print(f"  max |qdd_device - qdd_host| = {np.abs(got - ref).max():.2e}")
+
+# ---- the same loop body for a FLEET, device-resident (GPU time per control step, CUDA events) ----
+Rf = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+sf = Cf.sample_panda_states(np.random.default_rng(4), Rf)
+qf, qdf = torch.from_numpy(sf["q"]).to(dev), torch.from_numpy(sf["qd"]).to(dev)
+target.goal = torch.from_numpy(sf["goal"]).to(dev)
+lc = torch.from_numpy(urdf.link_capsules(urdf.PANDA_URDF, fkine.table, Cf.CONTROL_POINT_FRAMES)).to(dev)
+
+
+def fleet_loop(body, n=20):
+    for _ in range(3):
+        body()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        body()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def fleet_body():
+    dm.update_device(core, qf, spt, link_capsules=lc)
+    return core.evaluate(qf, qdf)
+
+
+def fleet_body_all_fields():
+    dm.update_device(core, qf, spt, link_capsules=lc)
+    out = core.evaluate(qf, qdf)
+    for fr in Cf.CONTROL_POINT_FRAMES:
+        dm[fr]["distance"].value, dm[fr]["normal_vec"].value, dm[fr]["relative_position"].value
+    return out
+
+
+us_f = fleet_loop(fleet_body)
+us_fa = fleet_loop(fleet_body_all_fields)
+print(f"fleet of {Rf} robots, device-resident, link capsules, {K} obstacles: update_device + evaluate {us_f:8.1f} us per control step "
+      f"= {Rf / us_f * 1e-3:6.3f} G robot steps/s;  with the three derived Datamanager fields read every step {us_fa:8.1f} us")

@@ -47,7 +47,7 @@ python tools/fence_cost.py > $O/exchange_timing.txt 2>/dev/null
 python tools/flag_tail.py > $O/flag_tail.txt 2>/dev/null
 python tools/closest_stage_timing.py 65536 50 > $O/closest_stage.txt 2>/dev/null
 python tools/rollout_diag.py 65536 > $O/rollout_diag.txt 2>/dev/null
-(python tools/dropin_latency.py 7 300; python tools/dropin_latency.py 32 300) > $O/dropin_latency.txt 2>/dev/null
+(python tools/dropin_latency.py 7 300 65536; python tools/dropin_latency.py 32 300 65536) > $O/dropin_latency.txt 2>/dev/null
 rm -rf $O/kt*/*/*.db $O/f3 $O/w3 $O/f3b $O/w3b $O/f2 $O/w2 $O/sq1 $O/sq2
 # the contract line once more, now that the counter files of THESE kernels exist (the line then carries traffic + executed)
 cp $O/traffic_config2.json $O/traffic_config3.json $O/traffic_config3b.json $O/executed_config3.json profiles/
