@@ -29,18 +29,26 @@ class ArrayVar:
 
     def assign(self, value):
         self._thunk = None
+        self._owner = None
         self._value = value.detach() if _is_tensor(value) else np.asarray(value, dtype=np.float32)
         return self
 
-    def assign_lazy(self, fn):
-        self._thunk, self._value = fn, None
+    def assign_lazy(self, fn, owner=None):
+        """The value is fn() at its first read.  `owner`: who will produce it (RmpCore's closest-point stage marks the holders
+        it feeds, and steps fused -- without ever forming the arrays -- while every holder still carries its mark)."""
+        self._thunk, self._value, self._owner = fn, None, owner
         return self
+
+    @property
+    def owner(self):
+        return self._owner
 
     @property
     def value(self):
         if self._thunk is not None:
-            fn, self._thunk = self._thunk, None
+            fn, owner = self._thunk, self._owner
             self.assign(fn())
+            self._owner = owner
         return self._value
 
     @value.setter
@@ -122,23 +130,20 @@ class Datamanager:
         q: [R, n] tensor on the core's device; primitives: [K,4] spheres or [K,8] capsules; link_capsules: urdf.link_capsules(...)
         rows in the order of the core's distance leaves, or None for the frame origins as control points."""
         import torch
-        pairs = core.update_distances(q, primitives, link_capsules=link_capsules)
-        eng = core.engine_for(q)
-        qt = as_tensor(q, eng.device)
-        single = qt.dim() == 1
-        # distance, normal_vec and relative_position follow from the stage's output: derived on their first read, for all
-        # frames at once (the exp-06 set reads none of them; at fleet size each is a pass over a 200 MB array)
-        pl_all, po_all = core._pairs_cache[0], core._pairs_cache[1]      # [R, L * K, 3]
-        frames = list(pairs)
-        L = len(frames)
-        K = pl_all.shape[1] // L
+        pairs = core.update_distances(q, primitives, link_capsules=link_capsules)   # (lazy: nothing has run yet)
+        src = pairs.source
+        eng, single = src.eng, src.single
+        frames = pairs.frames
+        L, K = len(frames), src.K
         table = self.fkine.table
         memo = {}
-        q_then = (qt[None] if single else qt).clone()   # (the caller may advance q in place before a derived field is read)
 
+        # distance, normal_vec and relative_position follow from the stage's output: derived on their first read, for all
+        # frames at once (the exp-06 set reads none of them; at fleet size each is a pass over a 200 MB array)
         def derived():
             if not memo:
-                T = eng.forward_kinematics(q_then)                                 # [R, F, 4, 4] on the device
+                pl_all, po_all = src.arrays()                                      # [R, L * K, 3]
+                T = eng.forward_kinematics(src.q)                                  # [R, F, 4, 4] on the device
                 diff = pl_all - po_all
                 dist = torch.linalg.norm(diff, dim=-1)
                 memo["dist"] = dist
@@ -149,9 +154,9 @@ class Datamanager:
             return memo
         for i, frame in enumerate(frames):
             st = self.state[frame]
-            pl, po = pairs[frame]
-            st["pos_on_link_in_base_frame"].assign(pl)      # the same tensors when the leaves hold this manager's holders
-            st["pos_on_obstacle_in_base_frame"].assign(po)
+            # (the same holders, already marked, when the core's leaves were built on this manager's state)
+            st["pos_on_link_in_base_frame"].assign_lazy(lambda i=i: src.view(i, 0), owner=src)
+            st["pos_on_obstacle_in_base_frame"].assign_lazy(lambda i=i: src.view(i, 1), owner=src)
             sl = slice(i * K, (i + 1) * K)
             st["distance"].assign_lazy(lambda sl=sl: derived()["dist"][0, sl] if single else derived()["dist"][:, sl])
             st["normal_vec"].assign_lazy(lambda sl=sl: derived()["nvec"][0, sl] if single else derived()["nvec"][:, sl])

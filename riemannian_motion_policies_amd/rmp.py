@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import descriptor as D
+from ._native import Rmp2Error
 from .data_management import ArrayVar, as_array, as_tensor
 from .rmp2 import RiemannianMotionPolicy
 from .taskmap import IdentityTaskmap, TaskmapSphereDistance, classify
@@ -48,6 +49,67 @@ def _null_table(n_dof: int) -> KinematicTable:
                           axis=z((0, 3), np.float32), T_const=z((0, 4, 4), np.float32), has_collision=z(0, bool),
                           order=[f"q{i}" for i in range(n_dof)], link_names=[], limits_lower=z(0, np.float32),
                           limits_upper=z(0, np.float32))
+
+
+class _StageSource:
+    """One call of RmpCore.update_distances: the inputs of the closest-point stage (snapshots: the caller may advance q or move
+    the obstacles in place afterwards) and, once somebody asks for them, its output arrays."""
+
+    def __init__(self, core, eng, q, single, prim, lc, n_leaves):
+        self.core, self.eng, self.single, self.n_leaves = core, eng, single, n_leaves
+        self._q_ptr, self._q_version, self._q_shape = q.data_ptr(), q._version, tuple(q.shape)
+        self.q = (q[None] if single else q).clone()
+        self.prim = prim.clone()
+        self.lc = None if lc is None else lc.clone()
+        self.K = int(prim.shape[0])
+        self._arrays = None
+        self._zeros = None
+        self.fusable = True    # (cleared when the engine refuses the fused form: its limits are the library's to state)
+
+    def same_q(self, q) -> bool:
+        return q.data_ptr() == self._q_ptr and q._version == self._q_version and tuple(q.shape) == self._q_shape
+
+    def link_capsules_or_origins(self):
+        if self.lc is not None:
+            return self.lc
+        if self._zeros is None:   # a capsule of zero length and radius at the frame origin IS the frame origin
+            self._zeros = torch.zeros((self.n_leaves, 8), dtype=torch.float32, device=self.eng.device)
+        return self._zeros
+
+    def arrays(self):
+        if self._arrays is None:
+            table = self.eng.obstacles(spheres=self.prim)
+            pl, po = self.eng.closest_points(self.q, table, link_capsules=self.lc)
+            self._arrays = (pl, po)
+            self.core._pairs_cache = (pl, po, [self.K] * self.n_leaves)
+        return self._arrays
+
+    def view(self, i, which):
+        a = self.arrays()[which][:, i * self.K:(i + 1) * self.K]
+        return a[0] if self.single else a
+
+
+class _LazyPairs:
+    """{frame name: (p_link, p_obs)} of one update_distances call; reading an entry runs the stage."""
+
+    def __init__(self, source, frames):
+        self.source, self.frames = source, list(frames)
+
+    def __getitem__(self, frame):
+        i = self.frames.index(frame)
+        return self.source.view(i, 0), self.source.view(i, 1)
+
+    def __iter__(self):
+        return iter(self.frames)
+
+    def __len__(self):
+        return len(self.frames)
+
+    def keys(self):
+        return list(self.frames)
+
+    def items(self):
+        return [(f, self[f]) for f in self.frames]
 
 
 class RmpCore:
@@ -142,12 +204,14 @@ class RmpCore:
         """The closest-point preprocessing stage on the device (simulation.py:462-484 calculate_distances followed by
         data_management.py:16-31 update): for every TaskmapJointFrame4x4ToDistance leaf and every obstacle primitive
         ([K,4] spheres or [K,8] capsules) the nearest points of the link (its capsule from `link_capsules`, rows in leaf order;
-        None: the frame origin) and the obstacle, written into the leaves' holders as device tensors [R,K,3] ([K,3] for one
-        robot) that the next evaluate(q, ...) reads in place.  Returns {frame name: (p_link, p_obs)}."""
+        None: the frame origin) and the obstacle, as device tensors [R,K,3] ([K,3] for one robot) in the leaves' holders.
+        LAZY: the arrays are formed when somebody reads a holder.  An evaluate(q, ...) on the same, unmodified q whose distance
+        leaves still hold what this call gave them never forms them: it hands the primitives and the link capsules to the step,
+        which forms the in-range pairs itself (rmp2_obstacles.link_capsules; same values, explicit-pair semantics).
+        Returns a mapping {frame name: (p_link, p_obs)} (reading an entry runs the stage); .frames lists the names."""
         single = q.dim() == 1 if isinstance(q, torch.Tensor) else np.ndim(q) == 1
         eng = self.engine_for(q)
         qt = as_tensor(q, eng.device)
-        qt = qt[None] if single else qt
         leaves = [(rmp, last) for rmp, kind, last in self._pair_leaves() if kind == D.TASKMAP_FK_DISTANCE
                   and not isinstance(last, TaskmapSphereDistance)]
         if not leaves:
@@ -157,23 +221,36 @@ class RmpCore:
             raise NotImplementedError("mixing explicit-pair and sphere distance task maps in one core")
         if len(dist_idx) != len(eng._dist_leaves):
             raise NotImplementedError("update_distances: attached-point leaves (TaskmapRelative4x4) carry their own pair data")
-        table = eng.obstacles(spheres=as_tensor(primitives, eng.device))
-        K = int(table.n_spheres)
-        pl, po = eng.closest_points(qt, table, link_capsules=None if link_capsules is None else as_tensor(link_capsules, eng.device))
-        self._pairs_cache = (pl, po, [K] * len(leaves))
-        out = {}
+        prim = as_tensor(primitives, eng.device)
+        lc = None if link_capsules is None else as_tensor(link_capsules, eng.device)
+        src = _StageSource(self, eng, qt, single, prim, lc, len(leaves))
+        self._stage = src
         names = self._table.frame_names
+        frames = []
         for i, (rmp, last) in enumerate(leaves):
-            a, b = pl[:, i * K:(i + 1) * K], po[:, i * K:(i + 1) * K]
-            a, b = (a[0], b[0]) if single else (a, b)
-            for attr, v in (("pos_on_link_in_base_frame", a), ("pos_on_obstacle_in_base_frame", b)):
+            for which, attr in enumerate(("pos_on_link_in_base_frame", "pos_on_obstacle_in_base_frame")):
                 h = getattr(last, attr)
                 if isinstance(h, ArrayVar):
-                    h.assign(v)
-                else:
-                    setattr(last, attr, v)
-            out[names[eng.desc.leaves[dist_idx[i]].frame]] = (a, b)
-        return out
+                    h.assign_lazy(lambda i=i, which=which: src.view(i, which), owner=src)
+                else:   # a plain attribute cannot defer: the stage runs now
+                    setattr(last, attr, src.view(i, which))
+            frames.append(names[eng.desc.leaves[dist_idx[i]].frame])
+        return _LazyPairs(src, frames)
+
+    def _fused_stage_obstacles(self, eng, q, pair_rmps):
+        """The obstacle input of a step whose distance leaves all still hold what the last update_distances(q, ...) gave them,
+        for the same unmodified q: the stage's INPUTS (primitives + link capsules) instead of its output.  None otherwise."""
+        src = getattr(self, "_stage", None)
+        if src is None or not src.fusable or src.eng is not eng or not src.same_q(q):
+            return None
+        for rmp, kind, last in pair_rmps:
+            if kind != D.TASKMAP_FK_DISTANCE:
+                return None
+            for attr in ("pos_on_link_in_base_frame", "pos_on_obstacle_in_base_frame"):
+                h = getattr(last, attr, None)
+                if not (isinstance(h, ArrayVar) and h.owner is src):
+                    return None
+        return eng.obstacles(spheres=src.prim, link_capsules=src.link_capsules_or_origins())
 
     def _evaluate_device(self, q, qd, spheres, link_capsules=None):
         """evaluate() for tensors that already live on the engine's device: nothing goes through the host, the result is a
@@ -197,6 +274,15 @@ class RmpCore:
                     raise ValueError("TaskmapSphereDistance leaves need evaluate(..., spheres=[K,4])")
                 obstacles = eng.obstacles(spheres=as_tensor(sp, dev),
                                           link_capsules=None if link_capsules is None else as_tensor(link_capsules, dev))
+            elif (fused := self._fused_stage_obstacles(eng, q, pair_rmps)) is not None:
+                try:
+                    out = eng.step(q2, qd2, goal=goal, obstacles=fused)
+                    return out[0] if single else out
+                except Rmp2Error as e:   # beyond the fused form's limits (table size, resolve mode ...): the arrays then
+                    if "link_capsules" not in str(e):
+                        raise
+                    self._stage.fusable = False
+                    return self._evaluate_device(q, qd, spheres, link_capsules)
             elif not any(isinstance(last, TaskmapSphereDistance) for _, _, last in pair_rmps):
                 def fleet(a, nd):
                     a = as_tensor(a, dev)

@@ -102,9 +102,22 @@ def test_experiment06_loop_stays_on_the_device(golden_dir, hip_lib):
     assert isinstance(qdd, torch.Tensor) and qdd.is_cuda and qdd.shape == (R, 9)
     err = np.abs(qdd.cpu().numpy() - g["qdd"]).max(axis=1)
     assert (err <= ATOL * np.maximum(1.0, np.abs(g["qdd"]).max(axis=1))).all()
-    # the holders the leaves read ARE the stage's output: nothing was gathered or copied
+    # nobody read a holder: the stage never ran, the step formed the in-range pairs itself from the primitives
+    assert core._stage._arrays is None
+    # reading one runs it; the holders the leaves read ARE its output (nothing gathered or copied), and the step fed with
+    # them (a modified q object would do the same: stale pairs, fresh q, as in the reference) gives the same accelerations
     first = data_manager[Cf.CONTROL_POINT_FRAMES[0]]['pos_on_link_in_base_frame'].value
     assert first.is_cuda and first.data_ptr() == core._pairs_cache[0].data_ptr()
+    q_other = q.clone()                                    # (another tensor object: the fused form is not taken)
+    qdd_explicit = core.evaluate(q_other, qd)
+    assert (qdd_explicit - qdd).abs().max().item() <= 5e-5 * max(1.0, qdd.abs().max().item())
+    # a holder somebody else assigned switches the fused form off for good reason: its value must be read
+    hold = data_manager[Cf.CONTROL_POINT_FRAMES[2]]['pos_on_obstacle_in_base_frame']
+    moved = hold.value.clone()
+    moved[:, 0, 2] += 0.2
+    hold.assign(moved)
+    assert (core.evaluate(q, qd) - qdd).abs().max().item() > 1e-6
+    data_manager.update_device(core, q, spheres)
     # (ii) the same fields as the host path fills for robot 0
     pl, po = Cf.pairs_from_spheres(g["origins"], g["spheres"])
     host = mods[4].Datamanager(fkine)
