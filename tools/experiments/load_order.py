@@ -84,3 +84,11 @@ for W in (4,):
     run("dealt_wg", wgs[inter].reshape(-1), W)
     rnd = torch.randperm(n_wg, device=dev)
     run("wg_shuffle", wgs[rnd].reshape(-1), W)
+
+# ---- the bound of ANY balancing between the robots of a wave: every wave holds 16 copies of ONE robot (no imbalance between its
+# quads at all; what remains is the quad's own ceil(pairs of a frame / 4)) ----
+rep = torch.arange(R // 16, device=dev).repeat_interleave(16)
+run("replicated", rep)
+pf_rep = per_frame[rep].reshape(-1, 16, per_frame.shape[1])
+print(f"replicated: trips per wave-step = sum over frames of ceil(pairs / 4) of the one robot: mean {pf_rep[:, 0].sum(dim=1).float().mean():.2f}; "
+      f"pairs / 4 without the ceil: {load[rep].float().mean() / 4:.2f}")
