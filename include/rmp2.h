@@ -11,7 +11,10 @@
  * Rules of the boundary
  *   - plain C, plain pointers and sizes; no C++/torch types.
  *   - the caller owns every buffer; the engine owns its handle, its constant tables and
- *     nothing else.  rmp2_step() allocates nothing and never synchronises the host.
+ *     nothing else.  rmp2_step() allocates nothing and never synchronises the host -- one exception: a handle
+ *     whose every robot is resolved by the pseudo-inverse (solve_mode = PINV, or a set without a positive-definite
+ *     identity-map leaf) on a 3..9-dof robot keeps the combined systems of the fleet between its two kernels
+ *     (8 n (n + 1) bytes per robot) and grows that buffer, synchronising, the first time a larger fleet is stepped.
  *   - all array arguments of rmp2_step / rmp2_forward_kinematics / rmp2_differentiate are
  *     DEVICE pointers (HBM), row-major, robot index slowest: q[R][n_dof] etc.
  *   - every call returns 0 on success or a negative RMP2_ERR_* code; the message is

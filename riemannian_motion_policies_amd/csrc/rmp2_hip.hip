@@ -485,7 +485,22 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
     // live across a second pass.
     if (STRICT) {
       double x[N];
-      const int dropped = pinv_solve<N>(A, fv, n_dof, x);
+      // a metric / force with NaN or Inf resolves to NaN (tf.linalg.pinv of such a matrix, rmp.py:153): the Jacobi iteration
+      // would skip the NaN rows and return the pseudo-inverse of what is left
+      bool finite_in = true;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) finite_in = finite_in && (fabs(A[i][j]) < 1.7e308);
+        finite_in = finite_in && (fabs(fv[i]) < 1.7e308);
+      }
+      int dropped = 0;
+      if (finite_in) {
+        dropped = pinv_solve<N>(A, fv, n_dof, x);
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = __builtin_nan("");
+      }
       if (dropped) status |= RMP2_STATUS_RANK_DROP;
       bool finite = true;
 #pragma unroll
@@ -580,6 +595,48 @@ rmp2_fk_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ q,
     o[12] = o[13] = o[14] = 0.f;
     o[15] = 1.f;
   }
+}
+
+// The resolve on its own: q'' = pinv(M) f for every robot (rmp.py:153-154, TensorFlow's cutoff), a lane per robot, register-resident
+// one-sided Jacobi (rmp2_solve.h pinv_solve).  Second kernel of the strict / rank-deficient control step at fleet size: the quad
+// mapping (culled, split pair loops) stops behind the combined metric and force, this kernel resolves them -- the lane-per-robot
+// step kernel that carries the same resolve walks all 256 pairs of a robot in one lane (285 us per step for config 3 at 65 536
+// robots).
+template <int N>
+__global__ void __launch_bounds__(kWave)
+rmp2_pinv_kernel(const double* __restrict__ M, const double* __restrict__ f, float* __restrict__ qdd, uint32_t* __restrict__ status_out,
+                 int n_dof, int R) {
+  const int robot = blockIdx.x * kWave + threadIdx.x;
+  if (robot >= R) return;
+  // M [n_dof * n_dof][R], f [n_dof][R]: robot index fastest (the quad kernel's skip_resolve layout) -- coalesced here
+  double A[N][N], fv[N], x[N];
+  bool finite_in = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      A[i][j] = (i < n_dof && j < n_dof) ? M[(size_t)(i * n_dof + j) * R + robot] : (i == j ? 1.0 : 0.0);  // padding dofs: identity
+      finite_in = finite_in && (fabs(A[i][j]) < 1.7e308);                                                  // rows, q'' = 0
+    }
+    fv[i] = i < n_dof ? f[(size_t)i * R + robot] : 0.0;
+    finite_in = finite_in && (fabs(fv[i]) < 1.7e308);
+  }
+  uint32_t status = 0u;
+  if (finite_in) {
+    if (pinv_solve<N>(A, fv, n_dof, x)) status |= RMP2_STATUS_RANK_DROP;
+  } else {  // (as the reference's pinv of a matrix with NaN / Inf)
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = __builtin_nan("");
+  }
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n_dof) {
+      finite = finite && (fabs(x[i]) < 1.7e308);
+      qdd[(size_t)robot * n_dof + i] = (float)x[i];
+    }
+  if (!finite) status |= RMP2_STATUS_NONFINITE;
+  if (status_out) status_out[robot] = status;
 }
 
 // Closest-point stage on its own: control point = frame origin of each distance leaf, nearest surface
@@ -1354,8 +1411,38 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // mappings (with their split pair loops and culling) keep sets without an inertia leaf, e.g. the TwoJoint half of the
   // mixed fleet (config 5)
   const bool cheap_fallthrough = N == 2 && !h->strict;
-  if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough)
+  if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough) {
+    // Fleets: two kernels -- the quad mapping up to the combined metric and force (its pair loops are culled and split four
+    // ways), then rmp2_pinv_kernel, a lane per robot.  The lane-per-robot step kernel with the same resolve keeps small fleets
+    // and what the quad mapping does not carry.
+    // (a caller who asks for the combined metric / force -- debug outputs, robot index slowest -- gets the lane kernel)
+    if (N == 9 && h->kernel_choice == 0 && h->d_system && (size_t)R <= h->system_robots && h->goal_floats <= 16 && !h->has_point &&
+        !o.link_caps && R > 1024 && !out.M && !out.f) {
+      const int n = h->n_dof;
+      OutArgs o2 = out;
+      o2.M = h->d_system;                       // [n * n][R], robot index fastest
+      o2.f = h->d_system + (size_t)R * n * n;   // [n][R]
+      rmp2_handle* hm = const_cast<rmp2_handle*>(h);  // (the handle is the caller's mutable object: step_impl)
+      void* const fence = hm->step_fence;
+      hm->step_fence = nullptr;        // the completion fence belongs to the LAST kernel of the step
+      hm->quad_skip_resolve = true;
+      bool ok = true;
+      switch (h->n_slots) {
+        case 0: launch_quad_n9_s0(h, q, qd, goal, gs, o, o2, ro, R, s); break;
+        case 1: launch_quad_n9_s1(h, q, qd, goal, gs, o, o2, ro, R, s); break;
+        case 2: launch_quad_n9_s2(h, q, qd, goal, gs, o, o2, ro, R, s); break;
+        default: ok = false; break;
+      }
+      hm->quad_skip_resolve = false;
+      hm->step_fence = fence;
+      if (ok) {
+        RMP2_STEP_LAUNCH(h, (rmp2_pinv_kernel<9>), dim3((R + kWave - 1) / kWave), dim3(kWave), 0, s, o2.M, o2.f, out.qdd, out.status, n, R);
+        h->last_kernel = "rmp2_step_quad_kernel up to (M, f) + rmp2_pinv_kernel (one lane per robot, Jacobi pseudo-inverse)";
+        return RMP2_OK;
+      }
+    }
     return dispatch_slots<N, true>(h, q, qd, goal, gs, o, out, R, s);
+  }
   // Kernel choice (all mappings produce the same numbers to fp32 rounding):
   //  * hex (16 lanes per robot, rmp2_hex.h): the latency build -- fleets up to 8 192 robots, where the other mappings
   //    leave SIMDs idle; every leaf kind, both resolves, robots with up to 16 dofs; carries the fused rollout loop;
@@ -1663,6 +1750,7 @@ int rmp2_destroy(rmp2_handle* h) {
   if (h->d_hex_blob) (void)hipFree(h->d_hex_blob);
   if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (h->d_system) (void)hipFree(h->d_system);
   if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
   delete h;
   return RMP2_OK;
@@ -1749,6 +1837,15 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   OutArgs oa;
   if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if ((h->strict || h->likely_singular) && h->n_template == 9 && R > 1024 && (size_t)R > h->system_robots) {
+    // the combined systems between the two kernels of the strict step (dispatch_solve): 8 n (n + 1) bytes per robot, owned by
+    // the handle, grown to the largest fleet stepped (hipFree synchronises the device: no launch still reads the old buffer)
+    if (h->d_system) HIP_TRY(h, hipFree(h->d_system));
+    h->d_system = nullptr;
+    h->system_robots = 0;
+    HIP_TRY(h, hipMalloc(&h->d_system, sizeof(double) * (size_t)R * h->n_dof * (h->n_dof + 1)));
+    h->system_robots = (size_t)R;
+  }
   int rc;
   if (h->n_template == 2)
     rc = dispatch_solve<2>(h, q, qd, goal, goal_stride, o, oa, ro, R, s);

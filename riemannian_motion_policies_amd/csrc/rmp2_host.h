@@ -54,6 +54,9 @@ struct rmp2_handle {
   bool pair_begin_valid = false;
   float* d_scratch = nullptr;  // rmp2_differentiate scratch
   size_t scratch_robots = 0;
+  double* d_system = nullptr;  // [robots][n_dof * (n_dof + 1)] combined metric and force between the quad step and rmp2_pinv_kernel
+  size_t system_robots = 0;
+  mutable bool quad_skip_resolve = false;  // set around that quad launch (dispatch_solve)
   mutable const char* last_kernel = "none";  // mapping the last control step / rollout was launched with (rmp2_last_kernel)
   std::string error;
 };
@@ -89,7 +92,7 @@ bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, 
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                  h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
-                 h->prio_tail >= 0 ? h->prio_tail : 0};
+                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0};
 }
 // rmp2_hex_tu.hip (false: the working set does not fit the CU's LDS -- the caller falls back to the quad mapping)
 bool launch_hex_n2(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,

@@ -790,6 +790,8 @@ struct QuadHdr {
   int32_t prio_tail;    // wave priority of the phases after the frame loop (rmp2_quad.h only): 0; RMP2_PRIO_TAIL pins another
                         // value for A/B runs (with the kernels of the middle of round 2 a fleet of many rounds preferred 2,
                         // with the final ones 0 wins at every size: tools/gpu_calls_r02/r02_run33_prio_tail.sh)
+  int32_t skip_resolve; // 1 (rmp2_quad.h, general flavour): the step stops behind the combined metric / force (out.M, out.f);
+                        // rmp2_pinv_kernel resolves every robot by the pseudo-inverse (solve = PINV, rank-deficient sets)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -1759,14 +1761,21 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       for (int m = 0; m < ROWS; ++m) {
         const int i = sub + kQuad * m;
         if (i < n_dof) {
+          // (skip_resolve: the handle's own buffer between this kernel and rmp2_pinv_kernel, robot index FASTEST -- the
+          // sixteen quads of the wave write 128 contiguous bytes per entry, the resolve kernel reads a lane per robot)
+          const bool soa = hdr.skip_resolve != 0;
           if (out.M) {
 #pragma unroll
             for (int j = 0; j < N; ++j)
-              if (j < n_dof) out.M[((size_t)rb * n_dof + i) * n_dof + j] = A[m][j];
+              if (j < n_dof) out.M[soa ? (size_t)(i * n_dof + j) * R + rb : ((size_t)rb * n_dof + i) * n_dof + j] = A[m][j];
           }
-          if (out.f) out.f[(size_t)rb * n_dof + i] = fv[m];
+          if (out.f) out.f[soa ? (size_t)i * R + rb : (size_t)rb * n_dof + i] = fv[m];
         }
       }
+    }
+    if (!LEAN && hdr.skip_resolve) {  // (wave-uniform) the pseudo-inverse of every robot follows in rmp2_pinv_kernel
+      flagged = false;
+      return;
     }
     // padding dofs of the template: identity rows so that they resolve to qdd = 0
 #pragma unroll

@@ -380,3 +380,74 @@ def test_two_by_two_closed_form_pseudo_inverse(torch_mod, golden_dir):
     assert stc[0] & 2 and stc[0] & 4, "rank drop of the start pose must be reported"
     assert stc[2] & 1 and not np.isfinite(got[2]).all()
     assert (stc[3:][cond < 1e4] == 0).all() and (cond < 100).sum() > 100
+
+
+def test_strict_pseudo_inverse_at_fleet_size_takes_two_kernels(torch_mod):
+    """solve = "pinv" (the reference's only resolve, rmp.py:153-154) for a fleet: the quad mapping up to the combined metric and
+    force, then rmp2_pinv_kernel for every robot.  Same numbers as the oracle's pseudo-inverse and as the lane-per-robot strict
+    kernel (which small fleets and RMP2_KERNEL=lane keep); a rank-deficient set (target only: rank <= 3 of 9) goes the same
+    way under solve = "auto"; a robot with a NaN state resolves to NaN, as tf.linalg.pinv of a NaN matrix does."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    R = 5000
+    rng = np.random.default_rng(31)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += np.float32(0.5)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    table, desc = Cf.config3("pinv")
+    from riemannian_motion_policies_amd.engine import Engine
+    eng = Engine(desc, 0)
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    M = torch.zeros(R, 9, 9, dtype=torch.float64, device="cuda")
+    got = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st)
+    assert "rmp2_pinv_kernel" in eng.last_kernel()
+    lane = _engine(desc, "lane")
+    want_lane = lane.step(q, qd, goal, obstacles=lane.obstacles(spheres=torch.from_numpy(sph)))
+    assert "STRICT" in lane.last_kernel()
+    torch.cuda.synchronize()
+    n = 512
+    ref = O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], spheres=sph)
+    # (parity is asserted for robots clear of contact, as everywhere: >= 0.05 m between every control point and every sphere)
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    org = O.forward_kinematics(desc, s["q"], precision="f64")[:, frames][:, :, :3, 3]
+    clr = (np.linalg.norm(org[:, :, None, :] - sph[None, None, :, :3], axis=-1) - sph[None, None, :, 3]).min(axis=(1, 2))
+    clear = clr >= 0.05
+    assert clear[:n].sum() > n // 3
+    _check(got[:n].cpu().numpy(), ref["qdd64"], "two-kernel strict step vs oracle", mask=clear[:n])
+    _check(got.cpu().numpy(), want_lane.cpu().numpy().astype(np.float64), "two-kernel strict step vs lane strict kernel", mask=clear)
+    assert (st[torch.from_numpy(clear).cuda()] == 0).all()
+    # a caller who asks for the combined metric (debug output, robot index slowest) gets the lane kernel
+    got2 = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), M=M)
+    torch.cuda.synchronize()
+    assert "STRICT" in eng.last_kernel()
+    Mn, c = M[:n].cpu().numpy(), clear[:n]
+    assert (np.abs(Mn - ref["M"]).max(axis=(1, 2))[c] <= 1e-5 * np.abs(ref["M"]).max(axis=(1, 2))[c]).all()
+    # a NaN state: NaN out, flagged, neighbours untouched
+    qb = q.clone()
+    qb[7, 3] = float("nan")
+    gb = eng.step(qb, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st)
+    torch.cuda.synchronize()
+    assert torch.isnan(gb[7]).all() and (st[7] & D.STATUS_NONFINITE) and torch.equal(gb[:7], got[:7]) and torch.equal(gb[8:], got[8:])
+    gl = lane.step(qb, qd, goal, obstacles=lane.obstacles(spheres=torch.from_numpy(sph)))
+    assert torch.isnan(gl[7]).all()
+    # rank-deficient set under AUTO: a lone target attractor on the Panda (rank <= 3): every robot takes the pseudo-inverse
+    spec = D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, table.frame_index("panda_grasptarget_hand"),
+                      Cf.TARGET_ATTRACTOR_PARAMS, goal_len=3)
+    d1 = D.build_desc(table, [spec])
+    e1 = Engine(d1, 0)
+    g1 = e1.step(q, qd, goal, status=st)
+    assert "rmp2_pinv_kernel" in e1.last_kernel()
+    f1 = torch.zeros(R, 9, dtype=torch.float64, device="cuda")
+    e1.step(q, qd, goal, M=M, f=f1)          # (the system itself: through the lane kernel's debug outputs)
+    torch.cuda.synchronize()
+    # WHAT the pseudo-inverse of such a system returns is decided by rounding noise in its six "zero" singular values (fp32
+    # pull-backs: ~1e-8 of the largest, far above TensorFlow's cutoff of 2e-14) and differs between any two implementations;
+    # pinned here: the system is consistent (f = J^T A e lies in the range of M = J^T A J), so the result solves it
+    x = g1.double()
+    res = (torch.einsum("rij,rj->ri", M, x) - f1).abs().max(dim=1).values
+    scale = (torch.einsum("rij,rj->ri", M.abs(), x.abs()) + f1.abs()).max(dim=1).values
+    assert torch.isfinite(g1).all() and (res <= 1e-4 * scale).all(), (res / scale).max().item()
+    r1 = O.step(d1, s["q"][:n], s["qd"][:n], s["goal"][:n])
+    assert np.abs(M[:n].cpu().numpy() - r1["M"]).max() <= 1e-5 * np.abs(r1["M"]).max()
