@@ -283,6 +283,10 @@ class Engine:
         rc = self._lib.rmp2_rollout(self._h, q.data_ptr(), qd.data_ptr(), goal_ptr, goal_stride,
                                     C.byref(obstacles) if obstacles is not None else None, C.byref(cfg), C.byref(o), R, s)
         _native.check(rc, self._h)
+        # q and qd were advanced through their raw pointers: tell torch (version counters; an in-place operation on an empty
+        # slice launches nothing) -- RmpCore's fused route after update_distances relies on "same q, unmodified"
+        q[:0].zero_()
+        qd[:0].zero_()
         return out
 
     def forward_kinematics(self, q: torch.Tensor) -> torch.Tensor:

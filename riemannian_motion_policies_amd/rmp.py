@@ -209,8 +209,9 @@ class RmpCore:
         leaves still hold what this call gave them never forms them: it hands the primitives and the link capsules to the step,
         which forms the in-range pairs itself (rmp2_obstacles.link_capsules; same values, explicit-pair semantics).
         Returns a mapping {frame name: (p_link, p_obs)} (reading an entry runs the stage); .frames lists the names.
-        ("Unmodified" is torch's version counter of q: an in-place torch operation is seen, a write through the raw pointer --
-        Engine.rollout advancing q -- is not; call update_distances again after one, as the reference's loop does every step.)"""
+        ("Unmodified" is torch's version counter of q: in-place torch operations and Engine.rollout bump it; a write through
+        the raw pointer by foreign code does not -- call update_distances again after one, as the reference's loop does every
+        step.)"""
         single = q.dim() == 1 if isinstance(q, torch.Tensor) else np.ndim(q) == 1
         eng = self.engine_for(q)
         qt = as_tensor(q, eng.device)

@@ -118,6 +118,14 @@ def test_experiment06_loop_stays_on_the_device(golden_dir, hip_lib):
     hold.assign(moved)
     assert (core.evaluate(q, qd) - qdd).abs().max().item() > 1e-6
     data_manager.update_device(core, q, spheres)
+    # ... and so does advancing q in place, by torch or by the engine's rollout (raw pointers; it bumps the version counters)
+    qr, qdr = q.clone(), qd.clone()
+    data_manager.update_device(core, qr, spheres)
+    assert core._stage.same_q(qr)
+    core.engine_for(qr).rollout(qr, qdr, torch.from_numpy(g["goal"]).to(dev), obstacles=core.engine_for(qr).obstacles(spheres=spheres),
+                                n_control_steps=1, substeps=2, dt=0.01)
+    assert not core._stage.same_q(qr)
+    data_manager.update_device(core, q, spheres)
     # (ii) the same fields as the host path fills for robot 0
     pl, po = Cf.pairs_from_spheres(g["origins"], g["spheres"])
     host = mods[4].Datamanager(fkine)
