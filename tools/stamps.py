@@ -14,7 +14,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 t = panda_table()
 damp = D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, Cf.JOINT_DAMPING_PARAMS)
 sets = {"D no-frames damping": D.build_desc(_null_table(9), [damp]), "C walk damping": D.build_desc(t, [damp]),
-        "config2": Cf.config2()[1], "config3": Cf.config3()[1], "config3 link geometry": Cf.config3()[1]}
+        "config2": Cf.config2()[1], "config3": Cf.config3()[1], "config3 link geometry": Cf.config3()[1],
+        "config3 explicit pairs": Cf.config3()[1]}
 s = Cf.sample_panda_states(np.random.default_rng(1), R)
 q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
 sph = torch.from_numpy(Cf.sample_spheres(np.random.default_rng(7))).cuda()
@@ -26,6 +27,9 @@ for name, desc in sets.items():
         from riemannian_motion_policies_amd import urdf as U
         lc = torch.from_numpy(U.link_capsules(U.PANDA_URDF, t, Cf.CONTROL_POINT_FRAMES)).cuda()
         obs = eng.obstacles(spheres=sph, link_capsules=lc)
+    if name == "config3 explicit pairs":   # interface B: the pairs of the same table as [R, 256, 3] arrays
+        pl_, po_ = eng.closest_points(q, eng.obstacles(spheres=sph))
+        obs = eng.obstacles(p_link=pl_, p_obs=po_)
     g = goal if desc.goal_floats else None
     n_blocks = (R + 3) // 4 if os.environ.get("RMP2_HEX_WAVES") == "1" else (R + 15) // 16
     buf = torch.zeros(R * 9 + 16 * n_blocks, dtype=torch.float64, device="cuda")  # f rows, then 16 stamps per block
