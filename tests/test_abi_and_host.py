@@ -192,6 +192,27 @@ def test_rmpcore_quick_signature_sees_every_mutation_that_changes_the_program():
     assert core._quick_signature(7) not in seen
 
 
+def test_arrayvar_lazy_values_and_owner_marks():
+    """data_management.ArrayVar: assign_lazy defers the value to its first read and keeps the producer's mark through that
+    read; any assign() by somebody else clears it (RmpCore steps fused only while every holder still carries the mark)."""
+    from riemannian_motion_policies_amd.data_management import ArrayVar, as_array
+    calls = []
+    owner = object()
+    v = ArrayVar(np.zeros((0, 3)))
+    assert v.owner is None and v.value.shape == (0, 3)
+    v.assign_lazy(lambda: calls.append(1) or np.arange(6, dtype=np.float64).reshape(2, 3), owner=owner)
+    assert v.owner is owner and calls == []
+    a = v.value
+    assert calls == [1] and a.dtype == np.float32 and a.shape == (2, 3) and v.owner is owner
+    assert v.value is a and calls == [1]                      # evaluated once
+    assert np.array_equal(as_array(v), a) and np.array_equal(np.asarray(v), a)
+    v.assign(np.ones((1, 3)))
+    assert v.owner is None and v.numpy().shape == (1, 3)
+    v.assign_lazy(lambda: np.full((1, 3), 7.0))
+    v.value = np.zeros((4, 3))                                # (attribute-style assignment is an assign)
+    assert v.owner is None and v.value.shape == (4, 3)
+
+
 def test_unsupported_chains_raise():
     from riemannian_motion_policies_amd import rmp, taskmap, urdf
     from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
