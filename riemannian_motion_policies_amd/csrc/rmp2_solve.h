@@ -80,11 +80,16 @@ __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int
         }
         // converged pair: |<w_p, w_q>| <= 4 eps |w_p| |w_q|  (a tighter bound than eps can never be met
         // and only burns sweeps)
-        const bool rot = (fabs(ga) > 1e-300) && (fabs(ga) > 1e-15 * sqrt(al * be));
+        const bool rot = (fabs(ga) > 1e-300) && (ga * ga > 1e-30 * (al * be));
         rotated = rotated || rot;
-        const double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        // the rotation that makes the two rows orthogonal: zeta = (be - al) / (2 ga), t = sign(zeta) / (|zeta| + sqrt(1 +
+        // zeta^2)), c = 1 / sqrt(1 + t^2), s = c t -- with numerator and denominator of t multiplied through by 2 |ga|:
+        // one square root, one division and one reciprocal square root per rotation instead of three and three (the fp64
+        // forms of those are ~25 instructions each: they were two thirds of the kernel that runs this for a whole fleet)
+        const double dd = be - al;
+        const double num = 2.0 * (dd == 0.0 ? fabs(ga) : (dd > 0.0 ? ga : -ga));
+        const double t = num / (fabs(dd) + sqrt(fma(dd, dd, 4.0 * ga * ga)));
+        double c = rsqrt(fma(t, t, 1.0)), s = c * t;
         c = rot ? c : 1.0;
         s = rot ? s : 0.0;
 #pragma unroll
