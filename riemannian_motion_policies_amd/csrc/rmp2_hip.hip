@@ -1412,12 +1412,12 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // mixed fleet (config 5)
   const bool cheap_fallthrough = N == 2 && !h->strict;
   if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough) {
-    // Fleets: two kernels -- the quad mapping up to the combined metric and force (its pair loops are culled and split four
-    // ways), then rmp2_pinv_kernel, a lane per robot.  The lane-per-robot step kernel with the same resolve keeps small fleets
-    // and what the quad mapping does not carry.
+    // Two kernels -- the quad mapping up to the combined metric and force (its pair loops are culled and split four ways;
+    // the latency build for small grids), then rmp2_pinv_kernel, a lane per robot.  The lane-per-robot step kernel with the
+    // same resolve keeps what the quad mapping does not carry (attached-point leaves, debug outputs, RMP2_KERNEL=lane).
     // (a caller who asks for the combined metric / force -- debug outputs, robot index slowest -- gets the lane kernel)
     if (N == 9 && h->kernel_choice == 0 && h->d_system && (size_t)R <= h->system_robots && h->goal_floats <= 16 && !h->has_point &&
-        !o.link_caps && R > 1024 && !out.M && !out.f) {
+        !o.link_caps && !out.M && !out.f) {
       const int n = h->n_dof;
       OutArgs o2 = out;
       o2.M = h->d_system;                       // [n * n][R], robot index fastest
@@ -1837,7 +1837,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   OutArgs oa;
   if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((h->strict || h->likely_singular) && h->n_template == 9 && R > 1024 && (size_t)R > h->system_robots) {
+  if ((h->strict || h->likely_singular) && h->n_template == 9 && (size_t)R > h->system_robots) {
     // the combined systems between the two kernels of the strict step (dispatch_solve): 8 n (n + 1) bytes per robot, owned by
     // the handle, grown to the largest fleet stepped (hipFree synchronises the device: no launch still reads the old buffer)
     if (h->d_system) HIP_TRY(h, hipFree(h->d_system));

@@ -67,17 +67,23 @@ template <int N>
 __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int n_dof, double (&x)[N]) {
   for (int sweep = 0; sweep < 30; ++sweep) {
     bool rotated = false;
+    // squared row norms: formed once per sweep, then carried through the rotations (|w_p'|^2 = |w_p|^2 - t <w_p, w_q>,
+    // |w_q'|^2 = |w_q|^2 + t <w_p, w_q> for the rotation below): one dot product per pair instead of three
+    double nrm[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      nrm[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) nrm[i] = fma(A[i][j], A[i][j], nrm[i]);
+    }
 #pragma unroll
     for (int p = 0; p < N - 1; ++p) {
 #pragma unroll
       for (int q = p + 1; q < N; ++q) {
-        double al = 0.0, be = 0.0, ga = 0.0;
+        const double al = nrm[p], be = nrm[q];
+        double ga = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          al = fma(A[p][j], A[p][j], al);
-          be = fma(A[q][j], A[q][j], be);
-          ga = fma(A[p][j], A[q][j], ga);
-        }
+        for (int j = 0; j < N; ++j) ga = fma(A[p][j], A[q][j], ga);
         // converged pair: |<w_p, w_q>| <= 4 eps |w_p| |w_q|  (a tighter bound than eps can never be met
         // and only burns sweeps)
         const bool rot = (fabs(ga) > 1e-300) && (ga * ga > 1e-30 * (al * be));
@@ -92,6 +98,9 @@ __device__ __forceinline__ int pinv_solve(double (&A)[N][N], double (&b)[N], int
         double c = rsqrt(fma(t, t, 1.0)), s = c * t;
         c = rot ? c : 1.0;
         s = rot ? s : 0.0;
+        const double tg = rot ? t * ga : 0.0;
+        nrm[p] = al - tg;
+        nrm[q] = be + tg;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           const double wp = A[p][j], wq = A[q][j];
