@@ -214,11 +214,49 @@ def spawn_ranks(args) -> int:
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # a session (= process group) of its own per rank: the supervisor can end exactly what it started
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    return supervise(procs, args.rank_timeout)
+
+
+def supervise(procs, timeout_s: float, poll_s: float = 0.2, grace_s: float = 5.0) -> int:
+    """Wait for the rank processes.  The job is all-or-nothing: when one rank exits non-zero, or any rank is still running
+    `timeout_s` seconds after the start (a hung RCCL initialisation, a collective a dead peer never joins), the surviving
+    ranks' process groups are ended (SIGTERM, SIGKILL after `grace_s`) and the supervisor returns non-zero -- the failing
+    rank's code, or 124 for the time-out -- instead of waiting for the driver's own limit with no line printed."""
+    import signal
+    t0 = time.monotonic()
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = (abs(bad[0][1]) or 1), f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() - t0 > timeout_s:
+            hung = [i for i, c in enumerate(codes) if c is None]
+            rc, why = 124, f"rank(s) {hung} still running after {timeout_s:.0f} s"
+            break
+        time.sleep(poll_s)
+    print(f"bench.py: {why}; ending the other ranks", file=sys.stderr)
+    for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, grace_s)):
+        alive = [p for p in procs if p.poll() is None]
+        if not alive:
+            break
+        for p in alive:
+            try:
+                os.killpg(p.pid, sig)   # p.pid is the id of the group created by start_new_session -- nothing else is in it
+            except (ProcessLookupError, PermissionError):
+                try:
+                    p.send_signal(sig)
+                except ProcessLookupError:
+                    pass
+        t1 = time.monotonic()
+        while time.monotonic() - t1 < wait and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
     return rc
 
 
@@ -416,16 +454,10 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         # loop below costs ~50 us of host time per step -- more than the step kernel takes)
         from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
         if not isinstance(exch, NativeObstacleExchange):
-            err = None
-            try:
-                exch = NativeObstacleExchange(K // world, dev, depth=args.exchange_depth)
-            except Exception as e:   # (RCCL could not be bound / the communicator not built: the torch-driven exchange still works)
-                err = e
-            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
-            if world > 1:   # every rank takes the same exchange: one rank falling back alone would leave the others in a collective
-                import torch.distributed as dist
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            from riemannian_motion_policies_amd.fleet import agree_on_exchange
+            # every rank takes the same exchange: one rank falling back alone would leave the others in a collective
+            exch, err = agree_on_exchange(lambda: NativeObstacleExchange(K // world, dev, depth=args.exchange_depth), world, dev)
+            if exch is None:
                 print(f"bench.py: native exchange unavailable (rank {rank}: {err!r}); every rank falls back to --exchange torch", file=sys.stderr)
                 args.exchange = "torch"
                 return build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=seed_rank, exch=None)
@@ -766,6 +798,8 @@ def main():
                     help="config4, native exchange: tables gathered this many control steps ahead (2: a full step of slack "
                          "for the gather, one more step of obstacle staleness)")
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
+    ap.add_argument("--rank-timeout", type=float, default=540.0,
+                    help="--gpus N without a launcher: seconds after which ranks that are still running are ended and the job fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()

@@ -281,6 +281,8 @@ int rmp2_exchange_create(const char *rccl_library, const rmp2_rccl_uid *uid, int
 int rmp2_exchange_destroy(rmp2_exchange *x);
 const char *rmp2_exchange_last_error(const rmp2_exchange *x);
 int rmp2_exchange_pending(const rmp2_exchange *x);
+/* Ranks of the communicator this exchange was created on (what ncclCommInitRank was given and joined; 0 for NULL). */
+int rmp2_exchange_nranks(const rmp2_exchange *x);
 /* Pipeline depth (before the first rmp2_exchange_start): depth + 1 gathers may be outstanding, depth + 1 table buffers are
  * in use.  1 (default): the table of step k is gathered while step k - 1 runs, from slices produced before step k - 1 was
  * issued.  2: gathered while steps k - 2 and k - 1 run -- one more control step of obstacle staleness, and a full step of
@@ -297,7 +299,9 @@ int rmp2_exchange_set_peer_wait(rmp2_exchange *x, int32_t on);
  * be outstanding. */
 int rmp2_exchange_start(rmp2_exchange *x, const float *local, int32_t local_is_ready, void *stream);
 /* One control step (as rmp2_step with SHARED_SPHERES) on the OLDEST outstanding table.  next_local != NULL: the gather of
- * the next table is issued before the launch (same as rmp2_exchange_start(x, next_local, next_local_is_ready, stream)).
+ * the next table is issued before the launch (same as rmp2_exchange_start(x, next_local, next_local_is_ready, stream)) --
+ * or right behind it, ordered after this step's read, when all depth + 1 buffers were outstanding and the gather therefore
+ * lands in the buffer this very step reads.
  * table_out (optional): device pointer of the table this step reads. */
 int rmp2_exchange_step(rmp2_exchange *x, rmp2_handle *h, const float *q, const float *qd, const float *goal,
                        int32_t goal_stride, const float *next_local, int32_t next_local_is_ready, const rmp2_outputs *out,

@@ -171,3 +171,44 @@ def pinv_solve(M, f):
     x = np.empty(n, np.float64)
     dropped = lib().orc_pinv_solve_f64(C.c_int(n), _ptr(M, C.c_double), _ptr(f, C.c_double), _ptr(x, C.c_double))
     return x, dropped
+
+
+def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5):
+    """Per-robot accuracy verdict of a computed q-double-dot `got` [R, n] against an oracle result `ref` (the dict of step()).
+    EVERY robot gets a bound -- none is exempted for being ill-conditioned:
+
+      A  (north star)   |got - ref|_inf <= atol * max(1, |ref|_inf)
+      B  (backward)     omega = |M_ref got - f_ref|_2 / (|M_ref|_2 |got|_2 + |f_ref|_2) <= eta   and
+                        |got - ref|_2 <= 4 eta cond_2(M_ref) |ref|_2            (what omega <= eta implies, with slack 2)
+                        and |got|_2 <= (1 + 1e-3) |ref|_2 when the oracle resolved by a rank-dropping pseudo-inverse
+                        (a consistent singular system: the residual is blind to null-space components, the minimum norm is not)
+
+    B is the statement "got solves a system within relative eta of the oracle's": it is what fp32 leaves can promise a robot
+    whose metric is ill-conditioned or whose distances sit in the exp(-x / 0.01) regime, and it does not loosen with the
+    condition number -- the forward clause only states its consequence.  Returns dict(a, b, ok: bool arrays; omega, cond)."""
+    got = np.asarray(got, np.float64)
+    q_ref, M, f = ref["qdd64"], ref["M"], ref["f"]
+    err_inf = np.abs(got - q_ref).max(axis=1)
+    a = err_inf <= atol * np.maximum(1.0, np.abs(q_ref).max(axis=1))
+    finite = np.isfinite(got).all(axis=1) & np.isfinite(M).all(axis=(1, 2)) & np.isfinite(f).all(axis=1)
+    g = np.where(finite[:, None], got, 0.0)
+    Mz = np.where(finite[:, None, None], M, 0.0)
+    fz = np.where(finite[:, None], f, 0.0)
+    sv = np.linalg.svd(Mz, compute_uv=False)
+    res = np.linalg.norm(np.einsum("rij,rj->ri", Mz, g) - fz, axis=1)
+    scale = sv[:, 0] * np.linalg.norm(g, axis=1) + np.linalg.norm(fz, axis=1)
+    omega = np.where(scale > 0, res / np.where(scale > 0, scale, 1.0), 0.0)
+    # rank the oracle's own resolve kept (TF's cutoff, rmp.py:153-154: 10 n eps_f64 sigma_max)
+    n = M.shape[1]
+    cutoff = 10.0 * n * np.finfo(np.float64).eps * sv[:, 0]
+    kept = (sv > cutoff[:, None]).sum(axis=1)
+    smin = np.take_along_axis(sv, np.maximum(kept - 1, 0)[:, None], axis=1)[:, 0]
+    cond = np.where(smin > 0, sv[:, 0] / np.where(smin > 0, smin, 1.0), np.inf)
+    err2 = np.linalg.norm(g - np.where(finite[:, None], q_ref, 0.0), axis=1)
+    ref2 = np.linalg.norm(np.where(finite[:, None], q_ref, 0.0), axis=1)
+    fwd = err2 <= 4.0 * eta * cond * np.maximum(ref2, 1e-30)
+    minnorm = (kept == n) | (np.linalg.norm(g, axis=1) <= (1.0 + 1e-3) * ref2 + 1e-12)
+    b = finite & (omega <= eta) & fwd & minnorm
+    # a robot the oracle itself resolves to NaN (non-finite state): the engine must answer NaN too
+    both_nan = ~np.isfinite(q_ref).all(axis=1) & ~np.isfinite(got).all(axis=1)
+    return {"a": a, "b": b & ~a, "ok": a | b | both_nan, "both_nan": both_nan, "omega": omega, "cond": cond, "err_inf": err_inf}

@@ -67,6 +67,7 @@ def lib():
     l.rmp2_exchange_last_error.restype = C.c_char_p
     l.rmp2_exchange_last_error.argtypes = [C.c_void_p]
     l.rmp2_exchange_pending.argtypes = [C.c_void_p]
+    l.rmp2_exchange_nranks.argtypes = [C.c_void_p]
     l.rmp2_exchange_set_depth.argtypes = [C.c_void_p, C.c_int32]
     l.rmp2_exchange_set_peer_wait.argtypes = [C.c_void_p, C.c_int32]
     l.rmp2_exchange_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

@@ -2058,7 +2058,12 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   // keeps the stream-wait on the system-scope event, whose acquire is what makes those writes visible.
   if (!(seen_complete && x->world == 1 && !x->peer_wait))
     XCH_TRY(x, hipStreamWaitEvent(static_cast<hipStream_t>(stream), x->ready[b], 0));
-  if (next_local)
+  // The gather of the next table goes out BEFORE the launch (it then takes its few workgroups between two steps) -- unless
+  // it would land in the very buffer this step reads (depth + 1 gathers were outstanding, so x->next == b): its only
+  // ordering against a reader is reader_done[b], which THIS step has not signalled yet.  Then the step is launched first
+  // and the gather is issued behind this launch's completion signal (round-3 advisor finding: a torn table).
+  const bool gather_after = next_local && x->next == b;
+  if (next_local && !gather_after)
     if (int rc = rmp2_exchange_start(x, next_local, next_local_is_ready, stream)) return rc;
   rmp2_obstacles o;
   std::memset(&o, 0, sizeof(o));
@@ -2074,8 +2079,12 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   if (rc != RMP2_OK) return x->error = h->error, rc;
   x->reader_valid[b] = true;
   if (table_out) *table_out = x->table[b];
+  if (gather_after)
+    if (int rc2 = rmp2_exchange_start(x, next_local, next_local_is_ready, stream)) return rc2;
   return RMP2_OK;
 }
+
+int rmp2_exchange_nranks(const rmp2_exchange* x) { return x ? x->world : 0; }
 
 // Two engines, one launch (include/rmp2.h): the fused grid when an instantiation exists for the pair, else two launches.
 int rmp2_step_pair(rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int32_t gsa,

@@ -192,40 +192,77 @@ class NativeObstacleExchange:
         for k in ...: qdd = exch.step(engine, q, qd, goal, out, next_local=local_k_plus_1)
     """
 
-    def __init__(self, spheres_per_rank: int, device, group=None, depth: int = 1):
+    def __init__(self, spheres_per_rank: int, device, group=None, depth: int = 1, *, rank: Optional[int] = None,
+                 world: Optional[int] = None, uid: Optional[bytes] = None, rccl_library: Optional[str] = None):
+        """Collective over `group` (the default process group when one exists): rank 0 creates the RCCL unique id,
+        torch.distributed broadcasts it, every rank joins the communicator.
+        rank / world / uid (all three): join a communicator WITHOUT torch.distributed -- the caller ships the id (from
+        `NativeObstacleExchange.unique_id`) to the ranks itself, e.g. several ranks as threads of one process.
+        rccl_library: path of the collective library to bind (default: the librccl.so this process already uses)."""
         import ctypes
         from . import _native
         self._lib = _native.lib()
+        self._ctypes = ctypes
         self.device = torch.device(device)
         self.depth = int(depth)
         if self.device.type != "cuda":
             raise ValueError("NativeObstacleExchange needs a HIP device (the CPU test path uses ObstacleExchange)")
-        collective = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if collective else 1
-        self.rank = dist.get_rank(group) if collective else 0
         self.spheres_per_rank = int(spheres_per_rank)
-        path = rccl_library_path().encode()
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            buf = (ctypes.c_char * 128)()
-            rc = self._lib.rmp2_exchange_unique_id(path, buf)
-            if rc != 0:
-                raise _native.Rmp2Error("rmp2_exchange_unique_id: " + self._lib.rmp2_last_error(None).decode())
-            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        explicit = rank is not None or world is not None or uid is not None
+        if explicit and (rank is None or world is None or uid is None):
+            raise ValueError("rank, world and uid go together")
+        collective = not explicit and dist.is_available() and dist.is_initialized()
+        self.world = int(world) if explicit else (dist.get_world_size(group) if collective else 1)
+        self.rank = int(rank) if explicit else (dist.get_rank(group) if collective else 0)
+        # -- local part (may fail on one rank only): resolve the library, rank 0 creates the id --
+        local_error = None
+        try:
+            path = (rccl_library or rccl_library_path()).encode()
+            if not explicit and self.rank == 0:
+                uid = self.unique_id(path.decode())
+        except Exception as exc:   # noqa: BLE001 -- agreed on below, re-raised on every rank
+            local_error, path = exc, b""
         if collective and self.world > 1:
-            t = uid.to(self.device)
+            # every rank learns whether ALL ranks got this far BEFORE anyone enters a blocking collective on the id: a rank
+            # that raised here would otherwise leave its peers waiting in the broadcast / in ncclCommInitRank for ever
+            ok = torch.tensor([0 if local_error is not None else 1], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                raise _native.Rmp2Error("NativeObstacleExchange: a rank failed before the communicator was formed"
+                                        + (f" (this rank: {local_error})" if local_error is not None else " (another rank)"))
+            t = torch.frombuffer(bytearray(uid if self.rank == 0 else bytes(128)), dtype=torch.uint8).to(self.device)
             dist.broadcast(t, 0, group=group)
-            uid = t.cpu()
-        uid_buf = (ctypes.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+            uid = bytes(t.cpu().numpy().tobytes())
+        elif local_error is not None:
+            raise local_error
+        if len(uid) != 128:
+            raise ValueError("uid must be the 128 bytes of rmp2_exchange_unique_id")
+        uid_buf = (ctypes.c_char * 128).from_buffer_copy(bytes(uid))
         self._h = ctypes.c_void_p()
         rc = self._lib.rmp2_exchange_create(path, uid_buf, self.rank, self.world, self.device.index or 0,
                                             self.spheres_per_rank, ctypes.byref(self._h))
         if rc != 0:
             raise _native.Rmp2Error("rmp2_exchange_create: " + self._lib.rmp2_last_error(None).decode())
         self._table = ctypes.c_void_p()
-        self._ctypes = ctypes
         if self.depth != 1:   # (depth + 1 gathers outstanding: include/rmp2.h rmp2_exchange_set_depth)
             self._check(self._lib.rmp2_exchange_set_depth(self._h, self.depth))
+
+    @staticmethod
+    def unique_id(rccl_library: Optional[str] = None) -> bytes:
+        """The 128 bytes of a fresh communicator id (rmp2_exchange_unique_id): rank 0 creates it, every rank joins on it."""
+        import ctypes
+        from . import _native
+        lib = _native.lib()
+        buf = (ctypes.c_char * 128)()
+        rc = lib.rmp2_exchange_unique_id((rccl_library or rccl_library_path()).encode(), buf)
+        if rc != 0:
+            raise _native.Rmp2Error("rmp2_exchange_unique_id: " + lib.rmp2_last_error(None).decode())
+        return bytes(buf)
+
+    @property
+    def nranks(self) -> int:
+        """Ranks of the communicator the library joined (from the exchange object, not from the launcher's environment)."""
+        return int(self._lib.rmp2_exchange_nranks(self._h))
 
     def _check(self, rc):
         if rc != 0:
@@ -284,6 +321,29 @@ class NativeObstacleExchange:
             self.close()
         except Exception:
             pass
+
+
+def agree_on_exchange(make, world: int, device=None, group=None):
+    """Every rank calls `make()` (e.g. the NativeObstacleExchange constructor); the ranks then agree (all-reduce MIN over
+    `group`) on whether ALL of them succeeded.  Returns (exchange, None) on every rank if so; otherwise (None, error) on
+    every rank -- a rank whose own `make()` succeeded closes what it built and reports the peers' failure --, so that no rank
+    falls back to another exchange alone and leaves its peers waiting in a collective."""
+    exch, err = None, None
+    try:
+        exch = make()
+    except Exception as e:   # noqa: BLE001 -- whatever kept this rank from building its exchange is agreed on below
+        err = e
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        if exch is not None:
+            try:
+                exch.close()
+            finally:
+                exch = None
+        return None, err if err is not None else RuntimeError("another rank could not build its exchange")
+    return exch, None
 
 
 class Fleet:
