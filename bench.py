@@ -492,23 +492,35 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
     return one_step, eng, desc, table, s, spheres_np, keep
 
 
-def check_against_oracle(desc, s, spheres_np, out, n=256, what="", pairs=None):
-    """Result check of a bench workload (outside every timed region): the first n robots against the CPU oracle.
-    pairs = (p_link, p_obs) device tensors: the oracle reads the same explicit pairs (interface B)."""
+TOLERANCE_RULE = ("every checked robot must pass one of: (A) |qdd - oracle|_inf <= 1e-5 * max(1, |oracle|_inf) [north star]; "
+                  "(B) normwise backward error against the oracle's system (M, f) <= 1e-4, with the forward bound it implies and the "
+                  "minimum-norm check for rank-dropping resolves; (C) |qdd - oracle|_inf <= 8 x the robot's fp32 resolution (response of "
+                  "the fp64 result to one unit-scale fp32 rounding of every input, or the reference-precision oracle's own distance from "
+                  "its fp64 evaluation) -- oracle/oracle.py accuracy_gate; no robot is exempted, none may fail")
+
+
+def check_against_oracle(desc, s, spheres_np, out, n=256, what="", pairs=None, extra_kw=None):
+    """Result check of a bench workload (outside every timed region): the first n robots against the CPU oracle -- a smoke alarm
+    on the buffers the timed steps wrote, not the parity statement (tests/ is).  pairs = (p_link, p_obs) device tensors: the
+    oracle reads the same explicit pairs (interface B).  extra_kw: further oracle arguments (ragged lists)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     kw = dict(spheres=spheres_np) if spheres_np is not None else {}
     if pairs is not None:
         kw = dict(p_link=pairs[0][:n].cpu().numpy(), p_obs=pairs[1][:n].cpu().numpy())
-    ref = O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], **kw)["qdd64"]
+    kw.update(extra_kw or {})
+    ref = O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], **kw)
     got = out[:n].cpu().numpy()
-    err = np.abs(got - ref).max(axis=1)
-    # perf inputs are unrestricted (SURVEY 8(d)): near-contact robots carry |qdd| of 1e2..1e3, where the relative bound applies
-    ok = (err <= 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))) | (err <= 1e-3 * np.abs(ref).max(axis=1))
-    if not (np.isfinite(got).all() and ok.mean() >= 0.97):
-        raise SystemExit(f"bench.py: {what} result check FAILED against the oracle: worst {err.max():.3e}, {(~ok).sum()} of {n} out")
-    return {"robots_checked": int(n), "max_abs_err": float(err.max()), "within_tolerance": int(ok.sum())}
+    # perf inputs are unrestricted (SURVEY 8(d)): near-contact robots carry |qdd| of 1e2..1e3 -- they are bounded by (B) / (C)
+    verdict = O.accuracy_gate(got, ref, spread=O.fp32_resolution(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], **kw))
+    summary = O.gate_summary(verdict)
+    if not verdict["ok"].all():
+        raise SystemExit(f"bench.py: {what} result check FAILED against the oracle: {summary}")
+    return {"robots_checked": int(n), "max_abs_err": summary["worst_abs_err"], "admitted_by": {
+        "A_north_star_1e-5": summary["north_star_1e-5"], "B_backward_error_1e-4": summary["backward_error"],
+        "C_fp32_resolution_x8": summary["input_resolution"], "nan_in_oracle_and_engine": summary["both_nan"]},
+        "rejected": summary["rejected"], "tolerance": TOLERANCE_RULE}
 
 
 def emulate_world(args, workload, dev, local_rank, use_dist):
@@ -681,6 +693,13 @@ def worker(args) -> int:
         # result check, outside the timed region: the buffers the timed steps wrote, against the oracle
         line_extra["result_check"] = check_against_oracle(desc, s, spheres_np, keep[3], what=workload,
                                                           pairs=(keep[4], keep[5]) if workload in ("config3b", "config3l") else None)
+        if workload == "config4":
+            ex = next(k for k in keep if hasattr(k, "start") and hasattr(k, "world"))
+            line_extra["exchange"] = args.exchange
+            # from the communicator the exchange joined (the library's own for the native exchange, c10d's otherwise), not from
+            # WORLD_SIZE: the driver can hold it against --gpus
+            line_extra["rccl_nranks"] = int(ex.nranks) if args.exchange == "native" else int(dist.get_world_size())
+            line_extra["exchange_depth"] = int(args.exchange_depth) if args.exchange == "native" else 1
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
         kernel_name = eng.last_kernel() + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)"
@@ -712,6 +731,18 @@ def worker(args) -> int:
         # the dominant kernel (the Panda engine's) timed on its own right after the timed region, same buffers
         kk = Timed(dev, False).run(shard.step_dominant, min(args.steps, 200), 10)
         kern.update(kernel_ms=kk["kernel_ms"], grp=kk["grp"], raw_ms=kk["raw_ms"], floor_ms=kk["floor_ms"])
+        # result check of BOTH robot types of this rank's shard (outside the timed region), ragged lists and all
+        chk = {}
+        for key, part in shard.parts.items():
+            pq, pqd, pgoal, _ = part["keep"]
+            m = min(256, part["n"])
+            off = part["host"]["csr_offset"][: m + 1]
+            host = {"q": pq[:m].cpu().numpy(), "qd": pqd[:m].cpu().numpy(), "goal": pgoal[:m].cpu().numpy()}
+            chk[key] = check_against_oracle(part["desc"], host, part["host"]["spheres"], part["out"], n=m, what=f"config5 {key}",
+                                            extra_kw=dict(csr_offset=off, csr_index=part["host"]["csr_index"][: off[-1]]))
+            chk[key].pop("tolerance")
+        chk["tolerance"] = TOLERANCE_RULE
+        line_extra["result_check"] = chk
         per_launch_bytes, per_launch_flops = shard.dominant_bytes, shard.dominant_flops
         bytes_rs = per_launch_bytes / max(shard.dominant_robots, 1)
         flops_rs = per_launch_flops / max(shard.dominant_robots, 1)
@@ -794,9 +825,9 @@ def main():
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="config4: obstacle exchange inside librmp2_hip.so (one C-ABI call per step) or driven from Python "
                          "through torch.distributed (A/B)")
-    ap.add_argument("--exchange-depth", type=int, default=2, choices=[1, 2],
-                    help="config4, native exchange: tables gathered this many control steps ahead (2: a full step of slack "
-                         "for the gather, one more step of obstacle staleness)")
+    ap.add_argument("--exchange-depth", type=int, default=1, choices=[1, 2],
+                    help="config4, native exchange: tables gathered this many control steps ahead (1: every step reads obstacles "
+                         "one control step old, as the reference's loop does; 2: one more step of staleness)")
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--rank-timeout", type=float, default=540.0,
                     help="--gpus N without a launcher: seconds after which ranks that are still running are ended and the job fails")

@@ -187,6 +187,9 @@ typedef struct rmp2_obstacles {
 #define RMP2_STATUS_NONFINITE 1u /* qdd contains NaN/Inf (e.g. JointVelocityCap pole, quirk Q4) */
 #define RMP2_STATUS_RANK_DROP 2u /* the pseudo-inverse dropped at least one singular value  */
 #define RMP2_STATUS_PINV_PATH 4u /* AUTO mode: this robot was resolved on the PINV path      */
+#define RMP2_STATUS_JACOBI 8u    /* PINV mode, certifying step (symmetric sets with an inertia leaf): the elimination could not
+                                  * certify this robot's metric as full rank above TensorFlow's cutoff, so it was resolved by the
+                                  * Jacobi pseudo-inverse instead of by the elimination (same result where both apply; diagnostic) */
 
 typedef struct rmp2_outputs {
   float *qdd;       /* device [R][n_dof]                      required                     */
@@ -228,6 +231,9 @@ int rmp2_validate(const rmp2_desc *desc);
  *   RMP2_QUAD_MINW  = 2 | 3 | 4           register cap of the quad mapping's throughput build (waves per SIMD it leaves room for)
  *   RMP2_QUAD_SYM   = 0                   general (full-matrix) form of the quad mapping for sets that qualify for the symmetric one
  *   RMP2_EXCHANGE_THROTTLE_US = n         (rmp2_exchange_create) bound of the host throttle of rmp2_exchange_step, 0 = free-running
+ *   RMP2_EXCHANGE_BUFFERS = 2 | 3         (rmp2_exchange_create) table buffers in rotation: 3 (default), or depth + 1
+ *   RMP2_STRICT_CERTIFY = 0               (rmp2_create) solve = PINV: the Jacobi pseudo-inverse on EVERY robot (two kernels) instead of
+ *                                         the certifying one-launch step -- the A/B the equality test of the two is built on
  * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with
  * -DRMP2_TUNING (tools/); the shipped library ignores them.  A deployment should leave all of them unset. */
 
@@ -283,11 +289,14 @@ const char *rmp2_exchange_last_error(const rmp2_exchange *x);
 int rmp2_exchange_pending(const rmp2_exchange *x);
 /* Ranks of the communicator this exchange was created on (what ncclCommInitRank was given and joined; 0 for NULL). */
 int rmp2_exchange_nranks(const rmp2_exchange *x);
-/* Pipeline depth (before the first rmp2_exchange_start): depth + 1 gathers may be outstanding, depth + 1 table buffers are
- * in use.  1 (default): the table of step k is gathered while step k - 1 runs, from slices produced before step k - 1 was
- * issued.  2: gathered while steps k - 2 and k - 1 run -- one more control step of obstacle staleness, and a full step of
- * slack for the gather: it only gets a CU when waves of the running step retire (the step kernel fills every SIMD), so at
- * depth 1 the next step regularly waits for it. */
+/* Pipeline depth (before the first rmp2_exchange_start): depth + 1 gathers may be outstanding.  1 (default): the table of step
+ * k is gathered from slices produced before step k - 1 was issued -- the obstacles a step sees are ONE control step old, as in
+ * the reference's loop, which re-reads the obstacle data every control step (06_cluttered_environment.py:120-131).  2: one more
+ * control step of staleness and one more step of slack for the gather.  THREE table buffers rotate at either depth: the gather
+ * for step k + 1, issued with the launch of step k, lands in a buffer whose last reader was step k - 2 -- long complete -- and so
+ * starts at once and has a whole step to find a CU beside the running kernel (which fills every SIMD; with two buffers it had
+ * to wait for step k - 1 and regularly made step k + 1 wait: 49.7 against 41.6 us per step at 65 536 robots,
+ * profiles/r04_exchange_timing.txt).  RMP2_EXCHANGE_BUFFERS=2 (diagnostic) restores depth + 1 buffers. */
 int rmp2_exchange_set_depth(rmp2_exchange *x, int32_t depth);   /* gathers started and not yet consumed by a step (0 .. 2) */
 /* on != 0: a one-rank exchange orders its steps as an N-rank one does (GPU-side wait on the gathered table kept): what a
  * single-GPU EMULATION of an N-rank run must time.  No effect at nranks > 1 (the wait is always kept there). */

@@ -173,27 +173,70 @@ def pinv_solve(M, f):
     return x, dropped
 
 
-def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5):
+def ulp_spread(desc: D.Desc, q, qd, goal=None, trials: int = 4, seed: int = 0, **obstacle_kwargs):
+    """Per robot: how far q-double-dot (fp64 evaluation) moves when every fp32 input -- q, qd, goal, sphere / capsule table,
+    explicit pairs -- moves by one fp32 rounding at UNIT scale, `a -> a + s * 2^-23 * max(|a|, 1)` with a random sign s per
+    element (an ulp of the value, but at least an ulp of 1.0: the intermediates of the kinematic chain -- sines, cosines,
+    positions in metres -- live at unit scale whatever the magnitude of the joint angle); the maximum over `trials` draws,
+    inf-norm.  It is the resolution fp32 gives the result, whatever amplifies it (cond(M), exp(-x / 0.01) near contact, 1 / x^2
+    repulsion): no fp32 evaluation of the reference algorithm, TensorFlow's included, can promise a robot more than a small
+    multiple of it."""
+    rng = np.random.default_rng(seed)
+    eps = np.float64(2.0 ** -23)
+
+    def jiggle(a):
+        a = np.ascontiguousarray(a, dtype=np.float32).astype(np.float64)
+        return (a + rng.choice(np.array([-1.0, 1.0]), a.shape) * eps * np.maximum(np.abs(a), 1.0)).astype(np.float32)
+
+    base = step(desc, q, qd, goal, precision="f64", **obstacle_kwargs)["qdd64"]
+    spread = np.zeros(len(base))
+    for _ in range(trials):
+        kw = {k: (jiggle(v) if k in ("spheres", "p_link", "p_obs", "dist") and v is not None else v) for k, v in obstacle_kwargs.items()}
+        r = step(desc, jiggle(q), jiggle(qd), None if goal is None else jiggle(goal), precision="f64", **kw)["qdd64"]
+        with np.errstate(invalid="ignore"):
+            spread = np.fmax(spread, np.abs(r - base).max(axis=1))
+    return spread
+
+
+def fp32_resolution(desc: D.Desc, q, qd, goal=None, trials: int = 4, seed: int = 0, **obstacle_kwargs):
+    """What fp32 can resolve of a robot's q-double-dot: the larger of ulp_spread (response of the exact result to one
+    unit-scale fp32 rounding of every input) and the distance of this oracle's own REFERENCE-PRECISION evaluation (fp32 leaves,
+    fp64 sum and resolve: rmp.py:133-155) from its fp64 evaluation.  The `spread` argument of accuracy_gate."""
+    sp = ulp_spread(desc, q, qd, goal, trials=trials, seed=seed, **obstacle_kwargs)
+    a = step(desc, q, qd, goal, precision="f32", **obstacle_kwargs)["qdd64"]
+    b = step(desc, q, qd, goal, precision="f64", **obstacle_kwargs)["qdd64"]
+    with np.errstate(invalid="ignore"):
+        return np.fmax(sp, np.abs(a - b).max(axis=1))
+
+
+def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, spread_factor: float = 8.0):
     """Per-robot accuracy verdict of a computed q-double-dot `got` [R, n] against an oracle result `ref` (the dict of step()).
-    EVERY robot gets a bound -- none is exempted for being ill-conditioned:
+    EVERY robot gets a bound -- none is exempted for being ill-conditioned or near contact:
 
       A  (north star)   |got - ref|_inf <= atol * max(1, |ref|_inf)
       B  (backward)     omega = |M_ref got - f_ref|_2 / (|M_ref|_2 |got|_2 + |f_ref|_2) <= eta   and
                         |got - ref|_2 <= 4 eta cond_2(M_ref) |ref|_2            (what omega <= eta implies, with slack 2)
                         and |got|_2 <= (1 + 1e-3) |ref|_2 when the oracle resolved by a rank-dropping pseudo-inverse
                         (a consistent singular system: the residual is blind to null-space components, the minimum norm is not)
+      C  (fp32 resolution, only when `spread` = fp32_resolution(...) of the same robots is given)
+                        |got - ref|_inf <= spread_factor * spread : within a few times what one fp32 rounding does to the
+                        exact result / what the reference-precision oracle itself misses the fp64 result by
 
     B is the statement "got solves a system within relative eta of the oracle's": it is what fp32 leaves can promise a robot
-    whose metric is ill-conditioned or whose distances sit in the exp(-x / 0.01) regime, and it does not loosen with the
-    condition number -- the forward clause only states its consequence.  Returns dict(a, b, ok: bool arrays; omega, cond)."""
+    whose metric is ill-conditioned, and it does not loosen with the condition number -- the forward clause only states its
+    consequence.  C covers the robots whose SYSTEM is sensitive (distances of millimetres: an ulp of a position is 1e-4 of the
+    distance, and the leaf differentiates exp(-x / 0.01) and 1 / x^2 of it).  Returns dict(a, b, c, ok: bool arrays -- b
+    excludes a, c excludes both --; omega, cond, err_inf)."""
     got = np.asarray(got, np.float64)
     q_ref, M, f = ref["qdd64"], ref["M"], ref["f"]
-    err_inf = np.abs(got - q_ref).max(axis=1)
-    a = err_inf <= atol * np.maximum(1.0, np.abs(q_ref).max(axis=1))
-    finite = np.isfinite(got).all(axis=1) & np.isfinite(M).all(axis=(1, 2)) & np.isfinite(f).all(axis=1)
+    with np.errstate(invalid="ignore"):
+        err_inf = np.abs(got - q_ref).max(axis=1)
+        a = err_inf <= atol * np.maximum(1.0, np.abs(q_ref).max(axis=1))
+    finite = np.isfinite(got).all(axis=1) & np.isfinite(M).all(axis=(1, 2)) & np.isfinite(f).all(axis=1) & np.isfinite(q_ref).all(axis=1)
     g = np.where(finite[:, None], got, 0.0)
     Mz = np.where(finite[:, None, None], M, 0.0)
     fz = np.where(finite[:, None], f, 0.0)
+    qz = np.where(finite[:, None], q_ref, 0.0)
     sv = np.linalg.svd(Mz, compute_uv=False)
     res = np.linalg.norm(np.einsum("rij,rj->ri", Mz, g) - fz, axis=1)
     scale = sv[:, 0] * np.linalg.norm(g, axis=1) + np.linalg.norm(fz, axis=1)
@@ -204,11 +247,23 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5):
     kept = (sv > cutoff[:, None]).sum(axis=1)
     smin = np.take_along_axis(sv, np.maximum(kept - 1, 0)[:, None], axis=1)[:, 0]
     cond = np.where(smin > 0, sv[:, 0] / np.where(smin > 0, smin, 1.0), np.inf)
-    err2 = np.linalg.norm(g - np.where(finite[:, None], q_ref, 0.0), axis=1)
-    ref2 = np.linalg.norm(np.where(finite[:, None], q_ref, 0.0), axis=1)
+    err2 = np.linalg.norm(g - qz, axis=1)
+    ref2 = np.linalg.norm(qz, axis=1)
     fwd = err2 <= 4.0 * eta * cond * np.maximum(ref2, 1e-30)
     minnorm = (kept == n) | (np.linalg.norm(g, axis=1) <= (1.0 + 1e-3) * ref2 + 1e-12)
     b = finite & (omega <= eta) & fwd & minnorm
+    c = np.zeros(len(got), bool)
+    if spread is not None:
+        c = finite & (err_inf <= spread_factor * np.asarray(spread))
     # a robot the oracle itself resolves to NaN (non-finite state): the engine must answer NaN too
     both_nan = ~np.isfinite(q_ref).all(axis=1) & ~np.isfinite(got).all(axis=1)
-    return {"a": a, "b": b & ~a, "ok": a | b | both_nan, "both_nan": both_nan, "omega": omega, "cond": cond, "err_inf": err_inf}
+    return {"a": a, "b": b & ~a, "c": c & ~a & ~b, "ok": a | b | c | both_nan, "both_nan": both_nan, "omega": omega, "cond": cond,
+            "err_inf": err_inf}
+
+
+def gate_summary(g) -> dict:
+    """Counts per admitting branch of an accuracy_gate verdict (for assertion messages and bench.py's result_check)."""
+    return {"robots": int(len(g["ok"])), "north_star_1e-5": int(g["a"].sum()), "backward_error": int(g["b"].sum()),
+            "input_resolution": int(g["c"].sum()), "both_nan": int((g["both_nan"] & ~g["a"]).sum()), "rejected": int((~g["ok"]).sum()),
+            "worst_abs_err": float(np.nanmax(g["err_inf"])) if len(g["err_inf"]) else 0.0,
+            "worst_omega_beyond_north_star": float(g["omega"][~g["a"]].max()) if (~g["a"]).any() else 0.0}

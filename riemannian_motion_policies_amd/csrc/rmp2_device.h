@@ -427,6 +427,42 @@ __device__ __forceinline__ void leaf_collision_avoidance(const float* P, float d
   wgt = d > r ? 0.f : spline;
 }
 
+// Datamanager fields of ONE (link capsule, primitive) pair for the attached-point leaves, formed on the device (the reference
+// takes them from PyBullet's closest points every control step, simulation.py:462-484 / data_management.py:22-53): world link
+// axis LA + s LD (laa = |LD|^2, inv_laa its reciprocal or 0, radius lrad), primitive record ca (a.xyz, radius) and cb (b.xyz;
+// = ca for a sphere).  X, Y = nearest points of the two axes (the clamped 2 x 2 normal equations, segment_segment's cases,
+// branch-free); p_link = X - lrad n, p_obs = Y + r n with n = (X - Y) / |X - Y|; out:
+//   dd = |p_link - p_obs|, nv = (p_link - p_obs) / dd, r = p_link - P3 (= R relative_position, the attached point's lever arm).
+// Overlapping shapes: the points have crossed, the distance reads positive and the normal flips (as the explicit arrays would).
+__device__ __forceinline__ void link_pair_fields(const float LA[3], const float LD[3], float laa, float inv_laa, float lrad,
+                                                 const float4 ca, const float4 cb, const float P3[3], float r[3], float nv[3],
+                                                 float& dd) {
+  const float d2v[3] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
+  const float rr[3] = {LA[0] - ca.x, LA[1] - ca.y, LA[2] - ca.z};
+  const float ee = dot3(d2v, d2v), ff = dot3(d2v, rr), cc = dot3(LD, rr), bb = dot3(LD, d2v);
+  const float inv_e = ee > 0.f ? 1.0f / ee : 0.f;
+  const float den = fmaf(laa, ee, -bb * bb);
+  const float s0 = (den > 0.f && laa > 0.f) ? fminf(fmaxf(fmaf(bb, ff, -cc * ee) / den, 0.f), 1.f) : 0.f;
+  const float t0 = fmaf(bb, s0, ff) * inv_e;
+  const float s_lo = fminf(fmaxf(-cc * inv_laa, 0.f), 1.f), s_hi = fminf(fmaxf((bb - cc) * inv_laa, 0.f), 1.f);
+  const float sl = (t0 < 0.f || !(ee > 0.f)) ? s_lo : (t0 > 1.f ? s_hi : s0);
+  const float to = fminf(fmaxf(t0, 0.f), 1.f);
+  float X[3], diff[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) X[c] = fmaf(sl, LD[c], LA[c]);
+  diff[0] = X[0] - fmaf(to, d2v[0], ca.x), diff[1] = X[1] - fmaf(to, d2v[1], ca.y), diff[2] = X[2] - fmaf(to, d2v[2], ca.z);
+  const float dn = sqrtf(dot3(diff, diff));
+  const float inv0 = 1.0f / dn;
+  const float sgap = dn - ca.w - lrad;
+  dd = fabsf(sgap);
+  const float inv = copysignf(inv0, sgap);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    nv[c] = diff[c] * inv;
+    r[c] = (X[c] - lrad * (diff[c] * inv0)) - P3[c];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void pull_position(const float (&col)[N][3], uint32_t active, const float S[6],
                                               const float h[3], double (&Ms)[N * (N + 1) / 2], double (&fv)[N]) {

@@ -709,9 +709,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position], one trip per pair (taskmap.py:79-99):
         //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J = Jacobian at x;  pulled back pair by
         //   pair (rmp.py:165-167 with B pairs on the batch axis); every lane of the robot forms the small vectors
+        // (the pairs' fields from the caller's arrays -- or formed here, per control step, from the primitive table and the
+        // leaf's link capsule: obs.link_caps, as in rmp2_quad.h; that form can roll out)
+        const bool from_table = obs.link_caps != nullptr;  // (wave-uniform)
         const int lidx = uni<true>(lf.index);
-        const int pb = obs.pair_begin[lidx];
-        const int cnt = obs.pair_begin[lidx + 1] - pb;
+        const int pb = from_table ? 0 : obs.pair_begin[lidx];
+        const int cnt = from_table ? obs.n_spheres : obs.pair_begin[lidx + 1] - pb;
         const size_t pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
         const float4* t4 = reinterpret_cast<const float4*>(TW + k * 12);
         const float4 r0 = t4[0], r1 = t4[1];
@@ -719,17 +722,36 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         const float4* wa4 = reinterpret_cast<const float4*>(WAb + g * hex_pad(n_ops * 8) + k * 8);
         const float4 w0 = wa4[0], w1 = wa4[1];
         const float Wf[3] = {w0.x, w0.y, w0.z}, ALf[3] = {w0.w, w1.x, w1.y};
-#pragma nounroll
-        for (int trip = 0; trip < cnt; ++trip) {
-          const float* rel = obs.p_link + (pbase + trip) * 3;
-          const float* nvp = obs.p_obs + (pbase + trip) * 3;
-          const float dd = obs.dist[pbase + trip];
-          float r[3], pt[3], t1[3], t2[3], xdp[3], cp[3];
+        float LA[3] = {0.f, 0.f, 0.f}, LD[3] = {0.f, 0.f, 0.f}, lrad = 0.f, laa = 0.f, inv_laa = 0.f;
+        if (from_table) {
+          const float* lc = obs.link_caps + 8 * uni<true>(lf.dist_ordinal);
+          lrad = lc[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            r[c] = Rw[3 * c] * rel[0] + Rw[3 * c + 1] * rel[1] + Rw[3 * c + 2] * rel[2];
-            pt[c] = P3[c] + r[c];
+            LA[c] = P3[c] + Rw[3 * c] * lc[0] + Rw[3 * c + 1] * lc[1] + Rw[3 * c + 2] * lc[2];
+            LD[c] = Rw[3 * c] * (lc[4] - lc[0]) + Rw[3 * c + 1] * (lc[5] - lc[1]) + Rw[3 * c + 2] * (lc[6] - lc[2]);
           }
+          laa = dot3(LD, LD);
+          inv_laa = laa > 0.f ? 1.0f / laa : 0.f;
+        }
+#pragma nounroll
+        for (int trip = 0; trip < cnt; ++trip) {
+          float r[3], nv[3], dd, pt[3], t1[3], t2[3], xdp[3], cp[3];
+          if (from_table) {
+            const float4* rec = reinterpret_cast<const float4*>(step_table) + (obs.capsule ? 2 * trip : trip);
+            const float4 ca = rec[0];
+            const float4 cb = obs.capsule ? rec[1] : ca;
+            link_pair_fields(LA, LD, laa, inv_laa, lrad, ca, cb, P3, r, nv, dd);
+          } else {
+            const float* rel = obs.p_link + (pbase + trip) * 3;
+            const float* nvp = obs.p_obs + (pbase + trip) * 3;
+            dd = obs.dist[pbase + trip];
+            nv[0] = nvp[0], nv[1] = nvp[1], nv[2] = nvp[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = Rw[3 * c] * rel[0] + Rw[3 * c + 1] * rel[1] + Rw[3 * c + 2] * rel[2];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pt[c] = P3[c] + r[c];
           cross3(Wf, r, t1);
 #pragma unroll
           for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
@@ -737,7 +759,6 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
           cross3(ALf, r, t1);
 #pragma unroll
           for (int c = 0; c < 3; ++c) cp[c] = A3[c] + t1[c] + t2[c];
-          const float nv[3] = {nvp[0], nvp[1], nvp[2]};
           float xdd[3], wgt;
           leaf_collision_avoidance(lh.P, dd, nv, xdp, xdd, wgt);
           S[0] = S[3] = S[5] = wgt;

@@ -35,8 +35,8 @@ bool launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
     RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave * WAVES), bytes, s, blob, h->hex_blob16, hdr, q, qd, goal, gs, o, out, \
                      ro, R);                                                                                              \
   } while (0)
-  if (!ROLL && h->has_point)  // attached-point leaves (rollouts refuse them upstream; capsule tables: sphere modes only)
-    RMP2_HEX_LAUNCH(false, true);
+  if (h->has_point)  // attached-point leaves (they roll out when their pairs come from a table + link capsules, which they read
+    RMP2_HEX_LAUNCH(false, true);  // from global memory: spheres or capsules alike, so the sphere-mode build serves both)
   else if (o.capsule)
     RMP2_HEX_LAUNCH(true, false);
   else

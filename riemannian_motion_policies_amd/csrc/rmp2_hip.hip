@@ -639,6 +639,19 @@ rmp2_pinv_kernel(const double* __restrict__ M, const double* __restrict__ f, flo
   if (status_out) status_out[robot] = status;
 }
 
+// Debug outputs of the two-kernel strict step: the combined systems sit robot-index-FASTEST in the handle's buffer (what the
+// two kernels exchange); the caller's M [R][n][n] and f [R][n] are robot-index-slowest.
+__global__ void __launch_bounds__(kWave)
+rmp2_system_copy_kernel(const double* __restrict__ Ms, const double* __restrict__ fs, double* __restrict__ M, double* __restrict__ f,
+                        int n, int R) {
+  const int robot = blockIdx.x * kWave + threadIdx.x;
+  if (robot >= R) return;
+  for (int e = 0; e < n * n; ++e)
+    if (M) M[(size_t)robot * n * n + e] = Ms[(size_t)e * R + robot];
+  for (int i = 0; i < n; ++i)
+    if (f) f[(size_t)robot * n + i] = fs[(size_t)i * R + robot];
+}
+
 // Closest-point stage on its own: control point = frame origin of each distance leaf, nearest surface
 // point of every primitive of the shared table (simulation.py:462-484 calculate_distances; lane per robot).
 template <int SLOTS>
@@ -1293,7 +1306,8 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     t.frame = s.frame;
     t.goal_offset = s.goal_offset;
     t.index = l;
-    t.dist_ordinal = s.taskmap == RMP2_TASKMAP_FK_DISTANCE ? n_dist++ : -1;
+    // (row of rmp2_obstacles.link_capsules: the leaves that consume per-pair obstacle data, in descriptor order)
+    t.dist_ordinal = (s.taskmap == RMP2_TASKMAP_FK_DISTANCE || s.taskmap == RMP2_TASKMAP_FK_POINT) ? n_dist++ : -1;
     std::memcpy(t.P, s.params, sizeof(t.P));
     std::memcpy(t.va, s.vec_a, sizeof(t.va));
     std::memcpy(t.vb, s.vec_b, sizeof(t.vb));
@@ -1410,14 +1424,23 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // ... except on 2-dof robots, where the fall-through of a flagged robot is a 2 x 2 Jacobi: there the elimination
   // mappings (with their split pair loops and culling) keep sets without an inertia leaf, e.g. the TwoJoint half of the
   // mixed fleet (config 5)
-  const bool cheap_fallthrough = N == 2 && !h->strict;
-  if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough) {
+  // (a strict 2-dof handle forced onto the quad mapping is served too: its closed-form 2 x 2 resolve IS the pseudo-inverse)
+  const bool cheap_fallthrough = N == 2 && (!h->strict || h->kernel_choice == 2);
+  // solve = PINV on a set whose metric is symmetric and carries an inertia leaf: the quad mapping's elimination CERTIFIES full
+  // rank per robot (rmp2_quad.h, hdr.strict) -- where every singular value lies above TensorFlow's cutoff pinv(M) IS inv(M) --
+  // and only uncertified robots take the Jacobi pseudo-inverse (its careful pass).  One launch, the AUTO step's cost, the
+  // reference's semantics; at every fleet size and inside the fused rollout.
+  const bool quad_certifies = quad_certifies_strict(h) && N == 9 && h->kernel_choice != 1 && !hex_forced;
+  // (link geometry inside the step exists in the quad mapping only: such calls go there, flagged robots through its careful pass)
+  if ((h->strict || h->likely_singular) && !rollout && !hex_forced && !cheap_fallthrough && !quad_certifies && !o.link_caps) {
     // Two kernels -- the quad mapping up to the combined metric and force (its pair loops are culled and split four ways;
     // the latency build for small grids), then rmp2_pinv_kernel, a lane per robot.  The lane-per-robot step kernel with the
     // same resolve keeps what the quad mapping does not carry (attached-point leaves, debug outputs, RMP2_KERNEL=lane).
     // (a caller who asks for the combined metric / force -- debug outputs, robot index slowest -- gets the lane kernel)
-    if (N == 9 && h->kernel_choice == 0 && h->d_system && (size_t)R <= h->system_robots && h->goal_floats <= 16 && !h->has_point &&
-        !o.link_caps && !out.M && !out.f) {
+    // (attached-point sets included: their quad builds stop behind the combined system like the others; RMP2_KERNEL=quad asks
+    // for exactly this path; debug outputs are copied out of the exchange buffer afterwards)
+    if (N == 9 && (h->kernel_choice == 0 || h->kernel_choice == 2) && h->d_system && (size_t)R <= h->system_robots &&
+        h->goal_floats <= 16 && !o.link_caps) {
       const int n = h->n_dof;
       OutArgs o2 = out;
       o2.M = h->d_system;                       // [n * n][R], robot index fastest
@@ -1436,6 +1459,8 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
       hm->quad_skip_resolve = false;
       hm->step_fence = fence;
       if (ok) {
+        if (out.M || out.f)
+          hipLaunchKernelGGL(rmp2_system_copy_kernel, dim3((R + kWave - 1) / kWave), dim3(kWave), 0, s, o2.M, o2.f, out.M, out.f, n, R);
         RMP2_STEP_LAUNCH(h, (rmp2_pinv_kernel<9>), dim3((R + kWave - 1) / kWave), dim3(kWave), 0, s, o2.M, o2.f, out.qdd, out.status, n, R);
         h->last_kernel = "rmp2_step_quad_kernel up to (M, f) + rmp2_pinv_kernel (one lane per robot, Jacobi pseudo-inverse)";
         return RMP2_OK;
@@ -1452,7 +1477,9 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   //    pseudo-inverse (register-resident Jacobi) and attached-point leaves at any fleet size.
   // hex carries every leaf kind and both resolves (strict: the pseudo-inverse on every robot through its careful path;
   // slower than the lane kernel's register-resident Jacobi, so that path is taken on request / for n_dof > 9 only)
-  const bool hex_ok = h->goal_floats <= 16 && !(h->has_point && rollout) && !o.link_caps;  // (link geometry: quad mapping only)
+  // (link geometry of distance leaves: quad mapping only; attached-point leaves fed from a table + link capsules: hex too, for
+  // sets without distance leaves -- its attached-point build stages no capsule table)
+  const bool hex_ok = h->goal_floats <= 16 && (!o.link_caps || (h->has_point && !h->has_distance));
   // measured (bench.py, us per step, round 2 kernels; profiles/r02_dispatch_sweep.txt):
   //   cluttered set (config 3)   R:  4096   8192  10240  16384  20480  32768
   //     hex                         19.0   22.2   36.6   42.2   55.4   81.3
@@ -1477,11 +1504,12 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   const int hex_max = h->has_point ? 0 : 8192;
   // the fused rollout of a solve = PINV handle (the reference's only resolve, rmp.py:153-154, inside the closed loop): the hex
   // mapping carries the strict pseudo-inverse through its careful path at any fleet size
-  const bool strict_rollout = h->strict && rollout;
-  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max)) &&
+  const bool strict_rollout = h->strict && rollout && !quad_certifies;
+  // (a certifying strict handle skips the hex mapping, whose strict form is the pseudo-inverse of EVERY robot in its careful path)
+  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max && !quad_certifies)) &&
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
-  if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (the quad mapping's resolve is AUTO: never a silent change of semantics)
+  if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (an uncertifying quad resolve would be AUTO: never a silent change of semantics)
   // (attached-point leaves: hex up to 20 480 robots, the quad mapping beyond -- round 3; the lane mapping on request)
   const bool lane = !rollout && !o.link_caps && (h->kernel_choice == 1 ||
                                  (h->kernel_choice == 0 && !h->has_distance && !h->has_point && R > 32768));
@@ -1656,6 +1684,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (const char* we = std::getenv("RMP2_PRIO_TAIL")) h->prio_tail = std::atoi(we) & 3;
   if (const char* we = std::getenv("RMP2_QUAD_LATENCY_BLOCKS")) h->quad_latency_blocks = std::atoi(we), h->quad_latency_set = true;
 #endif
+  if (const char* ce = std::getenv("RMP2_STRICT_CERTIFY")) h->strict_certify = std::atoi(ce) != 0;
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // 0 = general form (include/rmp2.h)
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
@@ -1771,11 +1800,18 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
   std::memset(&o, 0, sizeof(o));
   o.mode = obs ? obs->mode : RMP2_OBS_NONE;
   if (h->has_point) {
+    // attached-point leaves read (relative_position, normal_vec, distance) per pair: from the caller's arrays, or -- a shared
+    // primitive table plus link capsules -- formed inside the step from the closest points of link and primitive, per control
+    // step (which is what lets such a set roll out: 05_obstacle_avoidance.py:51-72 re-feeds the Datamanager every step)
+    const bool from_table = obs && obs->mode == RMP2_OBS_SHARED_SPHERES && obs->link_capsules;
     const bool rollout = ro.n_iters != 1 || ro.substeps != 0;
-    if (rollout) return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: attached-point leaves take per-step pair data");
-    if (o.mode != RMP2_OBS_EXPLICIT_PAIRS || !obs->dist)
+    if (rollout && !from_table)
+      return fail(h, RMP2_ERR_UNSUPPORTED, "rollout: attached-point leaves take per-step pair data -- give a SHARED_SPHERES table "
+                                           "with link_capsules instead of EXPLICIT_PAIRS arrays");
+    if (!from_table && (o.mode != RMP2_OBS_EXPLICIT_PAIRS || !obs->dist))
       return fail(h, RMP2_ERR_INVALID_ARGUMENT,
-                  "attached-point leaves need EXPLICIT_PAIRS data: p_link = relative_position, p_obs = normal_vec, dist");
+                  "attached-point leaves need EXPLICIT_PAIRS data (p_link = relative_position, p_obs = normal_vec, dist) or a "
+                  "SHARED_SPHERES table with link_capsules");
   }
   if (h->has_distance || h->has_point) {
     if (o.mode == RMP2_OBS_NONE)
@@ -1818,9 +1854,11 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
       if (o.mode != RMP2_OBS_SHARED_SPHERES || obs->n_spheres > kLdsSpheres)
         return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: SHARED_SPHERES tables of at most 256 primitives "
                                              "(otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
-      if (h->has_point || h->strict || (h->likely_singular && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)
-        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: sets without attached-point leaves on robots with at most 9 dofs, "
-                                             "AUTO resolve with an inertia leaf (otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
+      // (sets with attached-point leaves resolve as they do on explicit arrays: the rank-deficient ones through the careful pass)
+      if ((!h->has_point && ((h->strict && !quad_certifies_strict(h)) || (h->likely_singular && h->n_template != 2))) ||
+          (h->has_point && h->strict && !quad_certifies_strict(h) && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: robots with at most 9 dofs; solve = pinv only where the quad mapping "
+                                             "certifies or computes it (otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
       o.link_caps = obs->link_capsules;
     }
   }
@@ -1837,7 +1875,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   OutArgs oa;
   if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((h->strict || h->likely_singular) && h->n_template == 9 && (size_t)R > h->system_robots) {
+  if ((h->strict || h->likely_singular) && !quad_certifies_strict(h) && h->n_template == 9 && (size_t)R > h->system_robots) {
     // the combined systems between the two kernels of the strict step (dispatch_solve): 8 n (n + 1) bytes per robot, owned by
     // the handle, grown to the largest fleet stepped (hipFree synchronises the device: no launch still reads the old buffer)
     if (h->d_system) HIP_TRY(h, hipFree(h->d_system));
@@ -1894,11 +1932,13 @@ int load_rccl(const char* path, RcclApi& api, std::string& err) {
 }  // namespace
 
 struct rmp2_exchange {
-  static constexpr int kBuf = 3;                   // table buffers: depth + 1 are in use
+  static constexpr int kBuf = 3;                   // table buffers, all in rotation at either depth (see rmp2_exchange_set_depth)
   RcclApi api;
   void* comm = nullptr;
   int device = 0, rank = 0, world = 1, per_rank = 0;
   int depth = 1;                                   // gathers that may be outstanding minus one ... see rmp2_exchange_set_depth
+  int nbuf = kBuf;                                 // table buffers in rotation: all kBuf; depth + 1 with RMP2_EXCHANGE_BUFFERS=2 (A/B)
+  bool all_buffers = true;
   float* table[kBuf] = {nullptr, nullptr, nullptr};    // [world * per_rank][4]
   hipStream_t side = nullptr;                      // the gathers' stream
   hipEvent_t ready[kBuf] = {nullptr, nullptr, nullptr};        // gather into table b complete
@@ -1929,6 +1969,8 @@ int rmp2_exchange_create(const char* rccl_library, const rmp2_rccl_uid* uid, int
   if (!x) return fail(nullptr, RMP2_ERR_HIP, "out of host memory");
   x->device = device, x->rank = rank, x->world = nranks, x->per_rank = spheres_per_rank;
   if (const char* te = std::getenv("RMP2_EXCHANGE_THROTTLE_US")) x->throttle_us = std::max(0, std::atoi(te));
+  if (const char* tb = std::getenv("RMP2_EXCHANGE_BUFFERS")) x->all_buffers = std::atoi(tb) >= rmp2_exchange::kBuf;
+  x->nbuf = x->all_buffers ? rmp2_exchange::kBuf : x->depth + 1;
   std::string err;
   int rc = load_rccl(rccl_library, x->api, err);
   hipError_t e = hipSuccess;
@@ -1991,6 +2033,7 @@ int rmp2_exchange_set_depth(rmp2_exchange* x, int32_t depth) {
   if (!x || depth < 1 || depth > rmp2_exchange::kBuf - 1) return RMP2_ERR_INVALID_ARGUMENT;
   if (x->n_pending != 0) return x->error = "set the depth before the first gather is started", RMP2_ERR_INVALID_ARGUMENT;
   x->depth = depth;
+  x->nbuf = x->all_buffers ? rmp2_exchange::kBuf : depth + 1;
   x->next = 0;
   return RMP2_OK;
 }
@@ -2022,7 +2065,7 @@ int rmp2_exchange_start(rmp2_exchange* x, const float* local, int32_t local_is_r
   if (r != 0) return x->error = std::string("ncclAllGather: ") + (x->api.GetErrorString ? x->api.GetErrorString(r) : "?"), RMP2_ERR_HIP;
   XCH_TRY(x, hipEventRecord(x->ready[b], x->side));
   x->pending[x->n_pending++] = b;
-  x->next = (x->next + 1) % (x->depth + 1);
+  x->next = (x->next + 1) % x->nbuf;
   return RMP2_OK;
 }
 

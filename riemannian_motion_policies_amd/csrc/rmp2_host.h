@@ -31,6 +31,7 @@ struct rmp2_handle {
   float cull_c0 = 0.f;  // max over the distance leaves of (metric_modulation_radius + margin): beyond it a pair is culled
   uint32_t dof_ops[3] = {0u, 0u, 0u};  // op that owns each dof (quad kernel: Jacobian columns come from the frame slots)
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
+  bool strict_certify = true;  // RMP2_STRICT_CERTIFY=0: the Jacobi pseudo-inverse on every robot (A/B)
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;
@@ -89,10 +90,15 @@ RMP2_DECL_QUAD(launch_quad_n9_s2);
 bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int gsa, const ObsArgs& oa,
                       const OutArgs& outa, int Ra, const rmp2_handle* hb, const float* qb, const float* qdb, const float* goalb,
                       int gsb, const ObsArgs& ob, const OutArgs& outb, int Rb, hipStream_t s);
+// solve = PINV handles whose strict step is ONE quad launch: symmetric metric (the certificate reads the LDL^T of the
+// elimination), an inertia leaf (else every robot is rank deficient and would take the careful pass), <= 16 goal floats
+inline bool quad_certifies_strict(const rmp2_handle* h) {
+  return h->strict && h->strict_certify && h->symmetric && !h->likely_singular && h->n_template == 9 && h->goal_floats <= 16;
+}
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
-                 h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, 0,
-                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0};
+                 h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, h->strict ? 1 : 0,
+                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0, h->has_point ? 1 : 0};
 }
 // rmp2_hex_tu.hip (false: the working set does not fit the CU's LDS -- the caller falls back to the quad mapping)
 bool launch_hex_n2(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,

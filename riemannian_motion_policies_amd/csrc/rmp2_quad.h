@@ -786,12 +786,14 @@ struct QuadHdr {
   int32_t is_chain;  // every frame's parent is the previous frame of the program (rmp2_hex.h only)
   uint32_t dof_ops[3];  // op that owns dof j, 5 bits each, 6 dofs per word (rmp2_quad.h only)
   float cull_c0;        // max over the distance leaves of (metric_modulation_radius + margin): cull threshold
-  int32_t strict;       // 1: solve = PINV, the pseudo-inverse on every robot (rmp2_hex.h only; the quad kernel is AUTO)
+  int32_t strict;       // 1: solve = PINV.  rmp2_hex.h: the pseudo-inverse on every robot; rmp2_quad.h: the elimination's result for the
+                        // robots it certifies as full rank (pinv = inv there), the Jacobi pseudo-inverse for the rest
   int32_t prio_tail;    // wave priority of the phases after the frame loop (rmp2_quad.h only): 0; RMP2_PRIO_TAIL pins another
                         // value for A/B runs (with the kernels of the middle of round 2 a fleet of many rounds preferred 2,
                         // with the final ones 0 wins at every size: tools/gpu_calls_r02/r02_run33_prio_tail.sh)
   int32_t skip_resolve; // 1 (rmp2_quad.h, general flavour): the step stops behind the combined metric / force (out.M, out.f);
                         // rmp2_pinv_kernel resolves every robot by the pseudo-inverse (solve = PINV, rank-deficient sets)
+  int32_t has_point;    // the set carries attached-point leaves (full 16-float rotation records even when link geometry is given)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -902,7 +904,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   float* const s_goal = reinterpret_cast<float*>(s_lo + kMaxOps);
   // attached-point builds: [16 robots][n_ops][16] = rows of the world rotation (9), w (3), alpha (3), behind everything else
   float* const pt_base = STAGE ? s_goal + 16 * kRobotsPerWave : stage_base;
-  const int pt_slot = (PT && obs.link_caps) ? kPtSlotLink : kPtSlot;  // (wave-uniform)
+  const int pt_slot = (PT && obs.link_caps && !hdr.has_point) ? kPtSlotLink : kPtSlot;  // (wave-uniform)
   const DevOp* const ops = STAGE ? s_ops : prog->ops;
   const DevLeaf* const leaves = STAGE ? s_leaves : prog->leaves;
   const int32_t* const fk_list = STAGE ? s_fk : prog->fk_leaves;
@@ -1494,21 +1496,51 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2], q3 = pr4[3];
           const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
           const float W3[3] = {q2.y, q2.z, q2.w}, AL3[3] = {q3.x, q3.y, q3.z};
-          const int lidx = uni<STAGE>(lf.index);
-          const int pb = obs.pair_begin[lidx];
-          const int count = obs.pair_begin[lidx + 1] - pb;
-          const size_t pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
+          // The leaf's pairs: (relative_position, normal_vec, distance) per pair from the caller's arrays (the reference's
+          // Datamanager fields, data_management.py:22-53) -- or, with a primitive table and link capsules (obs.link_caps), formed
+          // HERE per control step: the closest points of the leaf's link capsule and every primitive, as PyBullet reports them
+          // to the reference's loop each step (simulation.py:462-484; 05_obstacle_avoidance.py:51-72 re-feeds them); this is
+          // what lets such a set roll out inside one launch.
+          const bool from_table = obs.link_caps != nullptr;  // (wave-uniform)
+          int count;
+          size_t pbase = 0;
+          float LA[3] = {0.f, 0.f, 0.f}, LD[3] = {0.f, 0.f, 0.f}, lrad = 0.f, laa = 0.f, inv_laa = 0.f;
+          if (from_table) {
+            count = obs.n_spheres;
+            const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
+            lrad = lc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              LA[c] = P3[c] + Rm[3 * c] * lc[0] + Rm[3 * c + 1] * lc[1] + Rm[3 * c + 2] * lc[2];
+              LD[c] = Rm[3 * c] * (lc[4] - lc[0]) + Rm[3 * c + 1] * (lc[5] - lc[1]) + Rm[3 * c + 2] * (lc[6] - lc[2]);
+            }
+            laa = dot3(LD, LD);
+            inv_laa = laa > 0.f ? 1.0f / laa : 0.f;
+          } else {
+            const int lidx = uni<STAGE>(lf.index);
+            const int pb = obs.pair_begin[lidx];
+            count = obs.pair_begin[lidx + 1] - pb;
+            pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
+          }
           h[0] = h[1] = h[2] = 0.f;
           for (int t = 0; kQuad * t < count; ++t) {  // (the pair layout is shared by the fleet: wave-uniform trip count)
             const int b_raw = kQuad * t + sub;
             const bool on = b_raw < count;
-            const size_t b = pbase + (on ? b_raw : 0);
-            const float rel[3] = {obs.p_link[3 * b], obs.p_link[3 * b + 1], obs.p_link[3 * b + 2]};
-            const float nv[3] = {obs.p_obs[3 * b], obs.p_obs[3 * b + 1], obs.p_obs[3 * b + 2]};
-            const float dd = obs.dist[b];
-            float r[3], t1[3], t2[3], xdp[3], cp[3];
+            float r[3], nv[3], dd, t1[3], t2[3], xdp[3], cp[3];
+            if (from_table) {
+              const int bi = on ? b_raw : 0;
+              const float4* rec = reinterpret_cast<const float4*>(step_table) + (obs.capsule ? 2 * bi : bi);
+              const float4 ca = rec[0];
+              const float4 cb = obs.capsule ? rec[1] : ca;
+              link_pair_fields(LA, LD, laa, inv_laa, lrad, ca, cb, P3, r, nv, dd);
+            } else {
+              const size_t b = pbase + (on ? b_raw : 0);
+              const float rel[3] = {obs.p_link[3 * b], obs.p_link[3 * b + 1], obs.p_link[3 * b + 2]};
+              nv[0] = obs.p_obs[3 * b], nv[1] = obs.p_obs[3 * b + 1], nv[2] = obs.p_obs[3 * b + 2];
+              dd = obs.dist[b];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * rel[0] + Rm[3 * c + 1] * rel[1] + Rm[3 * c + 2] * rel[2];
+              for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * rel[0] + Rm[3 * c + 1] * rel[1] + Rm[3 * c + 2] * rel[2];
+            }
             cross3(W3, r, t1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
@@ -1569,7 +1601,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
           if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
-            const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * kPtSlotLink);
+            const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * pt_slot);
             const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2];
             const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
             const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
@@ -1735,6 +1767,29 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       }
     };
     if (!sym) mirror();
+    if (sym) {
+      // Symmetric sets: make the kept part EXACTLY symmetric.  Inside a diagonal block both (i, j) and (j, i) are accumulated,
+      // as (S c_i) . c_j and (S c_j) . c_i -- equal up to fp32 rounding (1e-7 of terms that reach 1e2..1e3 near contact) --
+      // while the blocks below the diagonal exist only as mirrors.  The elimination reads M[i][k] from the pivot row there,
+      // i.e. it assumes the Schur complements stay symmetric; with the rounding-level asymmetry of the diagonal blocks it
+      // solved a matrix that differs from the stored one by that asymmetry (cond(M) x 1e-7 in qdd: invisible to the 1e-5
+      // tolerance away from contact, 1e-4 relative for near-contact robots -- found when the certified strict step was
+      // compared with the Jacobi pseudo-inverse of the same stored system).  The upper triangle is the matrix.
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m) {
+#pragma unroll
+        for (int c1 = 0; c1 < kQuad; ++c1) {
+#pragma unroll
+          for (int c2 = c1 + 1; c2 < kQuad; ++c2) {
+            if (kQuad * m + c2 < N) {  // compile time: both rows exist
+              const double v = A[m][kQuad * m + c2];  // lane c1 holds (4m + c1, 4m + c2)
+              const double t = c1 == 0 ? bcastd<0>(v) : c1 == 1 ? bcastd<1>(v) : bcastd<2>(v);
+              A[m][kQuad * m + c1] = (sub == c2) ? t : A[m][kQuad * m + c1];  // lane c2: (4m + c2, 4m + c1)
+            }
+          }
+        }
+      }
+    }
 
     switch (hdr.prio_tail) {  // (s_setprio takes an immediate)
       case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -1818,9 +1873,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       // symmetric sets: only the block-upper part (row block m, columns >= 4 m) is read and updated;
       // a multiplier whose entry lies below the diagonal blocks is taken from the broadcast pivot row, M[i][k] = M[k][i]
       bool nonfinite_matrix = false;
+      double scale = 0.0;          // max |M_ij| of the robot's system (quad-uniform after the two permutes below)
+      bool pivots_positive = true; // (quad-uniform) every pivot > 0: with a symmetric M the elimination is an LDL^T of an SPD matrix
       auto eliminate = [&](auto symc) __attribute__((always_inline)) {
         constexpr bool SYME = decltype(symc)::value;
-        double scale = 0.0;
 #pragma unroll
         for (int m = 0; m < ROWS; ++m)
 #pragma unroll
@@ -1846,6 +1902,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           }
           const bool bad = !(fabs(rowk[k]) > tiny);
           flagged = flagged || bad;
+          pivots_positive = pivots_positive && rowk[k] > 0.0;
           const double inv = bad ? 0.0 : rcpd(rowk[k]);
           inv_piv[k] = inv;
 #pragma unroll
@@ -1874,6 +1931,57 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       lmax = fmax(lmax, dppd<kXor1>(lmax));
       lmax = fmax(lmax, dppd<kXor2>(lmax));
       flagged = flagged || !(lmax <= 1e4);
+      if (hdr.strict) {  // (wave-uniform) solve = PINV: the reference's only resolve (rmp.py:153-154)
+        // qdd = pinv(M) f with TensorFlow's cutoff 10 n eps sigma_max.  Where EVERY singular value lies above the cutoff the
+        // pseudo-inverse IS the inverse, and the elimination above has just computed inv(M) f; so the strict step only has to
+        // CERTIFY full rank per robot -- the rest (uncertified, flagged) goes to the Jacobi pseudo-inverse in the careful pass.
+        // Certificate (symmetric sets, all pivots > 0, i.e. M = U^T D^-1 U is SPD and the elimination is growth-free):
+        //   W = D^-1/2 U,  M = W^T W,  sigma_min(M) = 1 / |W^-1|_2^2 >= 1 / (n |W^-1|_inf^2),
+        //   |W^-1|_inf <= |C(W)^-1 e|_inf  with the comparison matrix C(W) = diag|w_ii| - offdiag|w_ij|   (Higham, ASNA 8.2):
+        //   one back substitution on absolute values, t_i = (scale sqrt(d_i / scale) + sum_{j > i} |u_ij| t_j) / d_i  (t in units
+        //   that make M / scale the matrix: its sigma_max <= n).  Certified:  n t_max^2 * 10 n eps * n * 16 < 1  -- a factor 16
+        //   above the cutoff, far beyond what rounding in U (backward error ~ n eps |M| for SPD) or in TF's own SVD can move.
+        // (negative pivots: M = W^T sign(D) W, the bound is the same with |d_i|; the elimination without row exchanges is then
+        // only trusted with bounded growth -- max |u_ij| <= 4 max |m_ij| and multipliers <= 64 -- while for SPD it is
+        // backward stable unconditionally)
+        bool certified = SYM && !flagged;
+        if (SYM) {
+          double umax = 0.0;
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m)
+#pragma unroll
+            for (int j = kQuad * m; j < N; ++j) umax = fmax(umax, fabs(A[m][j]));
+          umax = fmax(umax, dppd<kXor1>(umax));
+          umax = fmax(umax, dppd<kXor2>(umax));
+          certified = certified && (pivots_positive || (umax <= 4.0 * scale && lmax <= 64.0));
+          double tr[ROWS], tmax = 0.0;
+#pragma unroll
+          for (int m = 0; m < ROWS; ++m) {
+            double dm = 1.0;  // my row's pivot u_ii, i = sub + 4 m (rows beyond N: unused)
+#pragma unroll
+            for (int c = 0; c < kQuad; ++c)
+              if (kQuad * m + c < N) dm = (sub == c) ? A[m][kQuad * m + c] : dm;
+            // an UPPER bound of sqrt(d / scale) from the fp32 square root (argument in [1e-11, ~1]: no over- / underflow)
+            const float rt = __builtin_sqrtf((float)(fabs(dm) / scale)) * 1.000001f + 1e-30f;
+            tr[m] = scale * (double)rt;
+          }
+#pragma unroll
+          for (int i = N - 1; i >= 0; --i) {
+            const int is = i & 3, im = i >> 2;
+            const double sv = tr[im] * fabs(inv_piv[i]);
+            const double ti = is == 0 ? bcastd<0>(sv) : is == 1 ? bcastd<1>(sv) : is == 2 ? bcastd<2>(sv) : bcastd<3>(sv);
+            tmax = fmax(tmax, ti);
+#pragma unroll
+            for (int m = 0; m < ROWS; ++m) {
+              if (kQuad * m >= i) continue;  // (rows at or below i of the same block add into right-hand sides already consumed)
+              tr[m] = fma(fabs(A[m][i]), ti, tr[m]);
+            }
+          }
+          // n^3 * 160 eps * t_max^2 < 1   (n = N: the padding rows are identity rows of the same system)
+          certified = certified && (tmax * tmax < 1.0 / (160.0 * (double)(N * N * N) * 2.220446049250313e-16));
+        }
+        flagged = flagged || !certified;
+      }
       // back substitution, column oriented: the owner finishes x_i and broadcasts it, then every
       // lane retires column i from the right-hand sides of ITS rows (independent FMAs: the
       // dependent chain per unknown is one multiply + one broadcast)
@@ -1939,12 +2047,13 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         const double v = fv[im];
         W[i * (N + 1) + N] = is == 0 ? bcastd<0>(v) : is == 1 ? bcastd<1>(v) : is == 2 ? bcastd<2>(v) : bcastd<3>(v);
       }
-      status |= RMP2_STATUS_PINV_PATH;
+      // (strict: the pseudo-inverse is the asked-for resolve, not a fall-back; the robot is marked "not certified full rank")
+      status |= hdr.strict ? RMP2_STATUS_JACOBI : RMP2_STATUS_PINV_PATH;
       bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does):
       for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);  // no point iterating on it
       if (!finite_in) {
         for (int i = 0; i < N; ++i) xp[i] = __builtin_nan("");
-      } else if (!lu_pivot_compact(W, T, N, xp)) {
+      } else if (hdr.strict || !lu_pivot_compact(W, T, N, xp)) {  // (strict: no elimination for an uncertified robot)
         const int dropped = pinv_solve_compact(W, N, n_dof, xp);
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }

@@ -14,7 +14,7 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
   const size_t lds_bytes = sizeof(float) * (QuadLds<N>::kFloats + kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) +
                                             quad_table_floats(o.capsule, n_sph_lds));
   const bool with_records = h->has_point || o.link_caps;  // attached-point leaves, link geometry: the builds with rotation records
-  const size_t pt_bytes = with_records ? sizeof(float) * (o.link_caps ? kPtSlotLink : kPtSlot) * kRobotsPerWave * quad_slots(h->n_ops_step)
+  const size_t pt_bytes = with_records ? sizeof(float) * ((o.link_caps && !h->has_point) ? kPtSlotLink : kPtSlot) * kRobotsPerWave * quad_slots(h->n_ops_step)
                                        : 0;  // (rotation, w, alpha per frame; link geometry: the rotation)
   const size_t stage_bytes = sizeof(DevOp) * h->n_ops_step + sizeof(DevLeaf) * h->n_leaves +
                              sizeof(int32_t) * (2 * RMP2_MAX_LEAVES + kMaxOps) + sizeof(float) * 16 * kRobotsPerWave;
@@ -45,7 +45,9 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
   }
   const size_t bytes = (latency ? lds_bytes + stage_bytes : lds_bytes) + pt_bytes;
-  h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot)";
+  h->last_kernel = quad_certifies_strict(h)
+                       ? "rmp2_step_quad_kernel (4 lanes per robot; strict: full rank certified per robot, Jacobi pseudo-inverse for the rest)"
+                       : "rmp2_step_quad_kernel (4 lanes per robot)";
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, FLAVOR)                                                            \
   RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, FLAVOR>), dim3(blocks), dim3(kWave), bytes, s, \
                    h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)

@@ -51,6 +51,7 @@ PRIM_CAPSULE = 1
 STATUS_NONFINITE = 1
 STATUS_RANK_DROP = 2
 STATUS_PINV_PATH = 4
+STATUS_JACOBI = 8   # PINV mode, certifying step: full rank not certified, resolved by the Jacobi pseudo-inverse (diagnostic)
 
 
 class Robot(C.Structure):

@@ -71,16 +71,20 @@ class Engine:
         """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result).
         link_capsules [n_distance_leaves, 8] = (a, radius, b, -) per distance leaf, in its frame's coordinates
         (urdf.link_capsules), with a shared table `spheres`: the control point of a pair is the nearest point of the link's
-        capsule to the obstacle, formed inside the step (the fused form of closest_points(link_capsules=) + explicit pairs)."""
+        capsule to the obstacle, formed inside the step (the fused form of closest_points(link_capsules=) + explicit pairs).
+        Attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance) take the same two arguments instead of the per-pair arrays
+        (p_link = relative_position, p_obs = normal_vec, dist): their Datamanager fields are then formed inside the step from the
+        closest points of link capsule and primitive, per control step -- the form that can roll out."""
         o = D.Obstacles()
         keep = []
         if link_capsules is not None:
             if spheres is None or csr_offset is not None or p_link is not None:
                 raise ValueError("link_capsules go with a shared table: obstacles(spheres=..., link_capsules=...)")
             link_capsules = _f32(link_capsules, self.device)
-            n_dist = sum(1 for i in range(self.desc.n_leaves) if self.desc.leaves[i].taskmap == D.TASKMAP_FK_DISTANCE)
+            # (one capsule per leaf that consumes per-pair obstacle data -- distance leaves and attached-point leaves -- in leaf order)
+            n_dist = len(D.distance_leaf_indices(self.desc))
             if tuple(link_capsules.shape) != (n_dist, 8):
-                raise ValueError(f"link_capsules must be [{n_dist}, 8] (one capsule per distance leaf, in leaf order)")
+                raise ValueError(f"link_capsules must be [{n_dist}, 8] (one capsule per distance / attached-point leaf, in leaf order)")
             o.link_capsules = link_capsules.data_ptr()
             keep.append(link_capsules)
         if p_link is not None:

@@ -224,6 +224,12 @@ def test_closest_points_with_link_geometry(torch_mod, prim, robot):
     err = np.abs(qdd.cpu().numpy() - ref["qdd64"]).max(axis=1)
     tol = 1e-5 * np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
     assert (err[ok] <= tol[ok]).all() and ok.sum() > R // 3, f"worst {err[ok].max():.2e}"
+    if not ok.all():   # the ill-conditioned TwoJoint robots are bounded too (oracle.accuracy_gate: backward error / fp32 resolution)
+        rest = ~ok
+        kw = dict(p_link=pl.cpu().numpy()[rest], p_obs=po.cpu().numpy()[rest])
+        verdict = O.accuracy_gate(qdd.cpu().numpy()[rest], {k: ref[k][rest] for k in ("qdd64", "M", "f")},
+                                  spread=O.fp32_resolution(desc, s["q"][rest], s["qd"][rest], s["goal"][rest], **kw))
+        assert verdict["ok"].all(), f"cond >= 100: {O.gate_summary(verdict)}"
 
 
 @pytest.mark.parametrize("prim", ["spheres", "capsules"])
@@ -277,6 +283,12 @@ def test_link_geometry_fused_into_the_step(torch_mod, prim, robot, R):
     mag = np.maximum(1.0, np.abs(ref["qdd64"]).max(axis=1))
     err = np.abs(fused_np[sub] - ref["qdd64"]).max(axis=1)
     assert (err[well] <= 3e-5 * mag[well]).all() and well.sum() > len(sub) // 4, f"vs oracle: worst {(err / mag)[well].max():.2e}"
+    if not well.all():   # ill-conditioned TwoJoint robots: bounded by the backward error / their fp32 resolution, not exempted
+        rest = ~well
+        kw = dict(p_link=pl_ref.astype(np.float32)[rest], p_obs=po_ref.astype(np.float32)[rest])
+        verdict = O.accuracy_gate(fused_np[sub][rest], {k: ref[k][rest] for k in ("qdd64", "M", "f")},
+                                  spread=O.fp32_resolution(desc, s["q"][sub][rest], s["qd"][sub][rest], s["goal"][sub][rest], **kw))
+        assert verdict["ok"].all(), f"cond >= 100: {O.gate_summary(verdict)}"
     magf = np.maximum(1.0, np.abs(two_np).max(axis=1))
     okf = ok & np.isfinite(two_np).all(axis=1)
     if robot == "two_joint":

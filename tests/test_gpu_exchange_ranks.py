@@ -98,7 +98,7 @@ def test_two_ranks_in_one_process_see_the_full_table(hip_lib, stub_rccl, golden_
     for rank in range(world):
         res = results[rank]
         mine = slice(rank * half, (rank + 1) * half)
-        assert len(set(res["seen"])) == depth + 1, "the table buffers must rotate"
+        assert len(set(res["seen"])) == 3, "the three table buffers must rotate (at either depth)"
         for k in range(steps):
             ref = O.step(desc, g["q"][mine], g["qd"][mine], g["goal"][mine], spheres=tables[k])["qdd64"]
             err = np.abs(res["outs"][k] - ref).max(axis=1)

@@ -1,0 +1,99 @@
+"""Host logic of the N-rank launcher, on CPU: bench.py's rank supervisor (a failing or hanging rank ends the job, non-zero),
+the ranks' agreement on which obstacle exchange they all take (fleet.agree_on_exchange under 2-rank gloo with the native
+constructor failing on ONE rank), and the stand-in collective library of tests/test_gpu_exchange_ranks.py (loads, exports the
+five RCCL entry points the exchange binds -- no compute calls without a GPU)."""
+import ctypes
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _child(code: str):
+    return subprocess.Popen([sys.executable, "-c", code], start_new_session=True)
+
+
+def test_supervisor_all_ranks_ok():
+    import bench
+    procs = [_child("import time; time.sleep(0.2)") for _ in range(3)]
+    assert bench.supervise(procs, timeout_s=30) == 0
+
+
+def test_supervisor_ends_the_siblings_of_a_failed_rank():
+    import bench
+    procs = [_child("import time; time.sleep(60)"), _child("import sys; sys.exit(3)"), _child("import time; time.sleep(60)")]
+    t0 = time.monotonic()
+    rc = bench.supervise(procs, timeout_s=50, grace_s=2)
+    assert rc == 3 and time.monotonic() - t0 < 15, "a dead rank must end the job at once, with its exit code"
+    assert all(p.poll() is not None for p in procs), "no rank may outlive the job"
+
+
+def test_supervisor_times_out_on_a_hung_rank():
+    import bench
+    # one rank ignores SIGTERM (a process stuck in a collective often does): it is killed after the grace period
+    procs = [_child("import time; time.sleep(0.1)"),
+             _child("import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(60)")]
+    t0 = time.monotonic()
+    rc = bench.supervise(procs, timeout_s=1.0, grace_s=1.0)
+    assert rc == 124 and time.monotonic() - t0 < 15
+    assert all(p.poll() is not None for p in procs)
+
+
+class _FakeExchange:
+    closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _agree_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from riemannian_motion_policies_amd.fleet import agree_on_exchange
+    built = _FakeExchange()
+
+    def make_fails_on_rank_1():
+        if rank == 1:
+            raise RuntimeError("dlopen(librccl.so): not found")   # what a rank without the library would raise
+        return built
+
+    exch, err = agree_on_exchange(make_fails_on_rank_1, world)
+    # every rank falls back TOGETHER; the rank that did build its exchange has closed it
+    assert exch is None and err is not None
+    assert built.closed == (rank == 0)
+    assert ("dlopen" in str(err)) == (rank == 1)
+    good, err2 = agree_on_exchange(lambda: built, world)
+    assert good is built and err2 is None
+    dist.barrier()      # (the collectives after the agreement still match up on both ranks)
+    open(os.path.join(tmp, f"ok_{rank}"), "w").close()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_exchange_when_one_cannot_build_it(tmp_path):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok_{r}").exists() for r in range(2))
+
+
+def test_stub_collective_library_exports_what_the_exchange_binds():
+    import __graft_entry__ as g
+    lib = ctypes.CDLL(g.build_stub_rccl())
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString",
+                "stub_rccl_allgathers"):
+        assert hasattr(lib, sym), sym
+    uid = (ctypes.c_char * 128)()
+    assert lib.ncclGetUniqueId(uid) == 0 and bytes(uid).startswith(b"stub-rccl")
+    uid2 = (ctypes.c_char * 128)()
+    lib.ncclGetUniqueId(uid2)
+    assert bytes(uid) != bytes(uid2)
