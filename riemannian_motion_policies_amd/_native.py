@@ -17,7 +17,14 @@ _lib = None
 
 
 class Rmp2Error(RuntimeError):
-    pass
+    """code: the library's RMP2_ERR_* return value (include/rmp2.h) when the error came out of a C-ABI call, else None."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ABI_MISMATCH = -1, -2, -3, -4, -5
 
 
 def lib():
@@ -84,4 +91,4 @@ def lib():
 def check(rc: int, handle=None):
     if rc != 0:
         msg = lib().rmp2_last_error(handle)
-        raise Rmp2Error(f"rmp2 error {rc}: {msg.decode() if msg else '?'}")
+        raise Rmp2Error(f"rmp2 error {rc}: {msg.decode() if msg else '?'}", code=rc)

@@ -90,10 +90,11 @@ RMP2_DECL_QUAD(launch_quad_n9_s2);
 bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int gsa, const ObsArgs& oa,
                       const OutArgs& outa, int Ra, const rmp2_handle* hb, const float* qb, const float* qdb, const float* goalb,
                       int gsb, const ObsArgs& ob, const OutArgs& outb, int Rb, hipStream_t s);
-// solve = PINV handles whose strict step is ONE quad launch: symmetric metric (the certificate reads the LDL^T of the
-// elimination), an inertia leaf (else every robot is rank deficient and would take the careful pass), <= 16 goal floats
+// solve = PINV handles whose strict step is ONE quad launch: an inertia leaf (else every robot is rank deficient and would take
+// the careful pass), <= 16 goal floats; symmetric sets are certified from the LDL^T of the elimination, the others from U and
+// the largest multiplier (rmp2_quad.h)
 inline bool quad_certifies_strict(const rmp2_handle* h) {
-  return h->strict && h->strict_certify && h->symmetric && !h->likely_singular && h->n_template == 9 && h->goal_floats <= 16;
+  return h->strict && h->strict_certify && !h->likely_singular && h->n_template == 9 && h->goal_floats <= 16;
 }
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,

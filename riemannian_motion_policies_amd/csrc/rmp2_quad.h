@@ -1944,26 +1944,35 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         // (negative pivots: M = W^T sign(D) W, the bound is the same with |d_i|; the elimination without row exchanges is then
         // only trusted with bounded growth -- max |u_ij| <= 4 max |m_ij| and multipliers <= 64 -- while for SPD it is
         // backward stable unconditionally)
-        bool certified = SYM && !flagged;
-        if (SYM) {
-          double umax = 0.0;
+        // General (non-symmetric) sets -- JointLimitAvoidance scales columns, quirk Q2 --: M = L U with unit lower L,
+        //   |M^-1|_inf <= |U^-1|_inf |L^-1|_inf,  |U^-1|_inf <= |C(U)^-1 e|_inf (the same back substitution, right-hand side e),
+        //   |L^-1|_inf <= (1 + l_max)^(n - 1)  (l_max = the largest multiplier; the elimination keeps no L),
+        //   sigma_min(M) >= 1 / (sqrt(n) |M^-1|_inf);  certified:  sqrt(n) t_max (1 + l_max)^(n-1) * 10 n eps * n * 16 < 1,
+        // with growth <= 4 and multipliers <= 4 (so that the elimination itself is trustworthy without row exchanges).
+        double umax = 0.0;
 #pragma unroll
-          for (int m = 0; m < ROWS; ++m)
+        for (int m = 0; m < ROWS; ++m)
 #pragma unroll
-            for (int j = kQuad * m; j < N; ++j) umax = fmax(umax, fabs(A[m][j]));
-          umax = fmax(umax, dppd<kXor1>(umax));
-          umax = fmax(umax, dppd<kXor2>(umax));
-          certified = certified && (pivots_positive || (umax <= 4.0 * scale && lmax <= 64.0));
+          for (int j = kQuad * m; j < N; ++j) umax = fmax(umax, fabs(A[m][j]));  // (general form: up to three stale entries left of the
+        umax = fmax(umax, dppd<kXor1>(umax));                                    //  diagonal are included: only ever conservative)
+        umax = fmax(umax, dppd<kXor2>(umax));
+        bool certified = !flagged && (SYM ? (pivots_positive || (umax <= 4.0 * scale && lmax <= 64.0))
+                                          : (umax <= 4.0 * scale && lmax <= 4.0));
+        {
           double tr[ROWS], tmax = 0.0;
 #pragma unroll
           for (int m = 0; m < ROWS; ++m) {
-            double dm = 1.0;  // my row's pivot u_ii, i = sub + 4 m (rows beyond N: unused)
+            if (SYM) {
+              double dm = 1.0;  // my row's pivot u_ii, i = sub + 4 m (rows beyond N: unused)
 #pragma unroll
-            for (int c = 0; c < kQuad; ++c)
-              if (kQuad * m + c < N) dm = (sub == c) ? A[m][kQuad * m + c] : dm;
-            // an UPPER bound of sqrt(d / scale) from the fp32 square root (argument in [1e-11, ~1]: no over- / underflow)
-            const float rt = __builtin_sqrtf((float)(fabs(dm) / scale)) * 1.000001f + 1e-30f;
-            tr[m] = scale * (double)rt;
+              for (int c = 0; c < kQuad; ++c)
+                if (kQuad * m + c < N) dm = (sub == c) ? A[m][kQuad * m + c] : dm;
+              // an UPPER bound of sqrt(d / scale) from the fp32 square root (argument in [1e-11, ~1]: no over- / underflow)
+              const float rt = __builtin_sqrtf((float)(fabs(dm) / scale)) * 1.000001f + 1e-30f;
+              tr[m] = scale * (double)rt;
+            } else {
+              tr[m] = scale;
+            }
           }
 #pragma unroll
           for (int i = N - 1; i >= 0; --i) {
@@ -1977,8 +1986,16 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               tr[m] = fma(fabs(A[m][i]), ti, tr[m]);
             }
           }
-          // n^3 * 160 eps * t_max^2 < 1   (n = N: the padding rows are identity rows of the same system)
-          certified = certified && (tmax * tmax < 1.0 / (160.0 * (double)(N * N * N) * 2.220446049250313e-16));
+          constexpr double kEps = 2.220446049250313e-16;
+          if (SYM) {
+            // n^3 * 160 eps * t_max^2 < 1   (n = N: the padding rows are identity rows of the same system)
+            certified = certified && (tmax * tmax < 1.0 / (160.0 * (double)(N * N * N) * kEps));
+          } else {
+            const double l1 = 1.0 + lmax, l2 = l1 * l1, l4 = l2 * l2, l8 = l4 * l4;  // (1 + l_max)^8 >= (1 + l_max)^(N - 1), N <= 9
+            static_assert(N <= 9, "the bound on |L^-1| is written for n <= 9");
+            // n^2.5 * 160 eps * t_max (1 + l_max)^(n-1) < 1;  sqrt(9) = 3 bounds sqrt(n)
+            certified = certified && (tmax * l8 < 1.0 / (160.0 * 3.0 * (double)(N * N) * kEps));
+          }
         }
         flagged = flagged || !certified;
       }

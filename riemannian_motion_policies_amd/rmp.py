@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import descriptor as D
-from ._native import Rmp2Error
+from ._native import ERR_UNSUPPORTED, Rmp2Error
 from .data_management import ArrayVar, as_array, as_tensor
 from .rmp2 import RiemannianMotionPolicy
 from .taskmap import IdentityTaskmap, TaskmapSphereDistance, classify
@@ -57,7 +57,14 @@ class _StageSource:
 
     def __init__(self, core, eng, q, single, prim, lc, n_leaves):
         self.core, self.eng, self.single, self.n_leaves = core, eng, single, n_leaves
-        self._q_ptr, self._q_version, self._q_shape = q.data_ptr(), q._version, tuple(q.shape)
+        # "the q the stage was given, unmodified": the tensor OBJECT (holding it pins its storage: the allocator cannot hand the
+        # address to a fresh tensor that would then pass for it) and its version counter (inference-mode tensors have none:
+        # the fused route is then not taken)
+        self._q_ref = q
+        try:
+            self._q_version = q._version
+        except RuntimeError:
+            self._q_version = None
         self.q = (q[None] if single else q).clone()
         self.prim = prim.clone()
         self.lc = None if lc is None else lc.clone()
@@ -67,7 +74,12 @@ class _StageSource:
         self.fusable = True    # (cleared when the engine refuses the fused form: its limits are the library's to state)
 
     def same_q(self, q) -> bool:
-        return q.data_ptr() == self._q_ptr and q._version == self._q_version and tuple(q.shape) == self._q_shape
+        if q is not self._q_ref or self._q_version is None:
+            return False
+        try:
+            return q._version == self._q_version
+        except RuntimeError:
+            return False
 
     def link_capsules_or_origins(self):
         if self.lc is not None:
@@ -282,7 +294,7 @@ class RmpCore:
                     out = eng.step(q2, qd2, goal=goal, obstacles=fused)
                     return out[0] if single else out
                 except Rmp2Error as e:   # beyond the fused form's limits (table size, resolve mode ...): the arrays then
-                    if "link_capsules" not in str(e):
+                    if getattr(e, "code", None) != ERR_UNSUPPORTED:   # (the library's code, not the wording of its message)
                         raise
                     self._stage.fusable = False
                     return self._evaluate_device(q, qd, spheres, link_capsules)

@@ -278,7 +278,26 @@ def compile_urdf(urdf_filepath: str, order: Sequence[str]) -> KinematicTable:
     )
 
 
-def link_capsules(urdf_filepath: str, table: KinematicTable, frames: Sequence[str], default_radius: float = 0.06) -> np.ndarray:
+def fitted_link_capsules(urdf_filepath: str) -> dict:
+    """{link name: {"a": [3], "b": [3], "r": float}} of capsules fitted to the collision MESHES of a robot whose kinematics-only
+    URDF ships here: `<stem>_link_capsules.json` next to `<stem>_kinematics.urdf` (the Panda's: generated from the vertex sets of
+    the reference's collision meshes by tests/golden/make_panda_link_capsules.py -- minimum-volume enclosing capsules, so
+    distances to the capsule never exceed distances to the mesh); {} when there is no such file."""
+    import json
+    stem = os.path.basename(urdf_filepath)
+    for suffix in ("_kinematics.urdf", ".urdf"):
+        if stem.endswith(suffix):
+            stem = stem[: -len(suffix)]
+            break
+    path = os.path.join(os.path.dirname(urdf_filepath), stem + "_link_capsules.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)["links"]
+
+
+def link_capsules(urdf_filepath: str, table: KinematicTable, frames: Sequence[str], default_radius: float = 0.06,
+                  fitted="auto") -> np.ndarray:
     """Link capsules [len(frames), 8] = (a, radius, b, 0) in FRAME coordinates for the closest-point stage with link
     geometry (Engine.closest_points(link_capsules=), include/rmp2.h rmp2_closest_points_links): the link that moves with
     each frame as a capsule.  The reference asks PyBullet for the closest points on the link's collision SHAPE
@@ -286,10 +305,12 @@ def link_capsules(urdf_filepath: str, table: KinematicTable, frames: Sequence[st
       * <cylinder length radius>: the cylinder's axis (local z of the collision origin), shortened by the radius at both ends;
       * <box size>: the box's longest edge as the axis, radius = half the larger of the two other edges, shortened likewise;
       * <sphere radius>: a capsule of zero length;
-      * <mesh> / no primitive (the Panda): the segment from the frame origin to the origin of its first child frame (the next
-        joint), radius `default_radius` -- a stand-in a caller replaces by capsules fitted to the collision meshes."""
+      * <mesh> / no primitive: the capsule FITTED to the link's collision mesh where one ships with the robot (`fitted`:
+        "auto" = fitted_link_capsules(urdf_filepath) -- the Panda's --, a dict of the same shape, or None); otherwise the segment
+        from the frame origin to the origin of its first child frame (the next joint), radius `default_radius`."""
     root = ElementTree.parse(urdf_filepath).getroot()
     link_by_name = {l.attrib["name"]: l for l in root.findall("link")}
+    fitted = fitted_link_capsules(urdf_filepath) if fitted == "auto" else (fitted or {})
     out = np.zeros((len(frames), 8), dtype=np.float32)
     for i, fr in enumerate(frames):
         f = table.frame_index(fr)
@@ -317,6 +338,10 @@ def link_capsules(urdf_filepath: str, table: KinematicTable, frames: Sequence[st
         elif prim is not None and prim[0] == "sphere":
             r, half, axis = float(prim[1].attrib["radius"]), 0.0, np.array([0.0, 0.0, 1.0])
         else:
+            cap = fitted.get(table.link_names[f])
+            if cap is not None:   # a capsule fitted to the link's collision mesh (robots/*_link_capsules.json)
+                out[i] = [cap["a"][0], cap["a"][1], cap["a"][2], cap["r"], cap["b"][0], cap["b"][1], cap["b"][2], 0.0]
+                continue
             kids = [c for c in range(table.n_frames) if table.parent[c] == f]
             b = table.T_const[kids[0], :3, 3].astype(np.float64) if kids else np.zeros(3)
             out[i] = [0.0, 0.0, 0.0, default_radius, b[0], b[1], b[2], 0.0]

@@ -209,7 +209,11 @@ def test_closest_points_with_link_geometry(torch_mod, prim, robot):
     T = O.forward_kinematics(desc, s["q"], precision="f64")
     frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
     pl_ref, po_ref = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
-    assert np.abs(pl.cpu().numpy() - pl_ref).max() < 2e-6 and np.abs(po.cpu().numpy() - po_ref).max() < 2e-6
+    # the DISTANCE of a pair is well conditioned; WHERE along two nearly parallel axes the nearest points sit is not (the
+    # fitted Panda capsules meet the capsule table at every angle): 2e-6 for the distance, 2e-5 for the points
+    pln, pon = pl.cpu().numpy(), po.cpu().numpy()
+    assert np.abs(pln - pl_ref).max() < 2e-5 and np.abs(pon - po_ref).max() < 2e-5
+    assert np.abs(np.linalg.norm(pln - pon, axis=-1) - np.linalg.norm(pl_ref.astype(np.float64) - po_ref, axis=-1)).max() < 2e-6
     pl1, po1 = _engine_with(desc, "lane").closest_points(torch.from_numpy(s["q"]), t_dev, link_capsules=torch.from_numpy(lc))
     assert (pl1 - pl).abs().max().item() < 1e-6 and (po1 - po).abs().max().item() < 1e-6   # lane-per-robot form of the stage
     # the control points really differ from the frame origins, pair by pair
@@ -254,7 +258,7 @@ def test_link_geometry_fused_into_the_step(torch_mod, prim, robot, R):
         s = Cf.sample_two_joint_states(rng, R)
         lc = U.link_capsules(U.TWO_JOINT_URDF, table, Cf.TWO_JOINT_CONTROL_POINT_FRAMES)
     tab = Cf.sample_spheres(rng, K) if prim == "spheres" else Cf.sample_capsules(rng, K)
-    lift = np.float32(0.45 if prim == "spheres" else (0.85 if robot == "panda" else 0.35))   # partly above the arms: a mix of in-range and culled pairs, few contacts
+    lift = np.float32(0.45 if prim == "spheres" else (0.6 if robot == "panda" else 0.35))   # partly above the arms: a mix of in-range and culled pairs, few contacts
     tab[:, 2] += lift
     if prim == "capsules":
         tab[:, 6] += lift
@@ -294,8 +298,18 @@ def test_link_geometry_fused_into_the_step(torch_mod, prim, robot, R):
     if robot == "two_joint":
         okf[sub[~well]] = False
         okf[np.setdiff1d(np.arange(R), sub)] = False
+    # fused form against the two-kernel flow: each is bounded against the oracle -- the fused form above, the two-kernel flow
+    # here on the pairs ITS stage wrote (oracle.accuracy_gate: north-star bound, else backward error / fp32 resolution) --, and
+    # the two agree with each other far inside what a wrong control point would cost (> 1e-3, asserted below).  (Round 3 held
+    # them to 5e-5 of each other; with the capsules fitted to the Panda's meshes -- 5 to 10 cm radii instead of the 6 cm
+    # stand-ins -- more pairs sit at a few centimetres, where two fp32 evaluations differ by more than that.)
+    okn = np.arange(R)[okf][:n_chk]
+    kw2 = dict(p_link=pl[okn].cpu().numpy(), p_obs=po[okn].cpu().numpy())
+    ref2 = O.step(desc, s["q"][okn], s["qd"][okn], s["goal"][okn], **kw2)
+    v2 = O.accuracy_gate(two_np[okn], ref2, spread=O.fp32_resolution(desc, s["q"][okn], s["qd"][okn], s["goal"][okn], **kw2))
+    assert v2["ok"].all(), f"stage + explicit pairs vs oracle: {O.gate_summary(v2)}"
     errf = np.abs(fused_np - two_np).max(axis=1)
-    assert (errf[okf] <= 5e-5 * magf[okf]).all(), f"vs stage + explicit pairs: worst {(errf / magf)[okf].max():.2e}"
+    assert (errf[okf] <= 5e-4 * magf[okf]).all(), f"vs stage + explicit pairs: worst {(errf / magf)[okf].max():.2e}"
     assert ((st.cpu().numpy()[okf] & 1) == 0).all()
     # the control points differ from the frame origins: the plain table mode gives other numbers
     plain = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=tab_t)).cpu().numpy()
@@ -333,6 +347,18 @@ def test_link_geometry_argument_errors(torch_mod):
     big = torch.from_numpy(Cf.sample_spheres(rng, 300)).cuda()                      # beyond the LDS-resident table
     with pytest.raises(_native.Rmp2Error, match="link_capsules"):
         eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=big, link_capsules=lc))
+    # solve = pinv: served since round 4 where the quad mapping certifies full rank per robot (the same numbers as AUTO on these
+    # well-conditioned robots); still refused where the strict step is two kernels (here forced: RMP2_STRICT_CERTIFY=0)
     _, dpinv = Cf.config3("pinv")
+    ep = Engine(dpinv, 0)
+    a = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=big[:8], link_capsules=lc))
+    b = ep.step(q, qd, goal, obstacles=ep.obstacles(spheres=big[:8], link_capsules=lc))
+    torch.cuda.synchronize()
+    assert "certified" in ep.last_kernel() and torch.equal(a, b)
+    os.environ["RMP2_STRICT_CERTIFY"] = "0"
+    try:
+        e2 = Engine(dpinv, 0)
+    finally:
+        del os.environ["RMP2_STRICT_CERTIFY"]
     with pytest.raises(_native.Rmp2Error, match="link_capsules"):
-        Engine(dpinv, 0).step(q, qd, goal, obstacles=Engine(dpinv, 0).obstacles(spheres=big[:8], link_capsules=lc))
+        e2.step(q, qd, goal, obstacles=e2.obstacles(spheres=big[:8], link_capsules=lc))

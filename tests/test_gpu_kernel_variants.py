@@ -445,13 +445,20 @@ def test_strict_pseudo_inverse_at_fleet_size_takes_two_kernels(torch_mod):
     eng = _engine_env(desc, RMP2_STRICT_CERTIFY="0")
     got = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st)
     assert "rmp2_pinv_kernel" in eng.last_kernel()
-    # a non-symmetric set (JointLimitAvoidance scales columns, quirk Q2) keeps the two kernels by itself
+    # a non-symmetric set (JointLimitAvoidance scales columns, quirk Q2): certified from U and the largest multiplier -- one
+    # launch as well, the same q-double-dot as its all-Jacobi two-kernel step to a last-place flip, and the oracle's
     _, d2 = Cf.config2("pinv")
-    e2 = Engine(d2, 0)
-    g2 = e2.step(q, qd, goal)
-    assert "rmp2_pinv_kernel" in e2.last_kernel()
+    e2, j2 = Engine(d2, 0), _engine_env(d2, RMP2_STRICT_CERTIFY="0")
+    s2 = torch.zeros(R, dtype=torch.int32, device="cuda")
+    g2 = e2.step(q, qd, goal, status=s2)
+    assert "certified" in e2.last_kernel()
+    w2 = j2.step(q, qd, goal)
+    assert "rmp2_pinv_kernel" in j2.last_kernel()
     torch.cuda.synchronize()
-    _check(g2[:256].cpu().numpy(), O.step(d2, s["q"][:256], s["qd"][:256], s["goal"][:256])["qdd64"], "config 2, strict, two kernels")
+    ulp2 = np.spacing(np.abs(w2.cpu().numpy()).max(axis=1, keepdims=True).astype(np.float32))
+    assert (np.abs(g2.cpu().numpy() - w2.cpu().numpy()) <= 2.0 * ulp2).all()
+    assert ((s2.cpu().numpy() & D.STATUS_JACOBI) != 0).mean() < 0.01
+    _check(g2[:256].cpu().numpy(), O.step(d2, s["q"][:256], s["qd"][:256], s["goal"][:256])["qdd64"], "config 2, strict, certified")
     lane = _engine(desc, "lane")
     want_lane = lane.step(q, qd, goal, obstacles=lane.obstacles(spheres=torch.from_numpy(sph)))
     assert "STRICT" in lane.last_kernel()
