@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RMP2_ABI_VERSION 3
+#define RMP2_ABI_VERSION 4 /* 4: rmp2_reserve, rmp2_exchange_nranks, RMP2_STATUS_JACOBI; attached-point leaves take a table + link_capsules */
 
 #define RMP2_MAX_FRAMES 32  /* frames (= URDF joints) per robot type                    */
 #define RMP2_MAX_DOF 16     /* actuated joints per robot type                            */
@@ -232,6 +232,10 @@ int rmp2_validate(const rmp2_desc *desc);
  *   RMP2_QUAD_SYM   = 0                   general (full-matrix) form of the quad mapping for sets that qualify for the symmetric one
  *   RMP2_EXCHANGE_THROTTLE_US = n         (rmp2_exchange_create) bound of the host throttle of rmp2_exchange_step, 0 = free-running
  *   RMP2_EXCHANGE_BUFFERS = 2 | 3         (rmp2_exchange_create) table buffers in rotation: 3 (default), or depth + 1
+ *   RMP2_EXPLICIT_GLDS = 1                (rmp2_create) EXPLICIT_PAIRS: the pair arrays streamed half a leaf ahead by LDS-DMA with per-quad
+ *                                         compaction of the in-range pairs (built and parity-tested in round 4; measured no faster than
+ *                                         the register loads -- the mode is bound by the bytes a CU can keep in flight beside the frame
+ *                                         records in LDS --, so it is off by default)
  *   RMP2_STRICT_CERTIFY = 0               (rmp2_create) solve = PINV: the Jacobi pseudo-inverse on EVERY robot (two kernels) instead of
  *                                         the certifying one-launch step -- the A/B the equality test of the two is built on
  * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with
@@ -315,6 +319,14 @@ int rmp2_exchange_start(rmp2_exchange *x, const float *local, int32_t local_is_r
 int rmp2_exchange_step(rmp2_exchange *x, rmp2_handle *h, const float *q, const float *qd, const float *goal,
                        int32_t goal_stride, const float *next_local, int32_t next_local_is_ready, const rmp2_outputs *out,
                        int32_t R, void *stream, const float **table_out);
+
+/* Pre-size the per-handle device buffers a step of up to R robots needs, so that rmp2_step never allocates.  Only handles whose
+ * step is TWO kernels own such a buffer: solve = PINV sets without an inertia leaf and rank-deficient sets under AUTO (the
+ * combined metric / force of every robot between the quad mapping and rmp2_pinv_kernel, 8 n (n + 1) bytes per robot); every
+ * other handle: no-op.  Without it the first step of a larger fleet grows the buffer (hipFree + hipMalloc: a device
+ * synchronisation, refused with RMP2_ERR_UNSUPPORTED while the stream is being captured).  Such a handle carries that buffer as
+ * per-handle state: its steps must be issued on ONE stream at a time. */
+int rmp2_reserve(rmp2_handle *h, int32_t R);
 
 /* One control step for R robots: qdd = resolve(sum_i pullback(leaf_i))   (rmp.py:133-155).
  *   q, qd       device [R][n_dof] fp32

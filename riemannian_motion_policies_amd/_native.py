@@ -54,6 +54,7 @@ def lib():
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     l.rmp2_create.argtypes = [C.POINTER(D.Desc), C.c_int, C.POINTER(C.c_void_p)]
     l.rmp2_destroy.argtypes = [C.c_void_p]
+    l.rmp2_reserve.argtypes = [C.c_void_p, C.c_int32]
     l.rmp2_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles),
                             C.POINTER(D.Outputs), C.c_int32, C.c_void_p]
     _step_args = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(D.Obstacles), C.POINTER(D.Outputs), C.c_int32]

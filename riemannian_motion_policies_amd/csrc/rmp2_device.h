@@ -48,7 +48,9 @@ struct DevLeaf {
   float vb[RMP2_MAX_DOF];
   int32_t index;  // leaf index in the caller's descriptor (pair_begin is indexed by it)
   int32_t dist_ordinal;  // FK_DISTANCE leaves: how many distance leaves precede it (row of rmp2_obstacles.link_capsules)
-  int32_t pad_[2];  // 208 bytes
+  int32_t next_pair_leaf;  // exec_leaves only: descriptor index of the NEXT FK_DISTANCE leaf in execution order (whose explicit
+                           // pairs the quad kernel prefetches while this leaf is evaluated), -1: none
+  int32_t pad_[1];  // 208 bytes
 };
 // the 64-byte head of a leaf / the 32-byte control block of an op, as value types: copying
 // them makes the compiler issue one wide scalar load instead of one dependent s_load per field
@@ -123,6 +125,8 @@ struct ObsArgs {
   const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
   const float* __restrict__ dist;          // [R][P] distances of the attached-point leaves
   const float* __restrict__ link_caps;     // [n_distance_leaves][8] link capsules in frame coordinates (table modes), or null
+  int32_t glds;  // EXPLICIT_PAIRS, plain two-wave quad build: the pair arrays are streamed half a leaf ahead by LDS-DMA (set by
+                 // launch_quad when every leaf segment is 16-byte aligned; the launch then carries 6 KiB more LDS per wave)
 };
 
 // Nearest point of the segment a-b (capsule axis) to the control point p: the point-vs-capsule case of the

@@ -1361,7 +1361,13 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     const DevOp& o = P.ops[P.leaf_ops[t]];
     P.leaf_frames[t] = {P.leaf_ops[t], o.anc_mask, o.leaf_begin, o.leaf_count};
   }
+  for (int i = 0; i < d.n_leaves; ++i) P.leaves[i].next_pair_leaf = -1;
   for (int i = 0; i < nfk; ++i) P.exec_leaves[i] = P.leaves[P.fk_leaves[i]];
+  for (int i = 0, last = -1; i < nfk; ++i)   // chain of the FK_DISTANCE leaves in execution order (explicit-pair prefetch)
+    if (P.exec_leaves[i].taskmap == RMP2_TASKMAP_FK_DISTANCE) {
+      if (last >= 0) P.exec_leaves[last].next_pair_leaf = P.exec_leaves[i].index;
+      last = i;
+    }
   for (int i = 0; i < nid; ++i) P.exec_leaves[nfk + i] = P.leaves[P.id_leaves[i]];  // (nfk + nid = n_leaves <= RMP2_MAX_LEAVES)
   for (int k = 0; k < F; ++k) {
     const DevOp& o = P.ops[k];
@@ -1685,6 +1691,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (const char* we = std::getenv("RMP2_QUAD_LATENCY_BLOCKS")) h->quad_latency_blocks = std::atoi(we), h->quad_latency_set = true;
 #endif
   if (const char* ce = std::getenv("RMP2_STRICT_CERTIFY")) h->strict_certify = std::atoi(ce) != 0;
+  if (const char* ge = std::getenv("RMP2_EXPLICIT_GLDS")) h->explicit_glds = std::atoi(ge) != 0;
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // 0 = general form (include/rmp2.h)
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
@@ -1866,6 +1873,27 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
   return RMP2_OK;
 }
 
+// handles whose plain step is two kernels with the combined systems in between (dispatch_solve)
+static bool needs_system_buffer(const rmp2_handle* h) {
+  return (h->strict || h->likely_singular) && !quad_certifies_strict(h) && h->n_template == 9;
+}
+
+static int grow_system_buffer(rmp2_handle* h, int32_t R) {
+  if (h->d_system) HIP_TRY(h, hipFree(h->d_system));
+  h->d_system = nullptr;
+  h->system_robots = 0;
+  HIP_TRY(h, hipMalloc(&h->d_system, sizeof(double) * (size_t)R * h->n_dof * (h->n_dof + 1)));
+  h->system_robots = (size_t)R;
+  return RMP2_OK;
+}
+
+int rmp2_reserve(rmp2_handle* h, int32_t R) {
+  if (!h || R < 0) return RMP2_ERR_INVALID_ARGUMENT;
+  if (int rc = use_device(h)) return rc;
+  if (needs_system_buffer(h) && (size_t)R > h->system_robots) return grow_system_buffer(h, R);
+  return RMP2_OK;
+}
+
 static int step_impl(rmp2_handle* h, const float* q, const float* qd, const float* goal, int32_t goal_stride,
                      const rmp2_obstacles* obs, const rmp2_outputs* out, const RolloutArgs& ro, int32_t R, void* stream) {
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
@@ -1875,14 +1903,15 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   OutArgs oa;
   if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((h->strict || h->likely_singular) && !quad_certifies_strict(h) && h->n_template == 9 && (size_t)R > h->system_robots) {
+  if (needs_system_buffer(h) && (size_t)R > h->system_robots) {
     // the combined systems between the two kernels of the strict step (dispatch_solve): 8 n (n + 1) bytes per robot, owned by
-    // the handle, grown to the largest fleet stepped (hipFree synchronises the device: no launch still reads the old buffer)
-    if (h->d_system) HIP_TRY(h, hipFree(h->d_system));
-    h->d_system = nullptr;
-    h->system_robots = 0;
-    HIP_TRY(h, hipMalloc(&h->d_system, sizeof(double) * (size_t)R * h->n_dof * (h->n_dof + 1)));
-    h->system_robots = (size_t)R;
+    // the handle, grown to the largest fleet stepped (hipFree synchronises the device: no launch still reads the old buffer).
+    // Not during a stream capture (an allocation there is illegal): rmp2_reserve(h, R) first.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(h, RMP2_ERR_UNSUPPORTED, "this handle's two-kernel step needs its system buffer grown: call rmp2_reserve(h, R) "
+                                           "before capturing the stream");
+    if (int rc = grow_system_buffer(h, R)) return rc;
   }
   int rc;
   if (h->n_template == 2)

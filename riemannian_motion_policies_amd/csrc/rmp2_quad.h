@@ -737,6 +737,134 @@ __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const
   }
 }
 
+// ---- explicit pairs streamed by LDS-DMA (gfx950 global_load_lds_dwordx4), half a leaf ahead ------------------------------
+// Interface B is bound by memory LATENCY at two waves per SIMD: a wave issues a leaf's sixteen loads, waits for them, then
+// computes for thousands of cycles with nothing in flight (round 3: three attempts to prefetch the next leaf into REGISTERS
+// spilled).  Here the next HALF leaf (16 pairs per robot: 6 KiB per wave, both arrays) flows into LDS while the current half
+// is evaluated out of registers: the loads hold no VGPRs, and every wave has a chunk in flight through the pair trips, the
+// quad sums and the pull-back.  One wave-instruction moves 64 x 16 B into 1 KiB of LDS, lane-linear; the source address is per
+// lane: chunk c = 64 i + lane of the (robot-major) half-leaf image belongs to robot c / 12, bytes 16 (c % 12) .. +16 of its
+// 192-byte segment -- every 64-byte sector of the arrays is fetched exactly once, by twelve adjacent lanes.
+// Image: [16 robots][16 pairs][3 floats] of p_link at buf, the same of p_obs at buf + 768 floats.
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+// What the stream buys is NOT hidden latency -- the mode is bound by instruction issue at two waves per SIMD, not by memory
+// (tools/stream_pairs.hip: the same access pattern with 110 dependent FMAs per pair streams at 5.1-5.7 TB/s on the same LDS
+// footprint; the step ran at 3.9) -- but the COMPACTION it makes affordable: with a half leaf in registers and the next one in
+// flight, every lane tests its four pairs, the quad ORs a 16-bit mask, and the in-range pairs (21 % in the cluttered scene) are
+// written, compacted, into a small per-quad LDS list (8 entries of 16 B: the difference vector and its square; kGldsList floats per
+// wave = 2 KiB), from which the quad's lanes
+// take them four per trip: ~2.2 trips per half leaf instead of 4 masked slots.  (Round 3's compacted loop re-fetched the dealt
+// pair from L2 -- one memory round trip per trip --, which is why the eight-slot form had won.)  A half in which some quad has
+// more than 8 pairs in range (contact clusters) evaluates its four slots masked, as before.
+constexpr int kGldsBuf = 1536;                       // floats: the half-leaf image, both arrays
+constexpr int kGldsListCap = 8;                      // entries per quad and half leaf
+constexpr int kGldsList = kRobotsPerWave * kGldsListCap * 4;  // floats: [16 quads][8 entries][diff.xyz, |diff|^2]
+// pf_pb: pair_begin of the leaf whose FIRST half is already in the buffer / in flight (-1: none); updated for the next leaf.
+__device__ __forceinline__ void pair_loop_explicit_glds(const float* PL, const float* PO, int n_pairs, int r0, int R, int pb,
+                                                        int pb_next, int& pf_pb, float* buf, int lane, int g, int sub,
+                                                        const float P3[3], const float V3[3], const float A3[3], const float* P,
+                                                        const float* IP, float thr2, float S[6], float h[3]) {
+  const float vv = dot3(V3, V3);
+  float* const list = buf + kGldsBuf + g * (kGldsListCap * 4);  // this quad's list
+  auto issue = [&](int pbx, int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = 64 * i + lane;
+      const int rr = (c * 5462) >> 16;  // c / 12 for c < 192
+      const int piece = c - 12 * rr;
+      const int robot = min(r0 + rr, R - 1);  // (quads beyond the fleet's tail re-read the last robot: in bounds, discarded)
+      const size_t off = ((size_t)robot * n_pairs + pbx + 16 * half) * 3 + 4 * piece;
+      glds16(PL + off, buf + 256 * i);
+      glds16(PO + off, buf + 768 + 256 * i);
+    }
+  };
+  auto evaluate = [&](const float diff[3], float d2, bool on) __attribute__((always_inline)) {
+    const float inv = rsq0(d2);
+    const float d = d2 * inv;
+    const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+    const float xdot = dot3(nh, V3);
+    const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+    float acc, met;
+    obstacle_pair(P, IP, d, xdot, acc, met);
+    if (!on) met = 0.f;
+    const float wgt = met * (acc - cd);
+    const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+    S[0] = fmaf(mn[0], nh[0], S[0]);
+    S[1] = fmaf(mn[0], nh[1], S[1]);
+    S[2] = fmaf(mn[0], nh[2], S[2]);
+    S[3] = fmaf(mn[1], nh[1], S[3]);
+    S[4] = fmaf(mn[1], nh[2], S[4]);
+    S[5] = fmaf(mn[2], nh[2], S[5]);
+    h[0] = fmaf(wgt, nh[0], h[0]);
+    h[1] = fmaf(wgt, nh[1], h[1]);
+    h[2] = fmaf(wgt, nh[2], h[2]);
+  };
+  if (pf_pb != pb) issue(pb, 0);  // (wave-uniform) first distance leaf of the step: nothing was prefetched for it
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk has landed (LDS-DMA counts on vmcnt)
+    F3 a[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* src = buf + g * 48 + 3 * (sub + kQuad * i);
+      a[i] = *reinterpret_cast<const F3*>(src);
+      o[i] = *reinterpret_cast<const F3*>(src + 768);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and is in registers: the buffer is free for the next chunk
+    if (half == 0)
+      issue(pb, 1);
+    else if (pb_next >= 0)
+      issue(pb_next, 0);
+    // range tests of my four pairs (taskmap.py:124-129: rel = stop_gradient(p_link - p_joint); crit = p_joint + rel)
+    float df[4][3], d2s[4];
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      df[i][0] = (P3[0] + (a[i].x - P3[0])) - o[i].x;
+      df[i][1] = (P3[1] + (a[i].y - P3[1])) - o[i].y;
+      df[i][2] = (P3[2] + (a[i].z - P3[2])) - o[i].z;
+      d2s[i] = df[i][0] * df[i][0] + df[i][1] * df[i][1] + df[i][2] * df[i][2];
+      mine |= !(d2s[i] > thr2) ? (1u << i) : 0u;  // (NaN compares "in range")
+    }
+    uint32_t m = mine << (kQuad * sub);  // the quad's 16-bit mask: nibble `sub` = lane sub's four slots
+    m |= dppu<kXor1>(m);
+    m |= dppu<kXor2>(m);
+    const int count = __builtin_popcount(m);
+    if (__any(count > kGldsListCap)) {  // (wave-uniform) a contact cluster: the four slots masked, out of the registers
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool on = (mine >> i) & 1u;
+        if (!__any(on)) continue;
+        evaluate(df[i], d2s[i], on);
+      }
+      continue;
+    }
+    // my in-range pairs go to the quad's list at their rank in the mask (the differences, ready to use: 3 floats + d2)
+    const uint32_t below = m & ((1u << (kQuad * sub)) - 1u);
+    int rank = __builtin_popcount(below);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((mine >> i) & 1u) {
+        float4* dst = reinterpret_cast<float4*>(list) + rank;  // (16-byte entries: diff.xyz, d2 -- 8 x 16 B per quad)
+        *dst = make_float4(df[i][0], df[i][1], df[i][2], d2s[i]);
+        ++rank;
+      }
+    }
+    asm volatile("" ::: "memory");  // (same wave: LDS executes its accesses in order; the compiler must not reorder them)
+    for (int t = 0; __any(kQuad * t < count); ++t) {
+      const int e = kQuad * t + sub;
+      const bool on = e < count;
+      const float4 v = reinterpret_cast<const float4*>(list)[on ? e : 0];
+      const float diff[3] = {v.x, v.y, v.z};
+      evaluate(diff, on ? v.w : 1.0f, on);
+    }
+    asm volatile("" ::: "memory");  // (the list is rewritten by the next half)
+  }
+  pf_pb = pb_next;
+}
+
 // v[4 m + sub] of a wave-uniform per-dof vector of the program (leaf va / vb): four scalar-cache words and three
 // selects instead of a lane-indexed vector load from global memory (a full memory latency in the middle of a leaf)
 __device__ __forceinline__ float pick4(const float* v, int m, int sub) {
@@ -984,6 +1112,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   const float* my_goal = !goal ? nullptr : (STAGE ? s_goal + gi * 16 : goal + (size_t)(live ? robot : 0) * goal_stride);
   uint32_t status = 0u;
   bool flagged = false;
+  // explicit pairs by LDS-DMA (pair_loop_explicit_glds): the plain two-wave build of the explicit-pair mode only -- its launch
+  // carries the 6 KiB chunk buffer behind the other regions (stage_base: no staged program, no sphere table in this build)
+  constexpr bool kGlds = OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2 && !STAGE && !PT;
+  int pf_pb = -1;  // (wave-uniform) pair_begin of the leaf whose first half is in the chunk buffer / in flight
 
   // ---- ragged lists over a small table: the robot's list as a membership mask (built once, by its quad) -----------------
   // Each lane reads every fourth entry of the robot's list (the wave's 16 lists are contiguous in the CSR array), sets the
@@ -1633,6 +1765,16 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
             const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
             // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
             const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
+            if (kGlds && obs.glds && count == 32) {  // (wave-uniform) streamed half a leaf ahead by LDS-DMA
+              const int nxt = lf.next_pair_leaf;
+              int pb_next = -1;
+              if (nxt >= 0) {
+                const int nb = obs.pair_begin[nxt];
+                pb_next = (obs.pair_begin[nxt + 1] - nb == 32) ? nb : -1;
+              }
+              pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, stage_base, lane, g, sub, P3,
+                                      V3, A3, lh.P, IP, thr * thr * kCullSlack, S, h);
+            } else
             pair_loop_explicit_culled(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
                                       thr * thr * kCullSlack, S, h);
           } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked

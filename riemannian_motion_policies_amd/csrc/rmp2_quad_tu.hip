@@ -44,13 +44,27 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     // loads (and the next leaf's prefetch) in flight per wave -- 123.7 us per step at 65 536 robots against 148.7 with four
     if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
   }
-  const size_t bytes = (latency ? lds_bytes + stage_bytes : lds_bytes) + pt_bytes;
+  size_t bytes = (latency ? lds_bytes + stage_bytes : lds_bytes) + pt_bytes;
   h->last_kernel = quad_certifies_strict(h)
                        ? "rmp2_step_quad_kernel (4 lanes per robot; strict: full rank certified per robot, Jacobi pseudo-inverse for the rest)"
                        : "rmp2_step_quad_kernel (4 lanes per robot)";
+  // explicit pairs (interface B) in the plain two-wave build: streamed half a leaf ahead by LDS-DMA when every leaf segment of
+  // the two arrays is 16-byte aligned (global_load_lds_dwordx4): 6 KiB more LDS per wave (16.5 KB: eight waves still share a CU)
+  ObsArgs og = o;
+  {
+    const bool plain_explicit = o.mode == RMP2_OBS_EXPLICIT_PAIRS && !latency && minw == 2 && !with_records && ro.n_iters == 1 &&
+                                ro.substeps == 0 && !ro.q_out && !out.M && !out.f && !o.capsule;
+    bool aligned = (o.n_pairs % 4) == 0 && (reinterpret_cast<uintptr_t>(o.p_link) % 16) == 0 &&
+                   (reinterpret_cast<uintptr_t>(o.p_obs) % 16) == 0 && h->explicit_glds;
+    for (int l = 0; l <= h->n_leaves && aligned; ++l) aligned = (h->h_pair_begin[l] % 4) == 0;
+    if (plain_explicit && aligned) {
+      og.glds = 1;
+      bytes += sizeof(float) * (kGldsBuf + kGldsList);  // chunk image + the quads' in-range lists: 8 KiB, 18.4 KB per wave
+    }
+  }
 #define RMP2_QUAD_LAUNCH(MINW, STAGE, CAP, SYM, OBS, FLAVOR)                                                            \
   RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, MINW, STAGE, CAP, SYM, OBS, FLAVOR>), dim3(blocks), dim3(kWave), bytes, s, \
-                   h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R)
+                   h->d_prog, hdr, q, qd, goal, gs, og, out, ro, R)
   // the symmetric form (block-upper system through the identity leaves and the elimination) exists for the 3..9-dof
   // template with sphere tables (symk above); everything else takes the general form
 #define RMP2_QUAD_BY_CAP(MINW, STAGE)                                                                                   \

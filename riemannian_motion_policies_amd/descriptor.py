@@ -14,7 +14,7 @@ import numpy as np
 
 from .urdf import KinematicTable
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_FRAMES = 32
 MAX_DOF = 16
 MAX_LEAVES = 48

@@ -245,6 +245,12 @@ class Engine:
         o._table_steps = int(tables.shape[0])
         return o
 
+    def reserve(self, robots: int) -> None:
+        """Pre-size the handle's device buffers for steps of up to `robots` robots (rmp2_reserve): afterwards a step never
+        allocates -- needed before capturing a stream with a handle whose step is two kernels (solve = "pinv" without an
+        inertia leaf, rank-deficient sets); a no-op for every other handle."""
+        _native.check(self._lib.rmp2_reserve(self._h, int(robots)), self._h)
+
     def rollout(self, q: torch.Tensor, qd: torch.Tensor, goal: Optional[torch.Tensor] = None, obstacles=None,
                 n_control_steps: int = 1, substeps: int = 10, dt: float = 0.01, out: Optional[torch.Tensor] = None,
                 status: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:

@@ -578,3 +578,47 @@ def test_strict_step_certifies_full_rank_and_keeps_the_jacobi_for_the_rest(torch
         resid = (torch.einsum("rij,rj->ri", Mn, x) - fn).abs().amax(dim=1)
         scale_ = (torch.einsum("rij,rj->ri", Mn.abs(), x.abs()) + fn.abs()).amax(dim=1)
         assert (resid <= 1e-4 * scale_).all(), (resid / scale_).max().item()
+
+
+@pytest.mark.parametrize("R", [8209, 40000])
+def test_explicit_pairs_streamed_by_lds_dma(torch_mod, R):
+    """Interface B at fleet size (the reference's Datamanager layout, data_management.py:8-37 -> taskmap.py:115-138): with
+    RMP2_EXPLICIT_GLDS=1 the plain two-wave build streams the pair arrays half a leaf ahead with global_load_lds_dwordx4 and
+    evaluates the in-range pairs compacted per quad (rmp2_quad.h pair_loop_explicit_glds).  The same pairs as the register-load
+    form, summed in another order: equal to fp32 rounding, tail robots included (R is not a multiple of 16); right against the
+    oracle; a layout the DMA cannot take (leaf segments not 16-byte aligned) falls back to the register loads by itself."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config3()
+    rng = np.random.default_rng(R)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += np.float32(0.4)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    eng, reg = _engine_env(desc, RMP2_EXPLICIT_GLDS="1"), Engine(desc, 0)   # (the stream is opt-in: measured no faster, DESIGN.md section 8)
+    pl, po = eng.closest_points(q, eng.obstacles(spheres=torch.from_numpy(sph)))
+    assert pl.shape[1] == 256 and pl.data_ptr() % 16 == 0
+    a = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl, p_obs=po))
+    b = reg.step(q, qd, goal, obstacles=reg.obstacles(p_link=pl, p_obs=po))
+    torch.cuda.synchronize()
+    assert "quad" in eng.last_kernel()
+    # (the streamed form evaluates a leaf's in-range pairs in another order -- compacted per quad --: equal to fp32 rounding of the
+    # sums, which near contact is the robot's fp32 resolution; every robot is then bounded against the oracle below)
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+    calm = np.abs(bn).max(axis=1) <= 50.0
+    assert np.isfinite(an).all() == np.isfinite(bn).all()
+    assert (np.abs(an - bn).max(axis=1)[calm] <= 2e-6 * np.maximum(1.0, np.abs(bn).max(axis=1))[calm]).all()
+    sub = np.unique(np.concatenate([np.arange(48), np.arange(R - 48, R), rng.integers(0, R, 160)]))
+    kw = dict(p_link=pl[sub].cpu().numpy(), p_obs=po[sub].cpu().numpy())
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], **kw)
+    verdict = O.accuracy_gate(a[sub].cpu().numpy(), ref, spread=O.fp32_resolution(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], **kw))
+    assert verdict["ok"].all(), O.gate_summary(verdict)
+    # a view shifted by one float: the same pairs at addresses the 16-byte DMA cannot take -> the register-load form, same result
+    pl1 = torch.empty(pl.numel() + 4, dtype=torch.float32, device="cuda")[1:1 + pl.numel()].view_as(pl)
+    pl1.copy_(pl)
+    assert pl1.data_ptr() % 16 != 0
+    c = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl1, p_obs=po))
+    torch.cuda.synchronize()
+    assert torch.equal(b, c) or torch.equal(torch.nan_to_num(b), torch.nan_to_num(c)), "the fall-back must be the register-load form"

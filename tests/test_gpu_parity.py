@@ -412,3 +412,44 @@ def test_mixed_fleet_shard_overlapped_step_against_the_oracle(torch_mod):
         verdict = O.accuracy_gate(got, ref, spread=O.fp32_resolution(part["desc"], *host, **kw))
         assert verdict["ok"].all() and np.isfinite(got).all(), f"{key}: {O.gate_summary(verdict)}"
         assert torch.equal(copies[key], part["out"])
+
+
+def test_two_kernel_step_is_capturable_after_reserve(torch_mod):
+    """Round-3 advisor finding: a handle whose step is two kernels (here a rank-deficient set under AUTO: every robot through
+    rmp2_pinv_kernel) grows its exchange buffer inside rmp2_step -- an allocation, illegal during stream capture.  rmp2_reserve
+    sizes it beforehand: the step then allocates nothing, captures into a HIP graph and replays with new inputs; a capture
+    WITHOUT the reservation is refused with RMP2_ERR_UNSUPPORTED (not a corrupted capture)."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, _native
+    table, _ = Cf.config3()
+    spec = D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, table.frame_index("panda_grasptarget_hand"),
+                      Cf.TARGET_ATTRACTOR_PARAMS, goal_len=3)
+    desc = D.build_desc(table, [spec])
+    s = Cf.sample_panda_states(np.random.default_rng(5), 300)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    eng = _engine(desc)
+    eng.reserve(300)
+    side = torch.cuda.Stream()
+    launch_s, out_s = eng.bind(q, qd, goal, stream=side.cuda_stream)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        launch_s()
+    assert "rmp2_pinv_kernel" in eng.last_kernel()
+    q.add_(0.02)
+    g.replay()
+    torch.cuda.synchronize()
+    eager = _engine(desc).step(q, qd, goal)
+    torch.cuda.synchronize()
+    assert torch.equal(out_s, eager)
+    # without the reservation: the raw ABI call on a capturing stream answers UNSUPPORTED and launches nothing
+    fresh = _engine(desc)
+    lib = _native.lib()
+    o = D.Outputs()
+    out2 = torch.empty_like(q)
+    o.qdd = out2.data_ptr()
+    import ctypes as C
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side):
+        out2.zero_()   # (something to capture: the refused call must leave the capture itself intact)
+        rc = lib.rmp2_step(fresh._h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, None, C.byref(o), 300, side.cuda_stream)
+    assert rc == _native.ERR_UNSUPPORTED and b"rmp2_reserve" in lib.rmp2_last_error(fresh._h)
