@@ -523,6 +523,29 @@ def check_against_oracle(desc, s, spheres_np, out, n=256, what="", pairs=None, e
         "rejected": summary["rejected"], "tolerance": TOLERANCE_RULE}
 
 
+def link_pairs_for_lists(desc, lc, table, q, off, idx):
+    """Explicit pairs (what the oracle reads) of a ragged fleet with link geometry, for the result check: per robot and
+    distance leaf one pair per LIST ENTRY -- the nearest points of the link's capsule and the listed primitive, fp64 closed form
+    on the oracle's fp64 forward kinematics -- and far-away fillers (metric exactly 0) up to the longest list."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    T = O.forward_kinematics(desc, q, precision="f64")
+    pl_all, po_all = Cf.pairs_from_link_capsules(T[:, frames], lc, table)
+    n, L, K = len(q), len(frames), table.shape[0]
+    kmax = max(int(np.diff(off[: n + 1]).max()), 1)
+    pl = np.zeros((n, L * kmax, 3), np.float32)
+    po = np.full((n, L * kmax, 3), 1.0e3, np.float32)
+    for r in range(n):
+        lst = idx[off[r]:off[r + 1]]
+        for l in range(L):
+            pl[r, l * kmax:l * kmax + len(lst)] = pl_all[r, l * K + lst]
+            po[r, l * kmax:l * kmax + len(lst)] = po_all[r, l * K + lst]
+    return pl, po
+
+
 def emulate_world(args, workload, dev, local_rank, use_dist):
     """Single-GPU EMULATION of an N-rank run: build each of the N rank shards one after the other on THIS GPU, time each
     on its own, and report per-rank time, the maximum, and the throughput N GPUs would reach if each ran its shard at the
@@ -722,7 +745,10 @@ def worker(args) -> int:
             sz = list(MixedFleetShard.CURVE_SIZES)
             cost = {"curves": {"two_joint": (sz, c[:n]), "panda": (sz, c[n:])}}
             line_extra["cost_model"] = {"robots": sz, "two_joint_us": c[:n], "panda_us": c[n:]}
-        shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve, cost=cost)
+        shard = MixedFleetShard.synthetic(R * world, world, rank, local_rank, seed=5, solve=args.solve, cost=cost,
+                                          link_geometry=args.link_geometry)
+        if args.link_geometry:
+            line_extra["link_geometry"] = "closest points on the links' capsules, formed inside the step over the ragged lists"
         # (a HIP graph of the two-stream step replays SLOWER than the eager sequence on this runtime -- 62.1 against 40.3 us per
         # step, profiles/r03_config5_graph_ab.txt: its cross-stream edges become full barriers -- so eager is the default)
         line_extra["step_issue"] = "hip graph replay" if (args.graph and shard.capture()) else "eager (<= 6 host calls)"
@@ -738,8 +764,14 @@ def worker(args) -> int:
             m = min(256, part["n"])
             off = part["host"]["csr_offset"][: m + 1]
             host = {"q": pq[:m].cpu().numpy(), "qd": pqd[:m].cpu().numpy(), "goal": pgoal[:m].cpu().numpy()}
-            chk[key] = check_against_oracle(part["desc"], host, part["host"]["spheres"], part["out"], n=m, what=f"config5 {key}",
-                                            extra_kw=dict(csr_offset=off, csr_index=part["host"]["csr_index"][: off[-1]]))
+            if args.link_geometry:   # the oracle reads explicit pairs: one per list entry (fp64 closed form), far fillers beyond
+                pl_, po_ = link_pairs_for_lists(part["desc"], part["host"]["link_capsules"], part["host"]["spheres"], host["q"],
+                                                off, part["host"]["csr_index"])
+                chk[key] = check_against_oracle(part["desc"], host, None, part["out"], n=m, what=f"config5 {key} (link geometry)",
+                                                extra_kw=dict(p_link=pl_, p_obs=po_))
+            else:
+                chk[key] = check_against_oracle(part["desc"], host, part["host"]["spheres"], part["out"], n=m, what=f"config5 {key}",
+                                                extra_kw=dict(csr_offset=off, csr_index=part["host"]["csr_index"][: off[-1]]))
             chk[key].pop("tolerance")
         chk["tolerance"] = TOLERANCE_RULE
         line_extra["result_check"] = chk
@@ -828,6 +860,9 @@ def main():
     ap.add_argument("--exchange-depth", type=int, default=1, choices=[1, 2],
                     help="config4, native exchange: tables gathered this many control steps ahead (1: every step reads obstacles "
                          "one control step old, as the reference's loop does; 2: one more step of staleness)")
+    ap.add_argument("--link-geometry", action="store_true",
+                    help="config5: control points on the links' capsules (fitted to the Panda's meshes / the TwoJoint URDF's "
+                         "primitives) instead of the frame origins, formed inside the step over the ragged lists")
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--rank-timeout", type=float, default=540.0,
                     help="--gpus N without a launcher: seconds after which ranks that are still running are ended and the job fails")

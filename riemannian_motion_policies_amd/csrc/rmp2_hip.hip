@@ -1858,8 +1858,11 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
     o.pair_begin = h->d_pair_begin;
     if (obs->link_capsules) {
       // link geometry inside the step (quad mapping, attached-record builds): see include/rmp2.h rmp2_obstacles
-      if (o.mode != RMP2_OBS_SHARED_SPHERES || obs->n_spheres > kLdsSpheres)
-        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: SHARED_SPHERES tables of at most 256 primitives "
+      // (ragged lists since round 4: as membership masks over tables of <= 64 primitives, by a list walk otherwise; sets with
+      // attached-point leaves keep the shared table -- their pairs are not culled per list)
+      const bool ragged_ok = o.mode == RMP2_OBS_RAGGED_SPHERES && !h->has_point;
+      if ((o.mode != RMP2_OBS_SHARED_SPHERES && !ragged_ok) || obs->n_spheres > kLdsSpheres)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: SHARED_SPHERES / RAGGED_SPHERES tables of at most 256 primitives "
                                              "(otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
       // (sets with attached-point leaves resolve as they do on explicit arrays: the rank-deficient ones through the careful pass)
       if ((!h->has_point && ((h->strict && !quad_certifies_strict(h)) || (h->likely_singular && h->n_template != 2))) ||

@@ -467,10 +467,13 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
 // tables, conservative for capsules (their bounding spheres): a pair beyond it is beyond metric_modulation_radius, where the
 // leaf's metric is exactly 0 (rmp2.py:191-195).  (The link's own bounding sphere instead of the segment -- the cheaper test --
 // keeps 2.7x the pairs: (0.5 + 0.2)^3 / 0.5^3 of the volume at the Panda's link lengths.)
+// masked: the robot's ragged list as a membership mask over a table of <= 64 primitives (mem_lo: primitives 0..31, mem_hi: 32..63);
+// the in-range mask of a chunk is ANDed with it -- the dense loop, masked, as pair_loop_culled<MEMBER> does for the sphere modes.
 template <bool SKIP, bool CAPS>
 __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int count, int sub, const float LA[3], const float LB[3],
                                                float lr, float c0, const float V3[3], const float A3[3], const float* P,
-                                               const float* IP, float S[6], float h[3], const float* caps) {
+                                               const float* IP, float S[6], float h[3], const float* caps, bool masked = false,
+                                               uint32_t mem_lo = 0u, uint32_t mem_hi = 0u) {
   constexpr int W = 4, kTests = 32 / W;
   const float4* aux = reinterpret_cast<const float4*>(tab);
   const float* rad = tab + 4 * n_tab;  // (sphere tables; a capsule table's records carry no radii)
@@ -506,6 +509,7 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
     m <<= sub;
     m |= dppu<kXor1>(m);
     m |= dppu<kXor2>(m);
+    if (masked) m &= base == 0 ? mem_lo : mem_hi;  // (tables of at most 64 primitives: two chunks)
     uint32_t rem = m;
     rem = sub > 0 ? (rem & (rem - 1u)) : rem;
     rem = sub > 1 ? (rem & (rem - 1u)) : rem;
@@ -593,6 +597,44 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
       h[1] = fmaf(wgt, nh[1], h[1]);
       h[2] = fmaf(wgt, nh[2], h[2]);
     }
+  }
+}
+
+// Link geometry over a ragged list that cannot be a membership mask (a repeated index -- the reference would count that
+// obstacle twice -- or a table beyond 64 primitives): the list walk, every listed primitive evaluated (no culling: a pair beyond
+// metric_modulation_radius contributes an exact 0 through the leaf's own where()), records from global memory.
+__device__ __forceinline__ void pair_loop_link_list(const float* table, bool capsule, const int32_t* ci, int count, int max_count,
+                                                    int sub, const float LA[3], const float LB[3], float lr, const float V3[3],
+                                                    const float A3[3], const float* P, const float* IP, float S[6], float h[3]) {
+  const float vv = dot3(V3, V3);
+  const float LD[3] = {LB[0] - LA[0], LB[1] - LA[1], LB[2] - LA[2]};
+  const float laa = dot3(LD, LD);
+  const float inv_laa = laa > 0.f ? 1.0f / laa : 0.f;
+  const float zero3[3] = {0.f, 0.f, 0.f};
+  for (int t = sub; t - sub < max_count; t += kQuad) {  // (wave-uniform trip count)
+    const bool on = t < count;
+    const int bi = on ? ci[t] : 0;
+    const float4* rec = reinterpret_cast<const float4*>(table) + (capsule ? 2 * bi : bi);
+    const float4 ca = rec[0];
+    const float4 cb = capsule ? rec[1] : ca;
+    float r_unused[3], nh[3], d;
+    link_pair_fields(LA, LD, laa, inv_laa, lr, ca, cb, zero3, r_unused, nh, d);
+    const float xdot = dot3(nh, V3);
+    const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+    float acc, met;
+    obstacle_pair(P, IP, d, xdot, acc, met);
+    if (!on) met = 0.f;
+    const float wgt = met * (acc - cd);
+    const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+    S[0] = fmaf(mn[0], nh[0], S[0]);
+    S[1] = fmaf(mn[0], nh[1], S[1]);
+    S[2] = fmaf(mn[0], nh[2], S[2]);
+    S[3] = fmaf(mn[1], nh[1], S[3]);
+    S[4] = fmaf(mn[1], nh[2], S[4]);
+    S[5] = fmaf(mn[2], nh[2], S[5]);
+    h[0] = fmaf(wgt, nh[0], h[0]);
+    h[1] = fmaf(wgt, nh[1], h[1]);
+    h[2] = fmaf(wgt, nh[2], h[2]);
   }
 }
 
@@ -1744,8 +1786,18 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               LA[c] = P3[c] + Rm[3 * c] * la[0] + Rm[3 * c + 1] * la[1] + Rm[3 * c + 2] * la[2];
               LB[c] = P3[c] + Rm[3 * c] * lb[0] + Rm[3 * c + 1] * lb[1] + Rm[3 * c + 2] * lb[2];
             }
+            if (obs_mode == RMP2_OBS_RAGGED_SPHERES && !use_member) {  // (wave-uniform) a list that is not a mask: the list walk
+              int rr_ = live ? robot : 0;
+              const int b0 = obs.csr_offset[rr_];
+              const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
+              int max_count = count;
+#pragma unroll
+              for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+              pair_loop_link_list(step_table, obs.capsule != 0, obs.csr_index + b0, count, max_count, sub, LA, LB, lc[3], V3, A3, lh.P,
+                                  IP, S, h);
+            } else
             pair_loop_link<(MINW >= 2), CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lc[3], hdr.cull_c0, V3, A3, lh.P, IP, S, h,
-                                             step_table);
+                                             step_table, obs_mode == RMP2_OBS_RAGGED_SPHERES, member_lo, member_hi);
           } else if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
             if (spheres_in_lds)
 #ifdef RMP2_STAMPS

@@ -78,8 +78,8 @@ class Engine:
         o = D.Obstacles()
         keep = []
         if link_capsules is not None:
-            if spheres is None or csr_offset is not None or p_link is not None:
-                raise ValueError("link_capsules go with a shared table: obstacles(spheres=..., link_capsules=...)")
+            if spheres is None or p_link is not None:
+                raise ValueError("link_capsules go with a primitive table: obstacles(spheres=..., link_capsules=...[, csr_offset=, csr_index=])")
             link_capsules = _f32(link_capsules, self.device)
             # (one capsule per leaf that consumes per-pair obstacle data -- distance leaves and attached-point leaves -- in leaf order)
             n_dist = len(D.distance_leaf_indices(self.desc))

@@ -637,9 +637,12 @@ class MixedFleetShard:
 
     @classmethod
     def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None,
-                  fused: bool = True):
+                  fused: bool = True, link_geometry: bool = False):
         """Synthetic config-5 fleet of `total` robots (k_r ~ U{0..32} as CSR lists into the type's
-        shared sphere table); builds only this rank's shard.  `cost`: see plan()."""
+        shared sphere table); builds only this rank's shard.  `cost`: see plan().
+        link_geometry: the control point of a pair is the nearest point of the LINK's capsule to the obstacle (formed inside
+        the step, rmp2_obstacles.link_capsules over the ragged lists: round 4) instead of the frame origin; the two robot
+        types then step as two launches (the one-grid build carries no link geometry)."""
         import numpy as np
         from . import configs as Cf
         from .engine import Engine
@@ -672,8 +675,17 @@ class MixedFleetShard:
             csr_offset = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
             q, qd, goal = (torch.from_numpy(st[x]).to(dev) for x in ("q", "qd", "goal"))
             out = torch.empty_like(q)
+            lc = None
+            if link_geometry:
+                from . import urdf as U
+                if key == "two_joint":
+                    lc = U.link_capsules(U.TWO_JOINT_URDF, U.two_joint_table(), Cf.TWO_JOINT_CONTROL_POINT_FRAMES)
+                else:
+                    lc = U.link_capsules(U.PANDA_URDF, U.panda_table(), Cf.CONTROL_POINT_FRAMES)
+                lc_host = lc
+                lc = torch.from_numpy(lc).to(dev)
             obs = eng.obstacles(spheres=torch.from_numpy(sph).to(dev), csr_offset=torch.from_numpy(csr_offset),
-                                csr_index=torch.from_numpy(csr_index))
+                                csr_index=torch.from_numpy(csr_index), link_capsules=lc)
             # the two types' kernels are independent: the TwoJoint part runs on a side stream, beside the Pandas'
             side = torch.cuda.Stream(dev) if key == "two_joint" and ranges[rank]["panda"][1] > ranges[rank]["panda"][0] else None
             launch, _ = eng.bind(q, qd, goal, obstacles=obs, out=out, stream=side.cuda_stream if side is not None else None)
@@ -682,7 +694,8 @@ class MixedFleetShard:
                 self._fork, self._join = _Fence(dev), _Fence(dev)
             pairs = float(cls.CONTROL_POINTS[key] * k.sum())
             self.parts[key] = dict(engine=eng, launch=launch, out=out, n=n, keep=(q, qd, goal, obs), desc=desc,
-                                   host=dict(spheres=sph, csr_offset=csr_offset, csr_index=csr_index),
+                                   host=dict(spheres=sph, csr_offset=csr_offset, csr_index=csr_index,
+                                             link_capsules=lc_host if link_geometry else None),
                                    bytes=float(n * (cls.BYTES[key] + 4) + 4 * k.sum()),
                                    flops=float(n * cls.BASE_FLOPS[key] + 240.0 * pairs))
             self.work += float(work[first + lo:first + hi].sum())

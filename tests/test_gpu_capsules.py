@@ -362,3 +362,75 @@ def test_link_geometry_argument_errors(torch_mod):
         del os.environ["RMP2_STRICT_CERTIFY"]
     with pytest.raises(_native.Rmp2Error, match="link_capsules"):
         e2.step(q, qd, goal, obstacles=e2.obstacles(spheres=big[:8], link_capsules=lc))
+
+
+@pytest.mark.parametrize("prim,K", [("spheres", 32), ("spheres", 48), ("capsules", 12), ("spheres", 80)])
+@pytest.mark.parametrize("robot,R", [("panda", 333), ("two_joint", 20000)])
+def test_link_geometry_over_ragged_lists(torch_mod, prim, K, robot, R):
+    """Link geometry inside the step for fleets whose robots see DIFFERENT obstacles (BASELINE config 5's ragged lists; round 3
+    took shared tables only): the robot's CSR list as a membership mask over a table of <= 64 primitives, the list walk beyond
+    and for a list that repeats an index (the reference would count that obstacle twice).  Oracle: explicit pairs in fp64 numpy
+    (configs.pairs_from_link_capsules) holding, per robot and leaf, one pair per LIST ENTRY and far-away filler pairs (metric
+    exactly 0) up to the longest list."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, urdf as U
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(1000 * K + R)
+    if robot == "panda":
+        table, desc = Cf.config3()
+        s = Cf.sample_panda_states(rng, R)
+        lc = U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)
+        lift = 0.5
+    else:
+        table, desc = Cf.config5_two_joint()
+        s = Cf.sample_two_joint_states(rng, R)
+        lc = U.link_capsules(U.TWO_JOINT_URDF, table, Cf.TWO_JOINT_CONTROL_POINT_FRAMES)
+        lift = 0.35
+    tab = Cf.sample_spheres(rng, K) if prim == "spheres" else Cf.sample_capsules(rng, K)
+    tab[:, 2] += np.float32(lift)
+    if prim == "capsules":
+        tab[:, 6] += np.float32(lift)
+    # ragged lists k_r ~ U{0..min(K, 24)}; the first 16 robots' lists repeat an index (their wave takes the list walk)
+    kmax = min(K, 24)
+    counts = rng.integers(0, kmax + 1, size=R)
+    counts[:16] = np.maximum(counts[:16], 2)
+    lists = [rng.permutation(K)[:c] for c in counts]
+    for r in range(16):
+        lists[r][1] = lists[r][0]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    idx = (np.concatenate(lists) if off[-1] else np.zeros(1)).astype(np.int32)
+    eng = Engine(desc, 0)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    obs = eng.obstacles(spheres=torch.from_numpy(tab), csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx),
+                        link_capsules=torch.from_numpy(lc))
+    got = eng.step(q, qd, goal, obstacles=obs)
+    torch.cuda.synchronize()
+    assert "quad" in eng.last_kernel()
+    # oracle on a sample: the listed pairs, padded with far pairs
+    sub = np.unique(np.concatenate([np.arange(32), rng.integers(0, R, 96)]))
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    T = O.forward_kinematics(desc, s["q"][sub], precision="f64")
+    pl_all, po_all = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)          # [n, L*K, 3], leaf-major
+    L = len(frames)
+    pl = np.zeros((len(sub), L * kmax, 3), np.float32)
+    po = np.full((len(sub), L * kmax, 3), 1.0e3, np.float32)                     # filler: a kilometre away, metric exactly 0
+    clr = np.full(len(sub), np.inf)
+    for n, r in enumerate(sub):
+        for l in range(L):
+            for t, b in enumerate(lists[r]):
+                pl[n, l * kmax + t] = pl_all[n, l * K + b]
+                po[n, l * kmax + t] = po_all[n, l * K + b]
+                clr[n] = min(clr[n], np.linalg.norm(pl_all[n, l * K + b] - po_all[n, l * K + b]))
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], p_link=pl, p_obs=po)
+    ok = clr >= 0.05                                                              # parity away from contact, as everywhere
+    assert ok.sum() > len(sub) // 3
+    kw = dict(p_link=pl[ok], p_obs=po[ok])
+    verdict = O.accuracy_gate(got.cpu().numpy()[sub][ok], {k: ref[k][ok] for k in ("qdd64", "M", "f")},
+                              spread=O.fp32_resolution(desc, s["q"][sub][ok], s["qd"][sub][ok], s["goal"][sub][ok], **kw))
+    assert verdict["ok"].all(), O.gate_summary(verdict)
+    assert verdict["a"].mean() > 0.8, O.gate_summary(verdict)
+    # the lists matter: the whole table for every robot gives other numbers
+    full = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(tab), link_capsules=torch.from_numpy(lc)))
+    torch.cuda.synchronize()
+    assert (full - got).abs().max().item() > 1e-3
