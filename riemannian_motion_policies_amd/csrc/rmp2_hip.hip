@@ -1372,6 +1372,17 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
   for (int k = 0; k < F; ++k) {
     const DevOp& o = P.ops[k];
     P.ops[k].ctl = (o.restore + 2) | ((o.save + 1) << 2) | (o.jtype << 4) | ((o.qidx + 1) << 6) | ((o.leaf_count > 0 ? 1 : 0) << 11);
+    // bits 12..17: row of rmp2_obstacles.link_capsules of the frame's FK_DISTANCE leaf + 1 (the lean link-geometry builds of the
+    // quad mapping form the link's world segment in the walk); frames with two such leaves keep the attached-record builds
+    // (rmp2_handle::link_rows_ok)
+    int n_dist_here = 0;
+    for (int i = 0; i < o.leaf_count; ++i) {
+      const DevLeaf& lf = P.leaves[P.fk_leaves[o.leaf_begin + i]];
+      if (lf.taskmap == RMP2_TASKMAP_FK_DISTANCE) {
+        if (n_dist_here++ == 0) P.ops[k].ctl |= (lf.dist_ordinal + 1) << 12;
+      }
+    }
+    (void)n_dist_here;
   }
   // the op that owns each dof (its frame's origin is the joint origin o_j, its world axis z_j): 5 bits per dof
   for (int w = 0; w < 3; ++w) P.dof_ops[w] = 0u;
@@ -1724,6 +1735,13 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   for (int l = 0; l < desc->n_leaves; ++l)
     if (desc->leaves[l].taskmap == RMP2_TASKMAP_FK_DISTANCE) h->distance_leaves.push_back(l);
   h->has_distance = !h->distance_leaves.empty();
+  {  // at most one FK_DISTANCE leaf per frame: the lean link-geometry builds carry one segment per leaf-bearing frame
+    int per_frame[RMP2_MAX_FRAMES] = {};
+    h->link_rows_ok = true;
+    for (int l : h->distance_leaves)
+      if (desc->leaves[l].frame >= 0 && desc->leaves[l].frame < RMP2_MAX_FRAMES && ++per_frame[desc->leaves[l].frame] > 1) h->link_rows_ok = false;
+  }
+  if (const char* le = std::getenv("RMP2_LINK_LEAN")) h->link_rows_ok = h->link_rows_ok && std::atoi(le) != 0;  // 0: attached-record builds (A/B)
   for (int l : h->distance_leaves)
     h->cull_c0 = std::max(h->cull_c0, desc->leaves[l].params[7] + desc->leaves[l].params[0]);
   for (int l = 0; l < desc->n_leaves; ++l)

@@ -32,6 +32,7 @@ struct rmp2_handle {
   uint32_t dof_ops[3] = {0u, 0u, 0u};  // op that owns each dof (quad kernel: Jacobian columns come from the frame slots)
   bool strict = false;  // solve_mode == RMP2_SOLVE_PINV
   bool strict_certify = true;  // RMP2_STRICT_CERTIFY=0: the Jacobi pseudo-inverse on every robot (A/B)
+  bool link_rows_ok = false;   // <= 1 distance leaf per frame: link geometry may take the lean builds (segments formed in the walk)
   bool explicit_glds = false;  // RMP2_EXPLICIT_GLDS=1: explicit pairs streamed half a leaf ahead by LDS-DMA (measured: no gain)
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)

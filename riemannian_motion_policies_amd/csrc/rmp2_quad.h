@@ -996,6 +996,12 @@ __device__ __forceinline__ int uni(int v) {
 // other modes' code: no per-lane 64-bit addresses of pair arrays, CSR lists, debug rows or rollout outputs for the
 // compiler to hoist into the prologue and park in scratch (what the 128-register build spilled in round 2).
 constexpr int kObsAny = -1;
+// OBS = kObsSharedLink (plain builds only): a shared primitive table with LINK GEOMETRY for the distance leaves
+// (rmp2_obstacles.link_capsules) in a lean build -- no rotation record per frame (the attached-record builds: 12 floats x every
+// frame, 256 registers, two waves per SIMD), but the link's world SEGMENT, formed in the walk for the frames that carry a distance
+// leaf (8 floats per leaf frame): 15.6 KB of LDS per wave for the Panda, ten waves per CU at 168 registers.
+constexpr int kObsSharedLink = 4;
+constexpr int kLinkSeg = 8;  // floats per (robot, leaf frame): A.xyz, -, B.xyz, -
 // FLAVOR: kGeneral = everything at run time (debug outputs M / f, rollout loop, any obstacle mode); kPlainStep = one control
 // step, no debug outputs, OBS fixed; kPlainRollout = the fused rollout loop, no debug outputs, OBS fixed (sphere-table modes).
 constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
@@ -1012,7 +1018,9 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
                                                const float* __restrict__ q, const float* __restrict__ qd,
                                                const float* __restrict__ goal, int goal_stride, const ObsArgs& obs, OutArgs out,
                                                const RolloutArgs& ro_arg, int R, const int block_idx) {
-  const int obs_mode = OBS == kObsAny ? obs.mode : OBS;
+  constexpr bool LINKSEG = OBS == kObsSharedLink;
+  static_assert(!LINKSEG || (FLAVOR == kPlainStep && !PT && !STAGE), "link segments: the lean plain builds");
+  const int obs_mode = OBS == kObsAny ? obs.mode : (LINKSEG ? RMP2_OBS_SHARED_SPHERES : OBS);
   constexpr bool PLAIN = FLAVOR == kPlainStep;   // no rollout loop
   constexpr bool LEAN = FLAVOR != kGeneral;      // no debug outputs
   const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr, 0} : ro_arg;
@@ -1482,8 +1490,18 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     float4 n0 = rec4n[0], n1 = rec4n[1], n2 = rec4n[2];
     // {axis, ctl} of the frame: wave-uniform, one 16-byte fetch per frame (scalar cache, or the staged copy), one ahead
     float4 nac = *reinterpret_cast<const float4*>(ops[0].axis);
+    // (link segments: the capsule of the frame's distance leaf, fetched with the control word a frame ahead; ctl bits 12..17 =
+    // its row of link_capsules + 1, 0 = the frame carries no distance leaf)
+    float4 nla = make_float4(0.f, 0.f, 0.f, 0.f), nlb = nla;
+    if (LINKSEG) {
+      const int row0 = ((__float_as_int(nac.w) >> 12) & 63) - 1;
+      const float4* lc0 = reinterpret_cast<const float4*>(obs.link_caps) + 2 * max(row0, 0);
+      nla = lc0[0], nlb = lc0[1];
+    }
+    int t_leaf = 0;  // (wave-uniform) ordinal of the frame among the leaf-bearing frames: its segment slot
     for (int k = 0; k < n_ops; ++k) {
       const float4 r0_ = n0, r1_ = n1, r2_ = n2, ac = nac;
+      const float4 la4 = nla, lb4 = nlb;
       const int ctl = uni<STAGE>(__float_as_int(ac.w));
       const int c_restore = (ctl & 3) - 2, c_save = ((ctl >> 2) & 3) - 1, c_jtype = (ctl >> 4) & 3;
       const int qi = ((ctl >> 6) & 31) - 1;
@@ -1499,6 +1517,11 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         n1 = rec4n[1];
         n2 = rec4n[2];
         nac = *reinterpret_cast<const float4*>(ops[kn].axis);
+        if (LINKSEG) {
+          const int rown = ((__float_as_int(nac.w) >> 12) & 63) - 1;
+          const float4* lcn = reinterpret_cast<const float4*>(obs.link_caps) + 2 * max(rown, 0);
+          nla = lcn[0], nlb = lcn[1];
+        }
       }
       const float Rl[9] = {r0_.x, r0_.y, r0_.z, r0_.w, r1_.x, r1_.y, r1_.z, r1_.w, r2_.x};
       const float tl[3] = {r2_.y, r2_.z, r2_.w};
@@ -1551,6 +1574,11 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         fr[3 + sub] = vn;
         fr[6 + sub] = an;
         fr[9 + sub] = z;
+        if (LINKSEG && ((ctl >> 12) & 63) != 0) {  // (wave-uniform) my component of the link's world segment A, B
+          float* sg = stage_base + (g * hdr.n_leaf_ops + t_leaf) * kLinkSeg;
+          sg[sub] = pn + Rn[0] * la4.x + Rn[1] * la4.y + Rn[2] * la4.z;
+          sg[4 + sub] = pn + Rn[0] * lb4.x + Rn[1] * lb4.y + Rn[2] * lb4.z;
+        }
         if (PT) {  // row `sub` of the world rotation and component `sub` of w and alpha, for the attached-point leaves
           float* pr = pt_base + (g * n_ops + k) * pt_slot;
           pr[3 * sub] = Rn[0];
@@ -1567,6 +1595,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         for (int s2 = 0; s2 < SLOTS; ++s2)
           if (c_save == s2) slot[s2] = cur;
       }
+      if (LINKSEG) t_leaf += (ctl >> 11) & 1;  // (the frame carries leaves: the next leaf-bearing frame takes the next slot)
     }
   }
   RMP2_STAMP();  // 2: walk done
@@ -1774,7 +1803,14 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
           h[0] = h[1] = h[2] = 0.f;
           const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
           const float* sph_lds = sph_lds_base;
-          if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
+          if (LINKSEG) {  // lean link build: the world segment was formed in the walk (slot t of this robot)
+            const float4* sg4 = reinterpret_cast<const float4*>(stage_base + (g * hdr.n_leaf_ops + t) * kLinkSeg);
+            const float4 sa = sg4[0], sb = sg4[1];
+            const float LA[3] = {sa.x, sa.y, sa.z}, LB[3] = {sb.x, sb.y, sb.z};
+            const float lrad = obs.link_caps[8 * lf.dist_ordinal + 3];
+            pair_loop_link<true, CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lrad, hdr.cull_c0, V3, A3, lh.P, IP, S, h,
+                                      step_table);
+          } else if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
             const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * pt_slot);
             const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2];
             const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};

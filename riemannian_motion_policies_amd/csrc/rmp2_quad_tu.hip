@@ -119,6 +119,35 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     return;
   }
 #undef RMP2_QUAD_ROLL_SYM
+  if constexpr (N == 9) {
+    // link geometry of the distance leaves over a SHARED table, plain control step, throughput grid: the lean builds (OBS =
+    // kObsSharedLink: the link's world segment formed in the walk, 8 floats per leaf-bearing frame -- no rotation records, no
+    // rollout loop, no debug outputs): three waves per SIMD by registers, ten waves per CU by LDS for the Panda
+    if (o.link_caps && !h->has_point && h->link_rows_ok && o.mode == RMP2_OBS_SHARED_SPHERES && !latency && ro.n_iters == 1 &&
+        ro.substeps == 0 && !ro.q_out && !out.M && !out.f) {
+      bytes = lds_bytes + sizeof(float) * kLinkSeg * kRobotsPerWave * h->n_leaf_ops;
+      const int lw = h->quad_minw == 2 ? 2 : 3;
+#define RMP2_QUAD_LINK(MINW, CAP, SYM)                                                                                   \
+      do {                                                                                                              \
+        auto kern = rmp2_step_quad_kernel<N, SLOTS, MINW, false, CAP, SYM, kObsSharedLink, kPlainStep>;                  \
+        if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        RMP2_STEP_LAUNCH(h, kern, dim3(blocks), dim3(kWave), bytes, s, h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);  \
+      } while (0)
+#define RMP2_QUAD_LINK_SYM(MINW, CAP)                                                                                    \
+      do {                                                                                                              \
+        if (symk) RMP2_QUAD_LINK(MINW, CAP, true); else RMP2_QUAD_LINK(MINW, CAP, false);                               \
+      } while (0)
+      if (o.capsule) {
+        if (lw == 2) RMP2_QUAD_LINK_SYM(2, true); else RMP2_QUAD_LINK_SYM(3, true);
+      } else {
+        if (lw == 2) RMP2_QUAD_LINK_SYM(2, false); else RMP2_QUAD_LINK_SYM(3, false);
+      }
+#undef RMP2_QUAD_LINK_SYM
+#undef RMP2_QUAD_LINK
+      h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot; link geometry, lean build: segments formed in the walk)";
+      return;
+    }
+  }
   if (with_records) {
     // attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance) and link geometry in the table modes: the general
     // flavour with the extra per-frame records (27 floats per frame instead of 12: two waves per SIMD at most)
