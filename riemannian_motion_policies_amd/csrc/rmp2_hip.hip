@@ -1441,8 +1441,10 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // ... except on 2-dof robots, where the fall-through of a flagged robot is a 2 x 2 Jacobi: there the elimination
   // mappings (with their split pair loops and culling) keep sets without an inertia leaf, e.g. the TwoJoint half of the
   // mixed fleet (config 5)
-  // (a strict 2-dof handle forced onto the quad mapping is served too: its closed-form 2 x 2 resolve IS the pseudo-inverse)
-  const bool cheap_fallthrough = N == 2 && (!h->strict || h->kernel_choice == 2);
+  // (solve = PINV on 2-dof robots takes the same mappings since round 4: the quad mapping's closed-form 2 x 2 resolve IS the
+  // pseudo-inverse with TensorFlow's cutoff, for every robot, and the hex mapping's strict form is its careful path's; the
+  // lane-per-robot strict kernel remains behind RMP2_KERNEL=lane)
+  const bool cheap_fallthrough = N == 2 && h->kernel_choice != 1;
   // solve = PINV on a set whose metric is symmetric and carries an inertia leaf: the quad mapping's elimination CERTIFIES full
   // rank per robot (rmp2_quad.h, hdr.strict) -- where every singular value lies above TensorFlow's cutoff pinv(M) IS inv(M) --
   // and only uncertified robots take the Jacobi pseudo-inverse (its careful pass).  One launch, the AUTO step's cost, the

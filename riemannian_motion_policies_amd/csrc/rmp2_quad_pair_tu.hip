@@ -22,7 +22,8 @@ bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, 
   if (ha->n_template == 9 && hb->n_template == 2)
     return launch_quad_pair(hb, qb, qdb, goalb, gsb, ob, outb, Rb, ha, qa, qda, goala, gsa, oa, outa, Ra, s);
   const auto lean = [](const rmp2_handle* h, const ObsArgs& o, const OutArgs& out) {
-    return !h->strict && !h->has_point && h->goal_floats <= 16 && !out.M && !out.f && !o.capsule && !o.link_caps &&
+    // (solve = PINV: the 2-dof part's closed form is the pseudo-inverse; the 3..9-dof part where its step certifies full rank)
+    return (!h->strict || h->n_template == 2 || quad_certifies_strict(h)) && !h->has_point && h->goal_floats <= 16 && !out.M && !out.f && !o.capsule && !o.link_caps &&
            (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES) && o.n_spheres <= kLdsSpheres &&
            h->kernel_choice == 0;
   };

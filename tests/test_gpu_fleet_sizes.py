@@ -84,8 +84,11 @@ def test_eight_rank_shard_shapes_of_the_mixed_fleet(rank):
         assert np.isfinite(allout).mean() > 0.999, f"rank {rank} {key}: {np.isnan(allout).any(axis=1).sum()} non-finite robots"
 
 
-def test_two_robot_types_in_one_grid():
-    """rmp2_step_pair: the TwoJoint and the Panda part of a mixed shard as ONE grid (the first blocks run the TwoJoint
+@pytest.mark.parametrize("solve", ["auto", "pinv"])
+def test_two_robot_types_in_one_grid(solve):
+    """(solve = "pinv", round 4: the 2-dof part's closed form IS the pseudo-inverse, the Panda part certifies full rank per
+    robot -- a strict mixed shard steps as one grid too.)
+    rmp2_step_pair: the TwoJoint and the Panda part of a mixed shard as ONE grid (the first blocks run the TwoJoint
     program, the rest the Panda's).  Same template bodies as the two separate launches: the results must be identical bit
     for bit, and right against the oracle; shards whose parts are small keep two launches."""
     import os
@@ -95,8 +98,8 @@ def test_two_robot_types_in_one_grid():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import oracle as O
     from riemannian_motion_policies_amd.fleet import MixedFleetShard
-    fused = MixedFleetShard.synthetic(40000, 1, 0, 0)               # 20 000 + 20 000 robots
-    plain = MixedFleetShard.synthetic(40000, 1, 0, 0, fused=False)
+    fused = MixedFleetShard.synthetic(40000, 1, 0, 0, solve=solve)               # 20 000 + 20 000 robots
+    plain = MixedFleetShard.synthetic(40000, 1, 0, 0, fused=False, solve=solve)
     assert fused._fused and "pair" in fused.parts["panda"]["engine"].last_kernel()
     assert not plain._fused
     for _ in range(2):
