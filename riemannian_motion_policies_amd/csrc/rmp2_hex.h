@@ -987,7 +987,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- resolve: Gauss-Jordan in fp64 without row exchanges, one row per lane ------------------------------
   // (certification as lu_solve<N>, rmp2_solve.h: tiny pivot, multiplier growth, non-finite result -> careful path)
   bool flagged = true;
-  if (!hdr.strict) {  // (strict: solve = PINV asks for the pseudo-inverse on every robot, rmp.py:153 -- no elimination)
+  // hdr.strict: 0 AUTO; 1 solve = PINV, the pseudo-inverse on every robot (no elimination); 2 / 3 solve = PINV with the
+  // round-4 certificate (3: symmetric set): the elimination's result stands for the robots it certifies as full rank above
+  // TensorFlow's cutoff -- pinv = inv there, rmp2_quad.h has the derivation --, the careful path's Jacobi for the rest
+  const bool certify = hdr.strict >= 2;
+  if (!hdr.strict || certify) {
     // magnitudes are compared on the HIGH WORD of the doubles (monotone for non-negative values, NaN / Inf on top):
     // integer max at fp32 rate instead of dependent fp64 max chains.  scale = max |M_ij| rounded down to its high word.
     int scale_hi = 0;
@@ -997,8 +1001,12 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     const double scale = __hiloint2double(scale_hi, 0);
     const double tiny = 1e-11 * scale;
     flagged = !(scale > 0.0) || !(scale < 1.7e308);
-    int lmax_hi = 0;
+    int lmax_hi = 0, umax_hi = 0;
     double inv_own = 0.0;
+    double Urow[N];  // (certificate) my row of U: pivot row s as it was when it was used -- columns >= s
+    bool piv_pos = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) Urow[j] = 0.0;
     // Pivots are taken TWO per LDS exchange: lanes k and k + 1 publish their rows together, every lane applies step k
     // to the copy of row k + 1 itself (n - k fp64 FMAs, redundantly) and then eliminates both columns from its own row
     // -- half the dependent LDS round trips of one pivot per exchange.
@@ -1036,6 +1044,15 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       const double inv1 = bad1 ? 0.0 : rcpd(r1[k1]);
       flagged = flagged || bad0 || bad1;
       inv_own = (s == k) ? inv0 : ((s == k1) ? inv1 : inv_own);
+      if (certify) {
+        piv_pos = piv_pos && r0[k] > 0.0 && r1[k1] > 0.0;
+#pragma unroll
+        for (int j = k; j < N; ++j) {
+          Urow[j] = (s == k) ? r0[j] : Urow[j];
+          if (j >= k1) Urow[j] = (s == k1) ? r1[j] : Urow[j];
+          umax_hi = max(umax_hi, max(__double2hiint(r0[j]) & 0x7fffffff, j >= k1 ? (__double2hiint(r1[j]) & 0x7fffffff) : 0));
+        }
+      }
       const double l0 = (s != k) ? A[k] * inv0 : 0.0;
 #pragma unroll
       for (int j = k1; j < N; ++j) A[j] = fma(-l0, r0[j], A[j]);
@@ -1059,12 +1076,46 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       flagged = flagged || bad;
       const double inv = bad ? 0.0 : rcpd(pk);
       inv_own = (s == k) ? inv : inv_own;
+      if (certify) {
+        piv_pos = piv_pos && pk > 0.0;
+        Urow[k] = (s == k) ? pk : Urow[k];
+        umax_hi = max(umax_hi, __double2hiint(pk) & 0x7fffffff);
+      }
       const double l = (s != k) ? A[k] * inv : 0.0;
       fv = fma(-l, bk, fv);
       hex_sync();
     }
     lmax_hi = hex_maxi(lmax_hi);
     flagged = flagged || !(lmax_hi <= __double2hiint(1e4));  // multiplier growth > 1e4 (NaN / Inf compare above it)
+    if (certify) {  // (wave-uniform)
+      // |U^-1|_inf (general sets) or |W^-1|_inf, W = |D|^-1/2 U (symmetric sets) by ONE back substitution on absolute values (the
+      // comparison matrix of a triangular factor): lane i finishes t_i and hands it to the robot's other lanes, which retire
+      // column i from the right-hand sides of their rows -- in units that make M / max|M| the matrix
+      const bool symset = hdr.strict == 3;
+      const double d_own = fabs(Urow[s < N ? s : 0]);
+      const float rt = __builtin_sqrtf((float)(d_own / scale)) * 1.000001f + 1e-30f;  // an UPPER bound of sqrt(d / scale)
+      double rhs = symset ? scale * (double)rt : scale;
+      double tmax = 0.0;
+#pragma unroll
+      for (int i = N - 1; i >= 0; --i) {
+        const double ti = __shfl(rhs * fabs(inv_own), i, kHex);
+        tmax = fmax(tmax, ti);
+        rhs = (s < i) ? fma(fabs(Urow[i]), ti, rhs) : rhs;
+      }
+      const double lmax = __hiloint2double(lmax_hi, 0) * 1.0000002;  // (the high word rounds down: nudged back up)
+      const double umax = __hiloint2double(hex_maxi(umax_hi), 0) * 1.0000002;
+      constexpr double kEps = 2.220446049250313e-16;
+      bool certified;
+      if (symset) {
+        certified = (piv_pos || (umax <= 4.0 * scale && lmax <= 64.0)) && tmax * tmax < 1.0 / (160.0 * (double)(N * N * N) * kEps);
+      } else {
+        double lb = 1.0;
+#pragma unroll
+        for (int i = 1; i < N; ++i) lb *= 1.0 + lmax;  // |L^-1|_inf <= (1 + l_max)^(n - 1)
+        certified = umax <= 4.0 * scale && lmax <= 4.0 && tmax * lb < 1.0 / (160.0 * sqrt((double)N) * (double)(N * N) * kEps);
+      }
+      flagged = flagged || !certified;
+    }
     const double x = fv * inv_own;
     const bool finite = (s >= n_dof) || (fabs(x) < 1.7e308);
     flagged = flagged || hex_any(!finite, g);
@@ -1081,6 +1132,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       double* const T = SYS + N * (N + 1);
       double* const xp = T + N * (N + 1);
       if (!hdr.strict) status |= RMP2_STATUS_PINV_PATH;
+      if (certify) status |= RMP2_STATUS_JACOBI;  // (not certified full rank: resolved by the Jacobi pseudo-inverse; diagnostic)
       bool finite_in = true;  // a metric / force with NaN or Inf resolves to NaN (as the reference's pinv does)
       for (int i = 0; i < N * (N + 1); ++i) finite_in = finite_in && (fabs(W[i]) < 1.7e308);
       if (!finite_in) {

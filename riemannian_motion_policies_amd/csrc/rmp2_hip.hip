@@ -1524,8 +1524,8 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // the fused rollout of a solve = PINV handle (the reference's only resolve, rmp.py:153-154, inside the closed loop): the hex
   // mapping carries the strict pseudo-inverse through its careful path at any fleet size
   const bool strict_rollout = h->strict && rollout && !quad_certifies;
-  // (a certifying strict handle skips the hex mapping, whose strict form is the pseudo-inverse of EVERY robot in its careful path)
-  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max && !quad_certifies)) &&
+  // (the hex mapping certifies too since round 4 -- its Gauss-Jordan keeps the pivot rows --: strict small fleets take it like AUTO ones)
+  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max && (!quad_certifies || hex_certifies_strict(h)))) &&
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (an uncertifying quad resolve would be AUTO: never a silent change of semantics)

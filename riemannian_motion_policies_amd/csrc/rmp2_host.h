@@ -98,6 +98,8 @@ bool launch_quad_pair(const rmp2_handle* ha, const float* qa, const float* qda, 
 inline bool quad_certifies_strict(const rmp2_handle* h) {
   return h->strict && h->strict_certify && !h->likely_singular && h->n_template == 9 && h->goal_floats <= 16;
 }
+// ... and in the hex mapping (any template size: its Gauss-Jordan keeps the pivot rows for the same certificate)
+inline bool hex_certifies_strict(const rmp2_handle* h) { return h->strict && h->strict_certify && !h->likely_singular; }
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                  h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, h->strict ? 1 : 0,

@@ -25,7 +25,7 @@ def _engine_env(desc, **env):
     """Engine created with diagnostic environment knobs (read at rmp2_create) set, restored afterwards."""
     from riemannian_motion_policies_amd.engine import Engine
     old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    os.environ.update({k: str(v) for k, v in env.items()})
     try:
         return Engine(desc, 0)
     finally:
@@ -217,20 +217,6 @@ def test_culling_is_exact_and_hardware_approximations_are_bounded(torch_mod, ker
     assert np.median(e_fast[near]) <= 4 * max(np.median(e_acc[near]), 1e-6), (np.median(e_fast[near]), np.median(e_acc[near]))
     assert np.quantile(e_fast[near], 0.95) <= 4 * max(np.quantile(e_acc[near], 0.95), 1e-5), \
         (np.quantile(e_fast[near], 0.95), np.quantile(e_acc[near], 0.95))
-
-
-def _engine_env(desc, **env):
-    from riemannian_motion_policies_amd.engine import Engine
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return Engine(desc, 0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_quad_register_caps_agree_bitwise_at_fleet_sizes(torch_mod):
@@ -448,17 +434,20 @@ def test_strict_pseudo_inverse_at_fleet_size_takes_two_kernels(torch_mod):
     # a non-symmetric set (JointLimitAvoidance scales columns, quirk Q2): certified from U and the largest multiplier -- one
     # launch as well, the same q-double-dot as its all-Jacobi two-kernel step to a last-place flip, and the oracle's
     _, d2 = Cf.config2("pinv")
-    e2, j2 = Engine(d2, 0), _engine_env(d2, RMP2_STRICT_CERTIFY="0")
-    s2 = torch.zeros(R, dtype=torch.int32, device="cuda")
-    g2 = e2.step(q, qd, goal, status=s2)
-    assert "certified" in e2.last_kernel()
-    w2 = j2.step(q, qd, goal)
-    assert "rmp2_pinv_kernel" in j2.last_kernel()
-    torch.cuda.synchronize()
-    ulp2 = np.spacing(np.abs(w2.cpu().numpy()).max(axis=1, keepdims=True).astype(np.float32))
-    assert (np.abs(g2.cpu().numpy() - w2.cpu().numpy()) <= 2.0 * ulp2).all()
-    assert ((s2.cpu().numpy() & D.STATUS_JACOBI) != 0).mean() < 0.01
-    _check(g2[:256].cpu().numpy(), O.step(d2, s["q"][:256], s["qd"][:256], s["goal"][:256])["qdd64"], "config 2, strict, certified")
+    for reps, mapping in ((1, "hex"), (4, "quad")):     # 5 000 robots: the hex mapping certifies; 20 000: the quad mapping
+        qq, qqd, gg = (x.repeat(reps, 1) for x in (q, qd, goal))
+        e2 = Engine(d2, 0)
+        j2 = _engine_env(d2, RMP2_STRICT_CERTIFY="0", **({"RMP2_KERNEL": "hex"} if mapping == "hex" else {}))
+        s2 = torch.zeros(R * reps, dtype=torch.int32, device="cuda")
+        g2 = e2.step(qq, qqd, gg, status=s2)
+        assert "certified" in e2.last_kernel() and mapping in e2.last_kernel(), e2.last_kernel()
+        w2 = j2.step(qq, qqd, gg)
+        assert ("strict pseudo-inverse" if mapping == "hex" else "rmp2_pinv_kernel") in j2.last_kernel(), j2.last_kernel()
+        torch.cuda.synchronize()
+        ulp2 = np.spacing(np.abs(w2.cpu().numpy()).max(axis=1, keepdims=True).astype(np.float32))
+        assert (np.abs(g2.cpu().numpy() - w2.cpu().numpy()) <= 2.0 * ulp2).all()
+        assert ((s2.cpu().numpy() & D.STATUS_JACOBI) != 0).mean() < 0.01
+        _check(g2[:256].cpu().numpy(), O.step(d2, s["q"][:256], s["qd"][:256], s["goal"][:256])["qdd64"], f"config 2, strict, certified ({mapping})")
     lane = _engine(desc, "lane")
     want_lane = lane.step(q, qd, goal, obstacles=lane.obstacles(spheres=torch.from_numpy(sph)))
     assert "STRICT" in lane.last_kernel()
@@ -527,13 +516,16 @@ def test_strict_step_certifies_full_rank_and_keeps_the_jacobi_for_the_rest(torch
     sph = Cf.sample_spheres(np.random.default_rng(7))
     q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
     table, desc = Cf.config3("pinv")
+    # small fleets take the 16-lanes-per-robot mapping, whose Gauss-Jordan certifies from its own pivot rows; fleets the quad
+    # mapping.  The all-Jacobi counterpart on the SAME systems: the hex mapping's strict careful path / the two kernels
+    mapping = "hex" if R <= 8192 else "quad"
     eng = Engine(desc, 0)
-    jac = _engine_env(desc, RMP2_STRICT_CERTIFY="0")
+    jac = _engine_env(desc, RMP2_STRICT_CERTIFY="0", **({"RMP2_KERNEL": "hex"} if mapping == "hex" else {}))
     st = torch.zeros(R, dtype=torch.int32, device="cuda")
     got = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st)
-    assert "certified" in eng.last_kernel() and "quad" in eng.last_kernel()
+    assert "certified" in eng.last_kernel() and mapping in eng.last_kernel(), eng.last_kernel()
     want = jac.step(q, qd, goal, obstacles=jac.obstacles(spheres=torch.from_numpy(sph)))
-    assert "rmp2_pinv_kernel" in jac.last_kernel()
+    assert ("strict pseudo-inverse" if mapping == "hex" else "rmp2_pinv_kernel") in jac.last_kernel(), jac.last_kernel()
     torch.cuda.synchronize()
     g, w, stc = got.cpu().numpy(), want.cpu().numpy(), st.cpu().numpy()
     fin = np.isfinite(w).all(axis=1)
@@ -559,14 +551,15 @@ def test_strict_step_certifies_full_rank_and_keeps_the_jacobi_for_the_rest(torch
                         Cf.TARGET_ATTRACTOR_PARAMS, goal_len=3),
              D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, [1.0, 0.0, 1e-30])]
     dn = D.build_desc(table, specs, "pinv")
-    en, jn = Engine(dn, 0), _engine_env(dn, RMP2_STRICT_CERTIFY="0")
+    en = Engine(dn, 0)
+    jn = _engine_env(dn, RMP2_STRICT_CERTIFY="0", **({"RMP2_KERNEL": "hex"} if m <= 8192 and mapping == "hex" else {}))
     stn = torch.zeros(m, dtype=torch.int32, device="cuda")
     gn = en.step(q[:m], qd[:m], goal[:m], status=stn)
     assert "certified" in en.last_kernel()
     Mn = torch.zeros((m, 9, 9), dtype=torch.float64, device="cuda")
     fn = torch.zeros((m, 9), dtype=torch.float64, device="cuda")
     wn = jn.step(q[:m], qd[:m], goal[:m], M=Mn, f=fn)
-    assert "rmp2_pinv_kernel" in jn.last_kernel()
+    assert "pseudo-inverse" in jn.last_kernel() or "rmp2_pinv_kernel" in jn.last_kernel()
     torch.cuda.synchronize()
     stn = stn.cpu().numpy()
     assert ((stn & D.STATUS_JACOBI) != 0).all(), "a metric with rows of 1e-30 must not be certified"
