@@ -36,6 +36,11 @@ def lib():
             f"{LIB_PATH} not found: the HIP engine is not built.  Run "
             "`python -c \"import __graft_entry__ as g; g.build()\"` at the repo root (needs hipcc). "
             "There is no CPU fallback.")
+    # PyTorch first: the process then has ONE HIP runtime, PyTorch's (its bundled libamdhip64), which this library's HIP calls
+    # resolve to as well.  Loaded the other way round -- this library before torch -- the process ends up with the system
+    # runtime AND PyTorch's, and hipGetDeviceCount of the first answers "no device" (seen with build() followed by smoke() in
+    # one process).  PyTorch is the plumbing for device memory and streams everywhere above this loader anyway.
+    import torch  # noqa: F401
     l = C.CDLL(LIB_PATH)
     l.rmp2_abi_version.restype = C.c_int
     l.rmp2_sizeof_desc.restype = C.c_size_t
