@@ -119,8 +119,14 @@ typedef struct rmp2_leaf {
 #define RMP2_SOLVE_AUTO 0 /* fp64 LU with threshold pivoting; robots whose metric is (numerically)
                              singular fall through to the PINV path.  Same result as PINV to fp64
                              rounding whenever M is well conditioned.                         */
-#define RMP2_SOLVE_PINV 1 /* reference-faithful: fp64 Moore-Penrose pseudo-inverse by one-sided Jacobi
-                             SVD with TensorFlow's cutoff 10*n*eps*sigma_max (rmp.py:153)     */
+#define RMP2_SOLVE_PINV 1 /* reference-faithful: qdd = pinv(M) f, the fp64 Moore-Penrose pseudo-inverse with
+                             TensorFlow's cutoff 10*n*eps*sigma_max (rmp.py:153).  Where the elimination can CERTIFY
+                             that every singular value of a robot's M lies above the cutoff (sets with an inertia
+                             leaf: a bound on |M^-1| from its own triangular factor), pinv(M) = inv(M) and the
+                             elimination's result stands; every other robot -- and every robot of a set without
+                             an inertia leaf -- is resolved by a one-sided Jacobi SVD (status RMP2_STATUS_JACOBI /
+                             RANK_DROP).  Same numbers either way to fp64 rounding; the certifying step costs
+                             what the AUTO step costs.                                                      */
 
 typedef struct rmp2_desc {
   int32_t abi_version; /* must be RMP2_ABI_VERSION */
@@ -344,9 +350,11 @@ int rmp2_step(rmp2_handle *h, const float *q, const float *qd, const float *goal
  * q and qd (device, [R][n_dof]) are advanced IN PLACE; out->qdd receives the last qdd, out->status the
  * OR of the per-step status words.  Goals and the sphere table are constant during the rollout;
  * RMP2_OBS_EXPLICIT_PAIRS is rejected (closest-point pairs are only valid for the state they were
- * computed at).  A handle created with RMP2_SOLVE_PINV rolls out with the strict pseudo-inverse on every robot and step (the
- * 16-lanes-per-robot mapping at any fleet size; RMP2_ERR_UNSUPPORTED where that mapping cannot hold the program) -- never
- * resolved differently from what was asked for. */
+ * computed at; sets with attached-point leaves roll out when their pairs come from a SHARED_SPHERES table with
+ * link_capsules -- formed anew every control step inside the launch -- instead of explicit arrays).  A handle created with
+ * RMP2_SOLVE_PINV rolls out with the pseudo-inverse semantics on every robot and step (certifying elimination + Jacobi for the
+ * rest where the set has an inertia leaf; otherwise the 16-lanes-per-robot mapping's Jacobi at any fleet size;
+ * RMP2_ERR_UNSUPPORTED where that mapping cannot hold the program) -- never resolved differently from what was asked for. */
 typedef struct rmp2_rollout_cfg {
   int32_t n_control_steps;
   int32_t substeps;
