@@ -29,6 +29,9 @@
 #include "rmp2_device.h"
 #include "rmp2_solve.h"
 
+#ifndef RMP2_EXPLICIT_WINDOW
+#define RMP2_EXPLICIT_WINDOW 2  // explicit pairs, register-capped builds: slots loaded this many ahead of their evaluation
+#endif
 #ifndef RMP2_EXPLICIT_LOCAL
 #define RMP2_EXPLICIT_LOCAL 1  // explicit pairs: every lane evaluates the pairs it loaded (0: compacted + re-fetched; A/B)
 #endif
@@ -652,6 +655,10 @@ __device__ __forceinline__ void pair_loop_link_list(const float* table, bool cap
 // slot, out of its own registers (RMP2_EXPLICIT_LOCAL) -- the dealt pair's second fetch is an L2 round trip per trip on the
 // wave's critical path, and this mode is bound by latency, not by issue slots: 132 -> 104 us per step at 65 536 robots.
 struct F3 { float x, y, z; };
+// WIN > 0 (the register-capped builds): the leaf's eight slots are not loaded up front (48 registers) but in a rolling window
+// -- the loads of slot i + WIN go out before slot i is evaluated, compiler barriers keep them from being hoisted --, so that the
+// explicit-pair step fits the 168- / 128-register builds that put three / four waves on a SIMD.
+template <int WIN = 0>
 __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const float* po, int count, int sub,
                                                           const float P3[3], const float V3[3], const float A3[3],
                                                           const float* P, const float* IP, float thr2, float S[6], float h[3]) {
@@ -672,6 +679,45 @@ __device__ __forceinline__ void pair_loop_explicit_culled(const float* pl, const
       // (loading the NEXT leaf's pairs early -- 48 registers held through the quad sums and the pull-back -- was tried twice,
       // on the compacted loop and on this one: 184 us against 124 and 171 against 104 per step; tools/experiments/README.md)
       F3 a[8], o[8];
+      if (WIN > 0) {
+        auto load = [&](int i) __attribute__((always_inline)) {
+          const int pos = base + sub + kQuad * i;
+          a[i] = *reinterpret_cast<const F3*>(pl + 3 * pos);
+          o[i] = *reinterpret_cast<const F3*>(po + 3 * pos);
+        };
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) load(i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          asm volatile("" ::: "memory");  // (the loads of slot i + WIN stay HERE: hoisted, they would all be live at once)
+          if (i + WIN < 8) load(i + WIN);
+          const float diff[3] = {(P3[0] + (a[i].x - P3[0])) - o[i].x, (P3[1] + (a[i].y - P3[1])) - o[i].y,
+                                 (P3[2] + (a[i].z - P3[2])) - o[i].z};
+          const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+          const bool on = !(d2 > thr2);
+          if (!__any(on)) continue;
+          const float inv = rsq0(d2);
+          const float d = d2 * inv;
+          const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+          const float xdot = dot3(nh, V3);
+          const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+          float acc, met;
+          obstacle_pair(P, IP, d, xdot, acc, met);
+          if (!on) met = 0.f;
+          const float wgt = met * (acc - cd);
+          const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+          S[0] = fmaf(mn[0], nh[0], S[0]);
+          S[1] = fmaf(mn[0], nh[1], S[1]);
+          S[2] = fmaf(mn[0], nh[2], S[2]);
+          S[3] = fmaf(mn[1], nh[1], S[3]);
+          S[4] = fmaf(mn[1], nh[2], S[4]);
+          S[5] = fmaf(mn[2], nh[2], S[5]);
+          h[0] = fmaf(wgt, nh[0], h[0]);
+          h[1] = fmaf(wgt, nh[1], h[1]);
+          h[2] = fmaf(wgt, nh[2], h[2]);
+        }
+        continue;  // (next chunk)
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int pos = base + sub + kQuad * i;
@@ -1863,8 +1909,8 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, stage_base, lane, g, sub, P3,
                                       V3, A3, lh.P, IP, thr * thr * kCullSlack, S, h);
             } else
-            pair_loop_explicit_culled(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3, lh.P, IP,
-                                      thr * thr * kCullSlack, S, h);
+            pair_loop_explicit_culled<(MINW >= 3 ? RMP2_EXPLICIT_WINDOW : 0)>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3,
+                                                                            lh.P, IP, thr * thr * kCullSlack, S, h);
           } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
             pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
                                                                   V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);

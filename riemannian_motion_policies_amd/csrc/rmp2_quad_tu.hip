@@ -42,7 +42,10 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     minw = (bc == 4 || bc >= 7) ? 4 : 2;
     // explicit pairs (interface B) are bound by memory latency, not by issue slots: the two-wave build keeps a whole leaf's
     // loads (and the next leaf's prefetch) in flight per wave -- 123.7 us per step at 65 536 robots against 148.7 with four
-    if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = 2;
+    // (round 4: with the leaf's slots loaded in a rolling window the 168-register build is spill-free too; it wins where it
+    // turns two rounds into one -- 49 152 robots: 80.5 against 89.5 us --, nowhere else: 65 536 robots 129.8 / 118.3 us with
+    // three / four waves against 104.6 with two)
+    if (o.mode == RMP2_OBS_EXPLICIT_PAIRS) minw = bc == 3 ? 3 : 2;
   }
   size_t bytes = (latency ? lds_bytes + stage_bytes : lds_bytes) + pt_bytes;
   h->last_kernel = quad_certifies_strict(h)
