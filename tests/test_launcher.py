@@ -97,3 +97,27 @@ def test_stub_collective_library_exports_what_the_exchange_binds():
     uid2 = (ctypes.c_char * 128)()
     lib.ncclGetUniqueId(uid2)
     assert bytes(uid) != bytes(uid2)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The line `python bench.py` printed on the GPU box this round (profiles/r04_bench_default.json): every field the driver's
+    contract names, the roofline and cpu_baseline objects, and the round-4 additions (tolerance rule + robots admitted per branch
+    in result_check)."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(line["value"] - line["config"]["robots_per_gpu"] * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference")
+    chk = line["result_check"]
+    assert chk["rejected"] == 0 and sum(chk["admitted_by"].values()) == chk["robots_checked"] and "north star" in chk["tolerance"]
