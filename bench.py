@@ -829,6 +829,22 @@ def worker(args) -> int:
                 "roofline": roofline_obj(eng2.last_kernel(), k2, w2["bytes"] * 4096, w2["flops"] * 4096, w2["bytes"], w2["flops"],
                                          "config2", 4096, "valu"),
                 "note": "latency regime: 1024 waves on 1024 SIMDs, ~3 us of the launch is dispatch floor (DESIGN.md section 5)"}
+        if workload == "config3" and args.solve == "auto" and not args.no_secondary:
+            # the same workload under the reference's ONLY resolve (solve = "pinv", rmp.py:153-154), same process, same inputs:
+            # one certifying launch -- what reference semantics cost over the line's solve = "auto"
+            _, dp = Cf.config3("pinv")
+            engp = Engine(dp, local_rank)
+            qp, qdp, gp = keep[0], keep[1], keep[2]
+            op = torch.empty_like(qp)
+            launchp, _ = engp.bind(qp, qdp, gp, obstacles=engp.obstacles(spheres=torch.from_numpy(spheres_np).to(dev)), out=op)
+            kp = Timed(dev, False).run(launchp, min(args.steps, 1000), min(args.warmup, 100))
+            torch.cuda.synchronize(dev)
+            line["solve_pinv"] = {
+                "workload": wl["name"] + ', solve = "pinv" (the reference\'s resolve)', "robots": R,
+                "ms_per_step": kp["dt"] / min(args.steps, 1000) * 1e3, "value": R * min(args.steps, 1000) / kp["dt"],
+                "unit": "robot control steps/s", "kernel": engp.last_kernel(),
+                "max_abs_diff_to_auto": float((op - keep[3]).abs().nan_to_num(0.0).max().item()),
+                "note": "full rank certified per robot inside the elimination (pinv = inv there), Jacobi pseudo-inverse for the rest"}
         if not args.no_cpu_baseline and world == 1 and desc is not None:
             line["cpu_baseline"] = cpu_baseline(workload, desc, table, s, spheres_np)
         print(json.dumps(line), flush=True)
