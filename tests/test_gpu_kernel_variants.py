@@ -217,6 +217,10 @@ def test_culling_is_exact_and_hardware_approximations_are_bounded(torch_mod, ker
     assert np.median(e_fast[near]) <= 4 * max(np.median(e_acc[near]), 1e-6), (np.median(e_fast[near]), np.median(e_acc[near]))
     assert np.quantile(e_fast[near], 0.95) <= 4 * max(np.quantile(e_acc[near], 0.95), 1e-5), \
         (np.quantile(e_fast[near], 0.95), np.quantile(e_acc[near], 0.95))
+    # (iii) and EVERY robot -- penetrating ones included -- is bounded by oracle.accuracy_gate: none is exempted
+    ref_sys = O.step(desc, s["q"], s["qd"], s["goal"], spheres=sph)
+    verdict = O.accuracy_gate(fast, ref_sys, spread=O.fp32_resolution(desc, s["q"], s["qd"], s["goal"], spheres=sph))
+    assert verdict["ok"].all(), f"{kernel}: {O.gate_summary(verdict)}"
 
 
 def test_quad_register_caps_agree_bitwise_at_fleet_sizes(torch_mod):
@@ -365,10 +369,18 @@ def test_ragged_lists_as_membership_masks_and_their_fallback(torch_mod, golden_d
             if b - a >= 2:
                 idx2[b - 1] = idx2[a]
         obs = eng.obstacles(spheres=torch.from_numpy(sph), csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx2))
-        ref = O.step(desc, g["q"], g["qd"], g["goal"], spheres=sph, csr_offset=off, csr_index=idx2)["qdd64"]
+        kw = dict(spheres=sph, csr_offset=off, csr_index=idx2)
+        ref = O.step(desc, g["q"], g["qd"], g["goal"], **kw)
         qdd = eng.step(q, qd, goal, obstacles=obs)
         torch.cuda.synchronize()
-        _check(qdd.cpu().numpy(), ref, f"ragged K={K} {kernel} dup={dup}", mask=clear)
+        _check(qdd.cpu().numpy(), ref["qdd64"], f"ragged K={K} {kernel} dup={dup}", mask=clear)
+        if (~clear).any():      # ... and the robots an extra sphere comes close to are bounded too (oracle.accuracy_gate)
+            nc = ~clear
+            verdict = O.accuracy_gate(qdd.cpu().numpy()[nc], {k: ref[k][nc] for k in ("qdd64", "M", "f")},
+                                      spread=O.fp32_resolution(desc, g["q"][nc], g["qd"][nc], g["goal"][nc], spheres=sph,
+                                                               csr_offset=np.concatenate([[0], np.cumsum(np.diff(off)[nc])]).astype(np.int32),
+                                                               csr_index=np.concatenate([idx2[off[r]:off[r + 1]] for r in np.nonzero(nc)[0]]).astype(np.int32)))
+            assert verdict["ok"].all(), f"ragged K={K} {kernel} dup={dup}: {O.gate_summary(verdict)}"
 
 
 def test_two_by_two_closed_form_pseudo_inverse(torch_mod, golden_dir):
@@ -461,6 +473,10 @@ def test_strict_pseudo_inverse_at_fleet_size_takes_two_kernels(torch_mod):
     clear = clr >= 0.05
     assert clear[:n].sum() > n // 3
     _check(got[:n].cpu().numpy(), ref["qdd64"], "two-kernel strict step vs oracle", mask=clear[:n])
+    near = ~clear[:n]           # ... and the robots near contact are bounded too: every one passes oracle.accuracy_gate
+    verdict = O.accuracy_gate(got[:n].cpu().numpy()[near], {k: ref[k][near] for k in ("qdd64", "M", "f")},
+                              spread=O.fp32_resolution(desc, s["q"][:n][near], s["qd"][:n][near], s["goal"][:n][near], spheres=sph))
+    assert verdict["ok"].all(), f"two-kernel strict step, near contact: {O.gate_summary(verdict)}"
     _check(got.cpu().numpy(), want_lane.cpu().numpy().astype(np.float64), "two-kernel strict step vs lane strict kernel", mask=clear)
     assert (st[torch.from_numpy(clear).cuda()] == 0).all()
     # a caller who asks for the combined metric (debug output, robot index slowest) gets it copied out of the two kernels'

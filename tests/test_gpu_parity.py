@@ -223,7 +223,8 @@ def test_full_size_properties(torch_mod):
             # perf inputs are unrestricted: some robots touch / penetrate spheres, where the reference
             # algorithm itself amplifies one fp32 ulp of distance by |x / 0.01| and |qdd| reaches 1e3
             # (SURVEY section 7).  The 1e-5 gate applies to the robots with >= 0.05 m clearance, as in
-            # the fixtures; the rest must agree to 1e-3 relative.
+            # the fixtures; EVERY other robot must pass oracle.accuracy_gate (backward error against the
+            # oracle's system, else its own fp32 resolution) -- none is exempted.
             T = O.forward_kinematics(desc, s["q"][sub], "f64")
             frames = [desc.leaves[i].frame for i in range(desc.n_leaves) if desc.leaves[i].taskmap == 2]
             org = T[:, frames][:, :, :3, 3]
@@ -231,7 +232,10 @@ def test_full_size_properties(torch_mod):
             clear = clr >= 0.05
             assert clear.sum() > 50
             assert (e[clear] <= ATOL * mag[clear]).all(), f"{name}: clear robots worst {e[clear].max():.2e}"
-            assert (e[~clear] <= 1e-3 * mag[~clear]).mean() > 0.98, f"{name}: near-contact robots {e[~clear].max():.2e}"
+            rest = sub[~clear]
+            verdict = O.accuracy_gate(qdd[rest], {k: ref[k][~clear] for k in ("qdd64", "M", "f")},
+                                      spread=O.fp32_resolution(desc, s["q"][rest], s["qd"][rest], s["goal"][rest], **obs))
+            assert verdict["ok"].all(), f"{name}: near-contact robots {O.gate_summary(verdict)}"
         else:
             assert (e <= ATOL * mag).all(), f"{name}: {e.max()}"
 
