@@ -201,7 +201,7 @@ def spawn_ranks(args) -> int:
     """--gpus N without a launcher: start N fresh ranks.  This process never initialises HIP (see count_gpus_without_hip):
     it only counts devices through sysfs, builds the library with hipcc and waits for its children."""
     have = count_gpus_without_hip()
-    if have < args.gpus:
+    if have < (1 if args.rehearse_one_gpu else args.gpus):
         print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} HIP device(s); "
               f"not silently running on fewer", file=sys.stderr)
         return 2
@@ -212,7 +212,7 @@ def spawn_ranks(args) -> int:
         port = sk.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if args.rehearse_one_gpu else str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         # a session (= process group) of its own per rank: the supervisor can end exactly what it started
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -460,6 +460,7 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
             if exch is None:
                 print(f"bench.py: native exchange unavailable (rank {rank}: {err!r}); every rank falls back to --exchange torch", file=sys.stderr)
                 args.exchange = "torch"
+                args.exchange_fell_back = f"native exchange unavailable on at least one rank ({err!r}); every rank took --exchange torch"
                 return build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=seed_rank, exch=None)
         while exch.pending < exch.depth:   # (a reused exchange -- the emulation -- still holds the previous user's gathers)
             exch.start(local, local_is_ready=True)
@@ -655,6 +656,8 @@ def worker(args) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_one_gpu:
+        local_rank = 0      # every rank on device 0 (a launcher's LOCAL_RANK is ignored): see --rehearse-one-gpu
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the RMP2 engine has no CPU path")
     if torch.cuda.device_count() <= local_rank:
@@ -679,7 +682,12 @@ def worker(args) -> int:
         saved_fd1 = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if args.rehearse_one_gpu:
+                # RCCL refuses two ranks on one device; gloo carries the barriers, the MAX-reduce, the rank agreement and
+                # (after the native exchange's communicator has failed on every rank) the torch-driven obstacle exchange
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize(dev)
         finally:
@@ -719,9 +727,12 @@ def worker(args) -> int:
         if workload == "config4":
             ex = next(k for k in keep if hasattr(k, "start") and hasattr(k, "world"))
             line_extra["exchange"] = args.exchange
+            if getattr(args, "exchange_fell_back", None):
+                line_extra["exchange_fell_back"] = args.exchange_fell_back
             # from the communicator the exchange joined (the library's own for the native exchange, c10d's otherwise), not from
             # WORLD_SIZE: the driver can hold it against --gpus
-            line_extra["rccl_nranks"] = int(ex.nranks) if args.exchange == "native" else int(dist.get_world_size())
+            line_extra["rccl_nranks"] = int(ex.nranks) if args.exchange == "native" else (
+                None if args.rehearse_one_gpu else int(dist.get_world_size()))     # (a rehearsal's process group is gloo's)
             line_extra["exchange_depth"] = int(args.exchange_depth) if args.exchange == "native" else 1
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
@@ -797,7 +808,7 @@ def worker(args) -> int:
             "metric": "RMP2 control steps/sec (batched robots)",
             "value": value,
             "unit": "robot control steps/s",
-            "n_gpus": world,
+            "n_gpus": 1 if args.rehearse_one_gpu else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": kern["dt"] / args.steps * 1e3,
@@ -813,6 +824,12 @@ def worker(args) -> int:
                                      "config3" if workload == "config4" else workload, R, bound),
         }
         line.update(line_extra)
+        if args.rehearse_one_gpu:
+            line["rehearsal"] = {
+                "ranks": world, "gpus": 1, "backend": "gloo",
+                "note": f"{world} rank processes time-sharing ONE GPU: executes the launcher, the rank agreement, the exchange's "
+                        "all-rank fall-back and the barrier / MAX-over-ranks timing of the N > 1 path on a one-GPU box.  NOT a "
+                        "scaling measurement: `value` is the ranks' robots over the time they took sharing the device"}
         if workload in ("config3", "config4") and not args.no_secondary:
             # BASELINE configs[1] in the same process: the latency-bound fleet (4096 robots: one wave per SIMD)
             t2, d2 = Cf.config2(args.solve)
@@ -882,6 +899,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="config5: replay the shard's step as a HIP graph (A/B: measured slower than eager)")
     ap.add_argument("--rank-timeout", type=float, default=540.0,
                     help="--gpus N without a launcher: seconds after which ranks that are still running are ended and the job fails")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="--gpus N on a node with ONE GPU: every rank on device 0, torch's gloo backend instead of RCCL (which "
+                         "refuses two ranks on one device).  Executes the N > 1 control flow; the line is labelled a rehearsal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()

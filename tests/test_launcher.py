@@ -121,3 +121,50 @@ def test_committed_bench_line_keeps_the_contract():
     assert cpu["kind"] in ("port", "reference")
     chk = line["result_check"]
     assert chk["rejected"] == 0 and sum(chk["admitted_by"].values()) == chk["robots_checked"] and "north star" in chk["tolerance"]
+
+
+def test_spawned_ranks_share_device_0_in_a_rehearsal(monkeypatch):
+    """bench.py --gpus N --rehearse-one-gpu: spawn_ranks needs ONE device, gives every child LOCAL_RANK 0 and its own RANK, and
+    still refuses N ranks on real devices the node does not have."""
+    import types
+    import bench
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            started.append(env)
+
+        def poll(self):
+            return 0
+
+    import __graft_entry__ as ge
+    monkeypatch.setattr(ge, "build_hip", lambda: None)
+    monkeypatch.setattr(bench, "count_gpus_without_hip", lambda: 1)
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    args = types.SimpleNamespace(gpus=2, rehearse_one_gpu=False, rank_timeout=5.0)
+    assert bench.spawn_ranks(args) == 2 and not started          # two real devices asked for, one present: refused, nothing started
+    args.rehearse_one_gpu = True
+    assert bench.spawn_ranks(args) == 0
+    assert [e["RANK"] for e in started] == ["0", "1"] and {e["LOCAL_RANK"] for e in started} == {"0"}
+    assert {e["WORLD_SIZE"] for e in started} == {"2"} and len({e["MASTER_PORT"] for e in started}) == 1
+
+
+def test_committed_two_rank_rehearsal_lines():
+    """profiles/r04_rehearsal_2ranks_*.json: what `tools/gpu_calls_r04_rehearsal.sh` printed on the one-GPU box -- two rank
+    PROCESSES through bench.py's own launcher and through torch.distributed.run (the driver's command shape).  Config 4: the
+    native exchange's communicator failed on both ranks (RCCL refuses two ranks on one device), the ranks agreed and every rank
+    took the torch-driven exchange; both configs: every checked robot passed the gate; each line says it is a rehearsal."""
+    import json
+    for name in ("config4", "config4_torchrun", "config5"):
+        line = json.loads(open(os.path.join(ROOT, "profiles", f"r04_rehearsal_2ranks_{name}.json")).read().strip().splitlines()[-1])
+        assert line["rehearsal"]["ranks"] == 2 and line["rehearsal"]["gpus"] == 1 and line["n_gpus"] == 1
+        assert "NOT a scaling measurement" in line["rehearsal"]["note"]
+        total = line["config"]["robots_per_gpu"] * 2
+        assert abs(line["value"] - total * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]      # all ranks' robots over the MAX time
+        chk = line["result_check"]
+        if name == "config5":
+            assert chk["two_joint"]["rejected"] == 0 and chk["panda"]["rejected"] == 0 and len(line["shards"]) == 2
+        else:
+            assert chk["rejected"] == 0
+            assert line["exchange"] == "torch" and "every rank took --exchange torch" in line["exchange_fell_back"]
+            assert line["rccl_nranks"] is None
