@@ -178,7 +178,7 @@ typedef struct rmp2_obstacles {
   const float *p_link;                     /* device [R][P][3]                               */
   const float *p_obs;                      /* device [R][P][3]                               */
   const int32_t *csr_offset;               /* device [R+1]                                   */
-  const int32_t *csr_index;                /* device [csr_offset[R]]                         */
+  const int32_t *csr_index;                /* device [csr_offset[R]]; non-null even when every list is empty */
   const float *dist;                       /* device [R][P], FK_POINT leaves only (else NULL) */
   const float *link_capsules;              /* device [n_distance_leaves][8] = (a, radius, b, -) in each distance leaf's FRAME
                                               coordinates (leaf order), or NULL.  SHARED_SPHERES only, at most 256 primitives:

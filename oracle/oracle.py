@@ -209,7 +209,35 @@ def fp32_resolution(desc: D.Desc, q, qd, goal=None, trials: int = 4, seed: int =
         return np.fmax(sp, np.abs(a - b).max(axis=1))
 
 
-def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, spread_factor: float = 8.0):
+def system_resolution(ref, trials: int = 4, eps: float = 2.0 ** -22, seed: int = 0):
+    """Per robot: how far the resolve `pinv(M) f` (TensorFlow's cutoff, rmp.py:153-154) of the oracle's combined system moves when
+    every ENTRY of M and f moves by a relative `eps` (two fp32 roundings by default) with a random sign, the maximum over `trials`
+    draws, inf-norm.  The reference forms every leaf's J^T A J and J^T A (xdd - c) in fp32 (rmp.py:133-151), so each entry of the
+    summed (M, f) carries at least that much relative error in ANY fp32 evaluation; an entrywise-relative perturbation keeps exact
+    zeros (a joint no leaf touches stays out of the system).  It is the resolution of the result at the SYSTEM level -- what matters for
+    rank-deficient and inconsistent systems (least-squares sensitivity grows with cond^2 times the residual), which the residual
+    test B of accuracy_gate cannot judge.  The `system_spread` argument of accuracy_gate."""
+    rng = np.random.default_rng(seed)
+    M, f = ref["M"], ref["f"]
+    R, n = f.shape
+    finite = np.isfinite(M).all(axis=(1, 2)) & np.isfinite(f).all(axis=1)
+    Mz = np.where(finite[:, None, None], M, 0.0)
+    fz = np.where(finite[:, None], f, 0.0)
+    rcond = 10.0 * n * np.finfo(np.float64).eps
+
+    def resolve(A, b):
+        return np.einsum("rij,rj->ri", np.linalg.pinv(A, rcond=rcond), b)
+
+    base = resolve(Mz, fz)
+    spread = np.zeros(R)
+    for _ in range(trials):
+        dM = 1.0 + eps * rng.choice(np.array([-1.0, 1.0]), Mz.shape)
+        df = 1.0 + eps * rng.choice(np.array([-1.0, 1.0]), fz.shape)
+        spread = np.fmax(spread, np.abs(resolve(Mz * dM, fz * df) - base).max(axis=1))
+    return np.where(finite, spread, 0.0)
+
+
+def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, spread_factor: float = 8.0, system_spread=None):
     """Per-robot accuracy verdict of a computed q-double-dot `got` [R, n] against an oracle result `ref` (the dict of step()).
     EVERY robot gets a bound -- none is exempted for being ill-conditioned or near contact:
 
@@ -221,6 +249,9 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, 
       C  (fp32 resolution, only when `spread` = fp32_resolution(...) of the same robots is given)
                         |got - ref|_inf <= spread_factor * spread : within a few times what one fp32 rounding does to the
                         exact result / what the reference-precision oracle itself misses the fp64 result by
+      D  (fp32 resolution of the system, only when `system_spread` = system_resolution(ref) is given)
+                        |got - ref|_inf <= spread_factor * system_spread : within a few times what two fp32 roundings of every
+                        entry of the oracle's (M, f) do to its resolve -- the bound for rank-deficient / inconsistent systems
 
     B is the statement "got solves a system within relative eta of the oracle's": it is what fp32 leaves can promise a robot
     whose metric is ill-conditioned, and it does not loosen with the condition number -- the forward clause only states its
@@ -255,15 +286,18 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, 
     c = np.zeros(len(got), bool)
     if spread is not None:
         c = finite & (err_inf <= spread_factor * np.asarray(spread))
+    d = np.zeros(len(got), bool)
+    if system_spread is not None:
+        d = finite & (err_inf <= spread_factor * np.asarray(system_spread))
     # a robot the oracle itself resolves to NaN (non-finite state): the engine must answer NaN too
     both_nan = ~np.isfinite(q_ref).all(axis=1) & ~np.isfinite(got).all(axis=1)
-    return {"a": a, "b": b & ~a, "c": c & ~a & ~b, "ok": a | b | c | both_nan, "both_nan": both_nan, "omega": omega, "cond": cond,
-            "err_inf": err_inf}
+    return {"a": a, "b": b & ~a, "c": c & ~a & ~b, "d": d & ~a & ~b & ~c, "ok": a | b | c | d | both_nan, "both_nan": both_nan,
+            "omega": omega, "cond": cond, "err_inf": err_inf}
 
 
 def gate_summary(g) -> dict:
     """Counts per admitting branch of an accuracy_gate verdict (for assertion messages and bench.py's result_check)."""
     return {"robots": int(len(g["ok"])), "north_star_1e-5": int(g["a"].sum()), "backward_error": int(g["b"].sum()),
-            "input_resolution": int(g["c"].sum()), "both_nan": int((g["both_nan"] & ~g["a"]).sum()), "rejected": int((~g["ok"]).sum()),
+            "input_resolution": int(g["c"].sum()), "system_resolution": int(g["d"].sum()), "both_nan": int((g["both_nan"] & ~g["a"]).sum()), "rejected": int((~g["ok"]).sum()),
             "worst_abs_err": float(np.nanmax(g["err_inf"])) if len(g["err_inf"]) else 0.0,
             "worst_omega_beyond_north_star": float(g["omega"][~g["a"]].max()) if (~g["a"]).any() else 0.0}

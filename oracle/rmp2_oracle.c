@@ -174,9 +174,62 @@ static int is_ancestor_or_self(const rmp2_robot *rb, int anc, int frame) {
   return 0;
 }
 
+/* Structural zeros of the position Jacobian.  The reference obtains d p_frame / d q_j by differentiating the product of LOCAL
+ * transforms (kinematics.py:240-247, 265-266): where the origin of `frame`, expressed in the frame of a revolute ancestor joint
+ * j, has exact zeros off joint j's axis -- the joint's own origin; a child joint with <origin xyz="0 0 0"> (Panda joints 1/2,
+ * 5/6); a tool frame straight up the last joint's axis -- every product in that derivative has an exact zero factor and the
+ * column is EXACTLY zero, whatever q.  The world-frame lever z_j x (p_frame - p_j) used below is rounding noise there (1e-8): a
+ * tiny but "real" column, which the pseudo-inverse of a set that gives dof j no other metric keeps now and then (rmp.py:153-154).
+ * So the zero pattern is taken the reference's way -- the chain of local transforms below joint j, multiplied left to right in
+ * `real` at one configuration, lever tested for EXACT zeros against the joint axis -- once per call (the pattern does not depend
+ * on q); lz[frame][j] != 0: the column of joint-frame j is exactly zero.  (Pinned against the autodiff restatement,
+ * torch_autodiff_oracle.py, in tests/test_oracle_pins.py.) */
+static void local_transform(const rmp2_robot *rb, int i, real qv, real Tl[12]) {
+  const real ax[3] = {(real)rb->axis[i][0], (real)rb->axis[i][1], (real)rb->axis[i][2]};
+  real Tv[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  if (rb->joint_type[i] == RMP2_JOINT_REVOLUTE) {
+    const real c = R_COS(qv), s = R_SIN(qv), omc = (real)1 - c;
+    const real ut[3][3] = {{0, -ax[2], ax[1]}, {ax[2], 0, -ax[0]}, {-ax[1], ax[0], 0}};
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 3; ++k) Tv[4 * r + k] = c * (r == k ? (real)1 : (real)0) + s * ut[r][k] + omc * (ax[r] * ax[k]);
+  } else if (rb->joint_type[i] == RMP2_JOINT_PRISMATIC) {
+    for (int r = 0; r < 3; ++r) Tv[4 * r + 3] = qv * ax[r];
+  }
+  real Tc[12];
+  for (int k = 0; k < 12; ++k) Tc[k] = (real)rb->T_const[i][k];
+  mat34_mul(Tc, Tv, Tl);
+}
+
+static void lever_zero_table(const rmp2_robot *rb, const float *q0, unsigned char lz[FMAX][FMAX]) {
+  const int F = rb->n_frames;
+  static const real I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  real Tl[FMAX][12];
+  for (int i = 0; i < F; ++i) local_transform(rb, i, rb->q_index[i] >= 0 ? (real)q0[rb->q_index[i]] : (real)0, Tl[i]);
+  for (int f = 0; f < F; ++f) {
+    int path[FMAX], len = 0;
+    for (int j = f; j >= 0; j = rb->parent[j]) path[len++] = j; /* f, parent(f), ..., root */
+    for (int j = 0; j < F; ++j) lz[f][j] = 0;
+    for (int a = 0; a < len; ++a) {
+      const int j = path[a];
+      if (rb->joint_type[j] != RMP2_JOINT_REVOLUTE || rb->q_index[j] < 0) continue;
+      real Mx[12], tmp[12];
+      memcpy(Mx, I34, sizeof(Mx));
+      for (int b = a - 1; b >= 0; --b) { /* the transforms below joint j, down to the frame */
+        mat34_mul(Mx, Tl[path[b]], tmp);
+        memcpy(Mx, tmp, sizeof(Mx));
+      }
+      const real ax[3] = {(real)rb->axis[j][0], (real)rb->axis[j][1], (real)rb->axis[j][2]};
+      const real r[3] = {Mx[3], Mx[7], Mx[11]};
+      real c[3];
+      cross3(ax, r, c);
+      lz[f][j] = (c[0] == 0 && c[1] == 0 && c[2] == 0);
+    }
+  }
+}
+
 /* translational Jacobian of the origin of `frame`  (rows 3,7,11 of the 16 x n Jacobian of
  * kinematics.py:266, i.e. what TaskmapFrom4x4ToPosition selects, taskmap.py:45-54) */
-static void jacobian_pos(const rmp2_robot *rb, const kin_state *ks, int frame, real J[3][NMAX]) {
+static void jacobian_pos(const rmp2_robot *rb, const kin_state *ks, int frame, real J[3][NMAX], unsigned char lz[FMAX][FMAX]) {
   const int n = rb->n_dof;
   for (int k = 0; k < 3; ++k)
     for (int d = 0; d < n; ++d) J[k][d] = 0;
@@ -187,6 +240,7 @@ static void jacobian_pos(const rmp2_robot *rb, const kin_state *ks, int frame, r
       real r[3], col[3];
       for (int k = 0; k < 3; ++k) r[k] = ks->T[frame][4 * k + 3] - ks->T[j][4 * k + 3];
       cross3(ks->z[j], r, col);
+      if (lz && lz[frame][j]) col[0] = col[1] = col[2] = 0; /* exactly zero in the reference (lever_zero_table) */
       for (int k = 0; k < 3; ++k) J[k][d] = col[k];
     } else {
       for (int k = 0; k < 3; ++k) J[k][d] = ks->z[j][k];
@@ -456,7 +510,7 @@ static int pinv_solve(int n, const double *M, const double *f, double *x) {
 /* One robot: RmpCore.evaluate   rmp.py:133-155                                            */
 static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32, const float *goal,
                      const rmp2_obstacles *obs, const float *p_link, const float *p_obs, const float *dist,
-                     const int32_t *csr_idx, int csr_n, double *Mc, double *fc) {
+                     const int32_t *csr_idx, int csr_n, double *Mc, double *fc, unsigned char lz[FMAX][FMAX]) {
   const rmp2_robot *rb = &desc->robot;
   const int n = rb->n_dof;
   kin_state ks;
@@ -497,7 +551,7 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
     } else if (lf->taskmap == RMP2_TASKMAP_FK_POSITION) {
       /* chain [FK(frame), 4x4->pos]: x = p, xd = v, J = J_pos, c = a_bias   taskmap.py:150-160 */
       real J[3][NMAX], x[3], xd[3], c[3], g[3], xdd[3], A[NMAX][NMAX];
-      jacobian_pos(rb, &ks, lf->frame, J);
+      jacobian_pos(rb, &ks, lf->frame, J, lz);
       for (int k = 0; k < 3; ++k) {
         x[k] = ks.T[lf->frame][4 * k + 3];
         xd[k] = ks.v[lf->frame][k];
@@ -515,7 +569,7 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
       /* chain [FK(frame), 4x4->distance] over B pairs; fp32 reduce_sum over the pairs
        * (rmp.py:149-150), one rmp per frame */
       real Jp[3][NMAX];
-      jacobian_pos(rb, &ks, lf->frame, Jp);
+      jacobian_pos(rb, &ks, lf->frame, Jp, lz);
       const real *Ti = ks.T[lf->frame];
       const real pj[3] = {Ti[3], Ti[7], Ti[11]};
       const real *v = ks.v[lf->frame], *ab = ks.a[lf->frame];
@@ -620,7 +674,9 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
           if (dd < 0 || rb->joint_type[j] == RMP2_JOINT_FIXED || !is_ancestor_or_self(rb, j, lf->frame)) continue;
           if (rb->joint_type[j] == RMP2_JOINT_REVOLUTE) {
             real arm[3], col[3];
-            for (int k = 0; k < 3; ++k) arm[k] = x[k] - ks.T[j][4 * k + 3];
+            /* (a structural joint: the frame's own origin is the point of its axis -- the lever of the attached point is
+             *  then its offset R rel, as the reference's local-frame derivative has it) */
+            for (int k = 0; k < 3; ++k) arm[k] = (lz && lz[lf->frame][j]) ? r[k] : x[k] - ks.T[j][4 * k + 3];
             cross3(ks.z[j], arm, col);
             for (int k = 0; k < 3; ++k) Jp[k][dd] = col[k];
           } else {
@@ -655,6 +711,8 @@ int ORC_NAME(orc_step)(const rmp2_desc *desc, const float *q, const float *qd, c
                        uint32_t *status, int R) {
   const int n = desc->robot.n_dof;
   if (n > NMAX || desc->robot.n_frames > FMAX) return -1;
+  unsigned char lz[FMAX][FMAX];
+  if (R > 0) lever_zero_table(&desc->robot, q, lz); /* once per call: the zero pattern does not depend on q */
 #pragma omp parallel for schedule(static)
   for (int r = 0; r < R; ++r) {
     double Mc[NMAX * NMAX], fc[NMAX], x[NMAX];
@@ -670,7 +728,7 @@ int ORC_NAME(orc_step)(const rmp2_desc *desc, const float *q, const float *qd, c
       cn = obs->csr_offset[r + 1] - obs->csr_offset[r];
     }
     step_one(desc, q + (size_t)r * n, qd + (size_t)r * n, goal ? goal + (size_t)r * goal_stride : NULL, obs, pl, po,
-             pd, ci, cn, Mc, fc);
+             pd, ci, cn, Mc, fc, lz);
     const int dropped = pinv_solve(n, Mc, fc, x); /* rmp.py:153-154 */
     uint32_t st = dropped ? RMP2_STATUS_RANK_DROP : 0u;
     for (int i = 0; i < n; ++i) {
@@ -718,7 +776,9 @@ int ORC_NAME(orc_differentiate)(const rmp2_desc *desc, const float *q, const flo
     memcpy(xo, T, sizeof(real) * 12);
     xo[15] = 1;
     real Jp[3][NMAX];
-    jacobian_pos(rb, &ks, frame, Jp);
+    unsigned char lz[FMAX][FMAX];
+    lever_zero_table(rb, q + (size_t)r * n, lz);
+    jacobian_pos(rb, &ks, frame, Jp, lz);
     const real *w = ks.w[frame], *al = ks.al[frame];
     for (int col = 0; col < 3; ++col) {
       const real Rc[3] = {T[col], T[4 + col], T[8 + col]};

@@ -674,7 +674,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
         const float4* d4 = reinterpret_cast<const float4*>(DOF + s * 8);
         const float4 z4 = d4[0], o4 = d4[1];
         const float zj[3] = {z4.x, z4.y, z4.z};
-        const float dd[3] = {pt[0] - o4.x, pt[1] - o4.y, pt[2] - o4.z};
+        // (bit 16 + s: the frame's origin P3 lies on my joint's axis for every q -- rmp2_hip.hip structural_lever_zeros: it is
+        //  the axis point then, the origin's lever exactly zero as in the reference, an attached point's its offset from P3)
+        const bool on_axis = (op.anc_mask >> (16 + s)) & 1u;
+        const float dd[3] = {pt[0] - (on_axis ? P3[0] : o4.x), pt[1] - (on_axis ? P3[1] : o4.y), pt[2] - (on_axis ? P3[2] : o4.z)};
         float cr[3];
         cross3(zj, dd, cr);
 #pragma unroll

@@ -52,14 +52,16 @@ struct Lds {
 // 0 for joints that do not move the frame.  zo = this lane's column of the LDS z/o table.
 template <int N>
 __device__ __forceinline__ void fill_cols(float (&col)[N][3], const float* zo, uint32_t anc_mask, uint32_t rev_mask,
-                                          const float pt[3]) {
+                                          const float pt[3], const float origin[3]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     if ((anc_mask >> j) & 1u) {
       const float zj[3] = {zo[(j * 6 + 0) * kWave], zo[(j * 6 + 1) * kWave], zo[(j * 6 + 2) * kWave]};
       if ((rev_mask >> j) & 1u) {
-        const float d[3] = {pt[0] - zo[(j * 6 + 3) * kWave], pt[1] - zo[(j * 6 + 4) * kWave],
-                            pt[2] - zo[(j * 6 + 5) * kWave]};
+        // (bit 16 + j: the frame's origin lies on joint j's axis for every q -- structural_lever_zeros: it is the axis point)
+        const bool on_axis = (anc_mask >> (16 + j)) & 1u;
+        const float d[3] = {pt[0] - (on_axis ? origin[0] : zo[(j * 6 + 3) * kWave]), pt[1] - (on_axis ? origin[1] : zo[(j * 6 + 4) * kWave]),
+                            pt[2] - (on_axis ? origin[2] : zo[(j * 6 + 5) * kWave])};
         cross3(zj, d, col[j]);
       } else {
         col[j][0] = zj[0];
@@ -158,7 +160,7 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
 
       // Jacobian columns of this frame's origin: z_j x (p - o_j) (revolute) or z_j (prismatic)
       float col[N][3];
-      fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p);
+      fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p, cur.p);
 
       for (int li = 0; li < op.leaf_count; ++li) {
         const DevLeaf& lf = prog->leaves[prog->fk_leaves[op.leaf_begin + li]];
@@ -207,7 +209,7 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
           cross3(cur.al, r, t1);
 #pragma unroll
           for (int c = 0; c < 3; ++c) cp[c] = cur.a[c] + t1[c] + t2[c];
-          fill_cols<N>(col, zo, op.anc_mask, rev_mask, pt);
+          fill_cols<N>(col, zo, op.anc_mask, rev_mask, pt, cur.p);
           const float nv[3] = {nvp[0], nvp[1], nvp[2]};
           float xdd[3], wgt;
           leaf_collision_avoidance(lf.P, dd, nv, xdp, xdd, wgt);
@@ -304,7 +306,7 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
         }
         pull_position<N>(col, op.anc_mask, S, h, Ms, fv);
         }  // trip
-        if (EXT && point) fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p);
+        if (EXT && point) fill_cols<N>(col, zo, op.anc_mask, rev_mask, cur.p, cur.p);
       }
     }
 
@@ -966,6 +968,7 @@ rmp2_diff_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
       if ((prog->rev_mask >> j) & 1u) {
         const float d[3] = {cur.p[0] - zo[j * 6 + 3], cur.p[1] - zo[j * 6 + 4], cur.p[2] - zo[j * 6 + 5]};
         cross3(zj, d, cj);
+        if ((op.anc_mask >> (16 + j)) & 1u) cj[0] = cj[1] = cj[2] = 0.f;   // the origin lies on joint j's axis (structural_lever_zeros)
       }
       for (int row = 0; row < 3; ++row) J[(4 * row + 3) * n + j] = cj[row];
     }
@@ -1120,6 +1123,85 @@ int use_device(rmp2_handle* h) {
   return RMP2_OK;
 }
 
+// Structural zeros of the position Jacobian.  The reference differentiates the frame's position through the chain of LOCAL
+// transforms (kinematics.py:243-270): where the origin of frame f lies ON the axis of a revolute ancestor joint j for every q
+// -- joint f's own axis; consecutive joints whose <origin xyz> is 0 (Panda joints 1/2, 5/6); a tool frame straight up the last
+// joint's axis -- its column d p_f / d q_j is EXACTLY zero there.  The kernels form columns in world coordinates,
+// z_j x (p_f - o_j), where such a lever comes out as fp32 rounding noise (1e-8): harmless beside any other metric on dof j, but
+// in a set that gives dof j nothing else (the reference's Panda experiments 01-03 carry only a target policy) the noise column
+// is a "real" tiny one, sigma ~ 1e-16 sigma_max is kept by the pseudo-inverse's cutoff now and then, and q-double-dot_j =
+// (noise) / (noise^2) ~ 1e7 where the reference returns 0 (found by tools/fuzz_parity.py).  So the compiler marks these
+// (frame, dof) pairs -- bit 16 + j of DevOp::anc_mask -- and the kernels take the frame's own origin as the point of joint j's
+// axis there: the lever of the origin is then exactly 0, and an attached point's lever is its offset from the origin.
+// Decided in fp64 from the descriptor's constants at four random configurations; zero_of[f] bit j: structural.
+static void structural_lever_zeros(const rmp2_robot& rb, std::vector<uint32_t>& zero_of) {
+  const int F0 = rb.n_frames, n = rb.n_dof;
+  zero_of.assign(F0, 0u);
+  std::vector<uint32_t> cand(F0, 0u);
+  for (int f = 0; f < F0; ++f)
+    for (int j = f; j >= 0; j = rb.parent[j])
+      if (rb.joint_type[j] == RMP2_JOINT_REVOLUTE && rb.q_index[j] >= 0) cand[f] |= 1u << rb.q_index[j];
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  auto uniform = [&]() {
+    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(lcg >> 11) / 9007199254740992.0;
+  };
+  struct Pose {
+    double R[9], p[3];
+  };
+  std::vector<Pose> T(F0);
+  for (int trial = 0; trial < 4; ++trial) {
+    double q[RMP2_MAX_DOF];
+    for (int j = 0; j < n; ++j) q[j] = 6.0 * uniform() - 3.0;
+    for (int f = 0; f < F0; ++f) {
+      Pose A;  // T_parent @ T_const
+      const float* C = rb.T_const[f];
+      if (rb.parent[f] < 0) {
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c) A.R[3 * r + c] = C[4 * r + c];
+          A.p[r] = C[4 * r + 3];
+        }
+      } else {
+        const Pose& Pp = T[rb.parent[f]];
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            A.R[3 * r + c] = Pp.R[3 * r] * C[c] + Pp.R[3 * r + 1] * C[4 + c] + Pp.R[3 * r + 2] * C[8 + c];
+          A.p[r] = Pp.R[3 * r] * C[3] + Pp.R[3 * r + 1] * C[7] + Pp.R[3 * r + 2] * C[11] + Pp.p[r];
+        }
+      }
+      const double qv = (rb.joint_type[f] != RMP2_JOINT_FIXED && rb.q_index[f] >= 0) ? q[rb.q_index[f]] : 0.0;
+      const double u[3] = {rb.axis[f][0], rb.axis[f][1], rb.axis[f][2]};
+      if (rb.joint_type[f] == RMP2_JOINT_REVOLUTE) {  // Rodrigues (kinematics.py:103-121)
+        const double c = std::cos(qv), s = std::sin(qv);
+        const double K[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
+        double Rv[9];
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) Rv[3 * r + cc] = (r == cc ? c : 0.0) + (1.0 - c) * u[r] * u[cc] + s * K[3 * r + cc];
+        double Rn[9];
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) Rn[3 * r + cc] = A.R[3 * r] * Rv[cc] + A.R[3 * r + 1] * Rv[3 + cc] + A.R[3 * r + 2] * Rv[6 + cc];
+        std::memcpy(A.R, Rn, sizeof(Rn));
+      } else if (rb.joint_type[f] == RMP2_JOINT_PRISMATIC) {
+        for (int r = 0; r < 3; ++r) A.p[r] += (A.R[3 * r] * u[0] + A.R[3 * r + 1] * u[1] + A.R[3 * r + 2] * u[2]) * qv;
+      }
+      T[f] = A;
+    }
+    for (int f = 0; f < F0; ++f)
+      for (int j = f; j >= 0; j = rb.parent[j]) {
+        if (rb.joint_type[j] != RMP2_JOINT_REVOLUTE || rb.q_index[j] < 0) continue;
+        const Pose& J = T[j];
+        const double z[3] = {J.R[0] * rb.axis[j][0] + J.R[1] * rb.axis[j][1] + J.R[2] * rb.axis[j][2],
+                             J.R[3] * rb.axis[j][0] + J.R[4] * rb.axis[j][1] + J.R[5] * rb.axis[j][2],
+                             J.R[6] * rb.axis[j][0] + J.R[7] * rb.axis[j][1] + J.R[8] * rb.axis[j][2]};
+        const double l[3] = {T[f].p[0] - J.p[0], T[f].p[1] - J.p[1], T[f].p[2] - J.p[2]};
+        const double c[3] = {z[1] * l[2] - z[2] * l[1], z[2] * l[0] - z[0] * l[2], z[0] * l[1] - z[1] * l[0]};
+        const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), ln = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+        if (cn > 1e-11 * (1.0 + ln)) cand[f] &= ~(1u << rb.q_index[j]);
+      }
+  }
+  zero_of = cand;
+}
+
 // Compile the descriptor into the device program: depth-first schedule with save/restore slots
 // (same algorithm as urdf.py:depth_first_schedule).
 // prune = true (control-step kernels): frames that are not an ancestor-or-self of a frame carrying a
@@ -1202,6 +1284,8 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     dof_owner[qi] = f0;
     if (rb.joint_type[f0] == RMP2_JOINT_REVOLUTE) rev_mask |= 1u << qi;
   }
+  std::vector<uint32_t> lever_zero;
+  structural_lever_zeros(rb, lever_zero);
   for (int k = 0; k < F; ++k) {
     const int w = order[k], p = wf[w].parent, f = wf[w].orig;
     DevOp& op = P.ops[k];
@@ -1231,7 +1315,7 @@ int compile_program(const rmp2_desc& d, DevProgram& P, int& n_slots, std::string
     uint32_t mask = 0;
     for (int j = f; j >= 0; j = rb.parent[j])
       if (rb.joint_type[j] != RMP2_JOINT_FIXED && rb.q_index[j] >= 0) mask |= 1u << rb.q_index[j];
-    op.anc_mask = mask;
+    op.anc_mask = mask | ((lever_zero[f] & mask & 0xffffu) << 16);  // (bits 16 + j: structural_lever_zeros above)
     for (int c = 0; c < 3; ++c) op.axis[c] = rb.axis[f][c];
     for (int c = 0; c < 12; ++c) op.Tc[c] = (float)wf[w].Tc[c];
   }

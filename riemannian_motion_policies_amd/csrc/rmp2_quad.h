@@ -1945,7 +1945,9 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;                 // the frame (nor is its record read)
               continue;
             }
-            const bool act = (op.anc_mask >> (sub + kQuad * m)) & 1u;  // (bits >= n_dof are never set)
+            // (bits >= n_dof are never set; bit 16 + j: the frame's origin lies on joint j's axis for every q, its column is
+            //  exactly zero in the reference -- rmp2_hip.hip structural_lever_zeros -- and here too, instead of rounding noise)
+            const bool act = ((op.anc_mask & ~(op.anc_mask >> 16)) >> (sub + kQuad * m)) & 1u;
             if (!kRowRecsInRegs) {
               const float4 j0 = rjs[m][0], j2 = rjs[m][2];
               rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;

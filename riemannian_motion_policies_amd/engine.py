@@ -124,6 +124,8 @@ class Engine:
             if csr_offset is not None:
                 csr_offset = csr_offset.to(device=self.device, dtype=torch.int32).contiguous()
                 csr_index = csr_index.to(device=self.device, dtype=torch.int32).contiguous()
+                if csr_index.numel() == 0:   # every list empty: the C ABI still wants a readable pointer (it cannot see the counts)
+                    csr_index = torch.zeros(1, dtype=torch.int32, device=self.device)
                 o.mode, o.csr_offset, o.csr_index = D.OBS_RAGGED_SPHERES, csr_offset.data_ptr(), csr_index.data_ptr()
                 keep += [csr_offset, csr_index]
             else:

@@ -457,3 +457,54 @@ def test_two_kernel_step_is_capturable_after_reserve(torch_mod):
         out2.zero_()   # (something to capture: the refused call must leave the capture itself intact)
         rc = lib.rmp2_step(fresh._h, q.data_ptr(), qd.data_ptr(), goal.data_ptr(), 3, None, C.byref(o), 300, side.cuda_stream)
     assert rc == _native.ERR_UNSUPPORTED and b"rmp2_reserve" in lib.rmp2_last_error(fresh._h)
+
+
+@pytest.mark.parametrize("kernel", ["", "hex", "quad", "lane"])
+def test_structural_zero_columns_of_the_position_jacobian(torch_mod, kernel):
+    """The reference's Panda experiments 01-03 carry ONLY a target policy (experiments/franka_panda/01_target_rmp_only.py:46): a
+    rank-3 metric on nine dofs, resolved by the pseudo-inverse.  Differentiating through the chain of local transforms
+    (kinematics.py:243-270) the reference gets EXACT zeros where a frame's origin lies on a joint's axis for every q: panda_joint7
+    for the grasp target straight up its axis, panda_joint5 for the origin of panda_joint6 (<origin xyz="0 0 0">), the fingers;
+    the pseudo-inverse returns exactly 0 for such a dof.  A world-frame lever z_j x (p - o_j) is rounding noise there (1e-8), a
+    'real' tiny column for the resolve: q-double-dot_j = noise / noise^2 ~ 1e7 (found by tools/fuzz_parity.py, seed 10460).  The
+    program compiler marks these (frame, dof) pairs (rmp2_hip.hip structural_lever_zeros): row, column and force of the dof are
+    exactly zero in the exported system, q-double-dot_j is exactly 0, as in the oracle -- in every mapping."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    t = Cf.panda_table()
+    R = 300
+    s = Cf.sample_panda_states(np.random.default_rng(3), R)
+    for frame, zero_dofs in (("panda_grasptarget_hand", [6, 7, 8]), ("panda_joint6", [4, 5, 6, 7, 8]), ("panda_joint2", [1, 2, 3, 4, 5, 6, 7, 8])):
+        specs = [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index(frame), Cf.PANDA04_TARGET_POLICY_PARAMS, goal_len=3)]
+        for solve in ("auto", "pinv"):
+            desc = D.build_desc(t, specs, solve)
+            old = os.environ.get("RMP2_KERNEL")
+            if kernel:
+                os.environ["RMP2_KERNEL"] = kernel
+            try:
+                from riemannian_motion_policies_amd.engine import Engine
+                eng = Engine(desc, 0)
+            finally:
+                if old is None:
+                    os.environ.pop("RMP2_KERNEL", None)
+                else:
+                    os.environ["RMP2_KERNEL"] = old
+            M = torch.empty((R, 9, 9), dtype=torch.float64, device="cuda")
+            f = torch.empty((R, 9), dtype=torch.float64, device="cuda")
+            st = torch.zeros(R, dtype=torch.int32, device="cuda")
+            qdd = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), M=M, f=f, status=st)
+            torch.cuda.synchronize()
+            Mn, fn, got = M.cpu().numpy(), f.cpu().numpy(), qdd.cpu().numpy()
+            ref = O.step(desc, s["q"], s["qd"], s["goal"])
+            what = f"{frame} / {solve} / {kernel or 'default'} ({eng.last_kernel()})"
+            for j in zero_dofs:
+                assert (Mn[:, j, :] == 0).all() and (Mn[:, :, j] == 0).all() and (fn[:, j] == 0).all(), f"{what}: dof {j} is not exactly out of the system"
+                assert (got[:, j] == 0).all(), f"{what}: q-double-dot of dof {j} is not exactly 0 (worst {np.abs(got[:, j]).max():.3e})"
+                # ... exactly as the oracle has it (rmp2_oracle.c lever_zero_table, pinned against the autodiff restatement of
+                # the reference in tests/test_oracle_pins.py)
+                assert (ref["M"][:, j, :] == 0).all() and (ref["M"][:, :, j] == 0).all() and (ref["qdd64"][:, j] == 0).all()
+            # the rest is a rank-3 system with fp32 rounding noise as its other singular values (kept by the cutoff, in the
+            # reference too): bounded the only way it can be -- the engine's answer solves the oracle's system
+            verdict = O.accuracy_gate(got, ref, system_spread=O.system_resolution(ref))
+            assert np.isfinite(got).all() and (verdict["omega"] <= 1e-4).all(), f"{what}: backward error {verdict['omega'].max():.2e}"

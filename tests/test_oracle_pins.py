@@ -341,3 +341,55 @@ def test_link_capsule_closest_points_against_a_brute_force_scan():
                     dmin = np.sqrt(((X[:, None, :] - Y[None, :, :]) ** 2).sum(-1)).min()
                     got = np.linalg.norm(pl[r, c * K + k].astype(np.float64) - po[r, c * K + k])
                     assert abs(got - abs(dmin - lc[c, 3] - tab[k, 3])) < 2e-3, (r, c, k, got, dmin)
+
+
+def test_structural_zero_columns_follow_the_autodiff_restatement(golden_dir):
+    """Where a frame's origin lies on the axis of a revolute ancestor joint for every q, differentiating through the chain of
+    LOCAL transforms (kinematics.py:243-270) gives a column of EXACT zeros -- the autodiff restatement of the reference shows
+    it (torch_autodiff_oracle.py, same graph as TensorFlow's) -- and the pseudo-inverse of a set that gives the dof no other
+    metric (the reference's Panda experiments 01-03: a target policy only) then returns exactly 0 for it.  The C oracle takes
+    the same zero pattern (rmp2_oracle.c lever_zero_table): pinned here for every frame of both reference robots, and through the
+    resolved q-double-dot of the experiment-01 set."""
+    import json
+    import torch
+    import torch_autodiff_oracle as TA
+    gold = json.load(open(os.path.join(golden_dir, "kinematic_tables.json")))
+    for name, table_fn, sampler in (("panda", Cf.panda_table, Cf.sample_panda_states), ("two_joint", Cf.two_joint_table, Cf.sample_two_joint_states)):
+        t = table_fn()
+        fk = TA.UrdfForwardKinematicTorch(gold[name])
+        desc = D.build_desc(t, [D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, Cf.JOINT_DAMPING_PARAMS)])
+        s = sampler(np.random.default_rng(11), 2)
+        found = 0
+        for frame in t.frame_names:
+            fi = t.frame_index(frame)
+            for r in range(2):
+                _, _, Jt, _ = fk.differentiate(torch.tensor(s["q"][r:r + 1]), torch.tensor(s["qd"][r:r + 1]), frame)
+                Jt = Jt[0].numpy()[[3, 7, 11]]                                      # d position / d q   (taskmap.py:45-54)
+                _, _, Jc, _ = O.differentiate(desc, s["q"][r:r + 1], s["qd"][r:r + 1], fi)
+                Jc = Jc[0][[3, 7, 11]]
+                zero_t, zero_c = (Jt == 0).all(axis=0), (Jc == 0).all(axis=0)
+                assert (zero_t == zero_c).all(), f"{name} {frame}: autodiff zero columns {np.nonzero(zero_t)[0]}, C oracle {np.nonzero(zero_c)[0]}"
+                assert np.abs(Jt - Jc).max() < 2e-6
+                # columns of ancestors that are exactly zero: the structural ones
+                anc = {t.q_index[j] for j in _ancestors(t, fi) if t.q_index[j] >= 0}
+                found += sum(1 for d in anc if zero_c[d])
+        assert found > 0 or name == "two_joint", f"{name}: no structural zero found"
+    # experiment 01 on the Panda (experiments/franka_panda/01_target_rmp_only.py:46): joint 7, on whose axis the grasp target
+    # sits, and the fingers resolve to exactly 0
+    t = Cf.panda_table()
+    desc = D.build_desc(t, [D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, t.frame_index("panda_grasptarget_hand"),
+                                       Cf.PANDA04_TARGET_POLICY_PARAMS, goal_len=3)], "pinv")
+    s = Cf.sample_panda_states(np.random.default_rng(3), 50)
+    ref = O.step(desc, s["q"], s["qd"], s["goal"])
+    assert (ref["M"][:, 6:, :] == 0).all() and (ref["M"][:, :, 6:] == 0).all() and (ref["f"][:, 6:] == 0).all() and (ref["qdd64"][:, 6:] == 0).all()
+    fk = TA.UrdfForwardKinematicTorch(gold["panda"])
+    qdd, M, f = TA.evaluate_one(fk, TA.leaves_from_desc(desc, t.frame_names), s["q"][0], s["qd"][0], s["goal"][0])
+    assert (M[6:, :] == 0).all() and (M[:, 6:] == 0).all() and (qdd[6:] == 0).all()
+
+
+def _ancestors(t, frame):
+    out, j = [], frame
+    while j >= 0:
+        out.append(j)
+        j = int(t.parent[j])
+    return out

@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Parity fuzz campaign: random robots x random RMP sets x obstacle interfaces x kernel mappings x resolves, the HIP engine
+against the CPU oracle through oracle.accuracy_gate (every robot bounded, none exempted).
+
+Test infrastructure (it calls oracle/): run on the GPU box, e.g.
+
+    python tools/fuzz_parity.py --seeds 0 2000 --minutes 8 --log gpurun_out/r04/fuzz_parity.log
+
+One case = one seed: a robot (TwoJoint, Panda, or a random URDF tree: revolute / prismatic / fixed joints, arbitrary axes,
+branches), a random subset of the thirteen leaf kinds in random ORDER (the order fixes the fp64 summation order) with
+jittered parameters on random frames, solve = auto | pinv, one obstacle interface (shared spheres / capsules, ragged lists,
+explicit pairs with uneven counts per leaf, attached-point records), a fleet size with awkward tails, and one of the
+mappings (default dispatch, hex, quad, lane).  A case the engine declines with RMP2_ERR_UNSUPPORTED is counted, not failed;
+anything else that differs from the oracle -- a robot outside the gate, a status word that disagrees about non-finite
+results, an exception -- is a failure and is logged with its seed for replay (`--seeds S S+1 --verbose`).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLEET_SIZES = [1, 3, 16, 17, 64, 65, 257, 1000, 2049]
+
+
+def jitter(rng, params):
+    return [float(p) * float(rng.uniform(0.8, 1.25)) for p in params]
+
+
+def draw_robot(rng, tmpdir):
+    from riemannian_motion_policies_amd import configs as Cf, urdf
+    kind = rng.choice(["two_joint", "panda", "random"], p=[0.2, 0.4, 0.4])
+    if kind == "two_joint":
+        t = Cf.two_joint_table()
+        lo, hi = Cf.TWO_JOINT_Q_LOW, Cf.TWO_JOINT_Q_HIGH
+    elif kind == "panda":
+        t = Cf.panda_table()
+        lo, hi = Cf.PANDA_Q_LOW, Cf.PANDA_Q_HIGH
+    else:
+        from test_gpu_random_robots import _write_urdf
+        path = os.path.join(tmpdir, "rnd.urdf")
+        t = None
+        for _ in range(50):
+            movable = _write_urdf(path, rng, int(rng.integers(2, 13)), branch_prob=0.25)
+            order = [m for m in movable if rng.random() < 0.9][:9]
+            if not order:
+                continue
+            t = urdf.compile_urdf(path, order)
+            if t.depth_first_schedule()[3] <= 2:
+                break
+            t = None
+        if t is None:
+            return draw_robot(rng, tmpdir)
+        lo, hi = -np.ones(t.n_dof) * 1.2, np.ones(t.n_dof) * 1.2
+    return kind, t, np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+
+
+def draw_specs(rng, t, lo, hi):
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    n, F = t.n_dof, t.n_frames
+    fr = lambda: int(rng.integers(0, F))
+    specs = []
+    if rng.random() < 0.6:
+        specs.append(D.LeafSpec(D.LEAF_TARGET_ATTRACTOR, D.TASKMAP_FK_POSITION, fr(), jitter(rng, Cf.TARGET_ATTRACTOR_PARAMS), goal_len=3))
+    if rng.random() < 0.35:
+        specs.append(D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_FK_POSITION, fr(), jitter(rng, Cf.TARGET_POLICY_PARAMS), goal_len=3))
+    if rng.random() < 0.2:
+        specs.append(D.LeafSpec(D.LEAF_TARGET_POLICY, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.EXP04_TARGET_POLICY_PARAMS), goal_len=n))
+    if rng.random() < 0.4:
+        specs.append(D.LeafSpec(D.LEAF_JOINT_VELOCITY_CAP, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.JOINT_VELOCITY_CAP_PARAMS)))
+    if rng.random() < 0.6:
+        specs.append(D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.JOINT_DAMPING_PARAMS)))
+    if rng.random() < 0.4:
+        specs.append(D.LeafSpec(D.LEAF_CSPACE_BIASING, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.CSPACE_BIASING_PARAMS),
+                                vec_a=rng.uniform(lo, hi) * 0.5))
+    if rng.random() < 0.4:
+        specs.append(D.LeafSpec(D.LEAF_JOINT_LIMIT_AVOIDANCE, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.JOINT_LIMIT_PARAMS), vec_a=lo, vec_b=hi))
+    if rng.random() < 0.2:
+        specs.append(D.LeafSpec(D.LEAF_CONFIG_SPACE_BIASING, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.PANDA04_CONFIG_SPACE_BIASING_PARAMS),
+                                vec_a=rng.uniform(lo, hi) * 0.5))
+    obstacle_kind = rng.choice(["none", "distance", "point"], p=[0.25, 0.55, 0.2])
+    if obstacle_kind != "none":
+        count = int(rng.integers(1, min(F, 8) + 1))
+        frames = list(rng.choice(F, size=count, replace=False))
+        if rng.random() < 0.15 and count < 8:
+            frames.append(frames[0])          # two leaves on one frame
+        for f in frames:
+            if obstacle_kind == "distance":
+                specs.append(D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, int(f), jitter(rng, Cf.OBSTACLE_AVOIDANCE_PARAMS)))
+            else:
+                specs.append(D.LeafSpec(D.LEAF_COLLISION_AVOIDANCE, D.TASKMAP_FK_POINT, int(f), jitter(rng, Cf.COLLISION_AVOIDANCE_PARAMS)))
+    if not specs:
+        specs.append(D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.JOINT_DAMPING_PARAMS)))
+    order = rng.permutation(len(specs))
+    return [specs[i] for i in order], obstacle_kind
+
+
+def draw_obstacles(rng, O, desc, q, obstacle_kind):
+    """(kwargs for oracle.step / Engine.obstacles as numpy arrays, label)."""
+    from riemannian_motion_policies_amd import descriptor as D
+    R = q.shape[0]
+    dl = D.distance_leaf_indices(desc)
+    if obstacle_kind == "none" or not dl:
+        return {}, "none"
+    T = O.forward_kinematics(desc, q, "f64")
+    org = T[:, [desc.leaves[i].frame for i in dl]][:, :, :3, 3]          # [R, L, 3]
+    if obstacle_kind == "point":
+        counts = [int(rng.integers(1, 5)) for _ in dl] if rng.random() < 0.5 else [int(rng.integers(1, 5))] * len(dl)
+        P = sum(counts)
+        rel = rng.uniform(-0.15, 0.15, (R, P, 3))
+        nv = rng.normal(size=(R, P, 3))
+        nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
+        d = rng.uniform(0.05, 1.3, (R, P))
+        return dict(p_link=rel.astype(np.float32), p_obs=nv.astype(np.float32), dist=d.astype(np.float32), pair_counts=counts), f"point records {counts}"
+    mode = rng.choice(["spheres", "capsules", "ragged", "ragged_capsules", "pairs"], p=[0.3, 0.15, 0.2, 0.1, 0.25])
+    lo, hi = org.reshape(-1, 3).min(axis=0) - 0.4, org.reshape(-1, 3).max(axis=0) + 0.4
+    if mode == "pairs":
+        counts = [int(rng.integers(1, 40)) for _ in dl] if rng.random() < 0.6 else [int(rng.choice([1, 4, 32]))] * len(dl)
+        pl, po = [], []
+        for k, c in enumerate(counts):
+            a = org[:, k, None, :] + rng.uniform(-0.08, 0.08, (R, c, 3))
+            dirs = rng.normal(size=(R, c, 3))
+            dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+            gap = np.where(rng.random((R, c)) < 0.3, rng.uniform(0.01, 0.06, (R, c)), rng.uniform(0.06, 0.8, (R, c)))
+            pl.append(a)
+            po.append(a + dirs * gap[..., None])
+        return dict(p_link=np.concatenate(pl, axis=1).astype(np.float32), p_obs=np.concatenate(po, axis=1).astype(np.float32),
+                    pair_counts=counts), f"explicit pairs {counts}"
+    K = int(rng.choice([1, 5, 32, 100, 300]))
+    c = rng.uniform(lo, hi, (K, 3))
+    rad = rng.uniform(0.03, 0.1, (K, 1))
+    if mode in ("capsules", "ragged_capsules"):
+        b = c + rng.normal(size=(K, 3)) * 0.25
+        tab = np.concatenate([c, rad, b, np.zeros((K, 1))], axis=1).astype(np.float32)
+        if K > 1:
+            tab[0, 4:7] = tab[0, 0:3]      # a degenerate capsule
+    else:
+        tab = np.concatenate([c, rad], axis=1).astype(np.float32)
+    kw = dict(spheres=tab)
+    if mode.startswith("ragged"):
+        counts = rng.integers(0, min(K, 40) + 1, size=R)
+        off = np.zeros(R + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        idx = np.concatenate([rng.integers(0, K, size=int(k)) for k in counts] + [np.zeros(0, np.int64)]).astype(np.int32)
+        kw.update(csr_offset=off, csr_index=idx)
+    return kw, f"{mode} K={K}"
+
+
+def run_case(seed, torch, verbose=False):
+    import oracle as O
+    from riemannian_motion_policies_amd import descriptor as D, _native
+    from riemannian_motion_policies_amd.engine import Engine
+    rng = np.random.default_rng(seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        robot_kind, t, lo, hi = draw_robot(rng, tmp)
+    specs, obstacle_kind = draw_specs(rng, t, lo, hi)
+    solve = str(rng.choice(["auto", "pinv"], p=[0.6, 0.4]))
+    kernel = rng.choice(["", "hex", "quad", "lane"], p=[0.4, 0.2, 0.25, 0.15])
+    R = int(rng.choice(FLEET_SIZES))
+    n = t.n_dof
+    what = dict(seed=seed, robot=robot_kind, dof=n, frames=t.n_frames, leaves=[(s.kind, s.taskmap, s.frame) for s in specs],
+                solve=solve, kernel=kernel or "default", robots=R)
+    try:
+        desc = D.build_desc(t, specs, solve)
+    except ValueError as e:
+        return "declined", dict(what, why=f"build_desc: {e}")
+    span = hi - lo
+    q = rng.uniform(lo + 0.05 * span, hi - 0.05 * span, (R, n)).astype(np.float32)
+    qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+    if rng.random() < 0.3:
+        qd *= 5.0                                     # faster robots: the velocity cap's band
+    goal = rng.uniform(-0.8, 0.8, (R, desc.goal_floats)).astype(np.float32) if desc.goal_floats else None
+    kw, obs_label = draw_obstacles(rng, O, desc, q, obstacle_kind)
+    what["obstacles"] = obs_label
+    old = os.environ.get("RMP2_KERNEL")
+    if kernel:
+        os.environ["RMP2_KERNEL"] = str(kernel)
+    try:
+        try:
+            eng = Engine(desc, 0)
+        finally:
+            if old is None:
+                os.environ.pop("RMP2_KERNEL", None)
+            else:
+                os.environ["RMP2_KERNEL"] = old
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in kw.items() if k != "pair_counts"}
+        if "pair_counts" in kw:
+            dev["pair_counts"] = kw["pair_counts"]
+        obstacles = eng.obstacles(**dev) if kw else None
+        st = torch.zeros(R, dtype=torch.int32, device="cuda")
+        want_system = (rng.random() < 0.3) or verbose
+        M = torch.empty((R, n, n), dtype=torch.float64, device="cuda") if want_system else None
+        f = torch.empty((R, n), dtype=torch.float64, device="cuda") if want_system else None
+        extra = dict(M=M, f=f) if want_system else {}
+        out = eng.step(torch.from_numpy(q), torch.from_numpy(qd), None if goal is None else torch.from_numpy(goal),
+                       obstacles=obstacles, status=st, **extra)
+        torch.cuda.synchronize()
+        what["ran"] = eng.last_kernel()
+    except _native.Rmp2Error as e:
+        if e.code == _native.ERR_UNSUPPORTED:
+            return "declined", dict(what, why=str(e))
+        return "failed", dict(what, why=f"Rmp2Error {e.code}: {e}")
+    except ValueError as e:
+        return "declined", dict(what, why=f"host: {e}")
+    got, stc = out.cpu().numpy(), st.cpu().numpy()
+    ref = O.step(desc, q, qd, goal, **kw)
+    res = O.fp32_resolution(desc, q, qd, goal, **kw)
+    sys_res = O.system_resolution(ref)
+    verdict = O.accuracy_gate(got, ref, spread=res, system_spread=sys_res)
+    summary = O.gate_summary(verdict)
+    # Robots whose system is UNDETERMINED at fp32: a singular value of the oracle's M inside (1e-18, 1e-6] x sigma_max.  M is built
+    # from fp32 leaves (rmp.py:133-151: relative noise ~1e-7) and resolved in fp64 with TensorFlow's cutoff 10 n eps64 sigma_max
+    # (rmp.py:153-154): a direction whose singular value is fp32 noise is KEPT, and contributes (noise of f) / (noise of M) -- in the
+    # reference as here, with different noise.  Such a robot is held to what a solver can promise it: the backward error against the
+    # oracle's system (omega <= 1e-4) and a finite answer.  Counted separately; every other robot passes the full gate.
+    # (the band is looked for in the oracle's reference-precision system AND in its fp64 evaluation: a pair within an fp32 rounding
+    #  of a leaf's cutoff radius has a metric of exactly 0 in one fp32 evaluation, +-1e-12 in another and +1e-11 in exact arithmetic
+    #  -- rmp2.py:170-174: the gate x^2 / r^2 - 2 x / r + 1 has a double root at the cutoff)
+    ref64 = O.step(desc, q, qd, goal, precision="f64", **kw)
+    with np.errstate(invalid="ignore"):
+        sv = np.linalg.svd(np.where(np.isfinite(ref["M"]), ref["M"], 0.0), compute_uv=False)
+        sv64 = np.linalg.svd(np.where(np.isfinite(ref64["M"]), ref64["M"], 0.0), compute_uv=False)
+    rel = sv / np.maximum(sv[:, :1], 1e-300)
+    rel64 = sv64 / np.maximum(sv64[:, :1], 1e-300)
+    undetermined = ((rel > 1e-18) & (rel <= 1e-6)).any(axis=1) | ((rel64 > 1e-18) & (rel64 <= 1e-6)).any(axis=1)
+    # ... and a system that is rank-deficient beyond its all-zero rows (seven active rank-one leaves on eight moving dofs): the
+    # exact singular value is 0, what an fp32 evaluation leaves of it is rounding noise around the cutoff (the oracle's per-pair
+    # outer products leave 1e-20, the engine's pull-back of the summed 3 x 3 leaf metric 1e-15; the cutoff sits at 6e-16)
+    cut = 10.0 * n * np.finfo(np.float64).eps
+    zero_rows = ((ref["M"] == 0).all(axis=2) & (ref["M"] == 0).all(axis=1)).sum(axis=1)
+    undetermined |= (rel <= cut).sum(axis=1) > zero_rows
+    backward_ok = np.isfinite(got).all(axis=1) & (verdict["omega"] <= 1e-4)
+    ok = verdict["ok"] | (undetermined & backward_ok)
+    summary["undetermined_at_fp32_backward_error_only"] = int((undetermined & ~verdict["ok"] & backward_ok).sum())
+    summary["rejected"] = int((~ok).sum())
+    problems = []
+    if not ok.all():
+        bad = np.nonzero(~ok)[0]
+        what["bad_detail"] = [dict(robot=int(b), err=float(verdict["err_inf"][b]), omega=float(verdict["omega"][b]), cond=float(verdict["cond"][b]),
+                                   resolution=float(res[b]), system_resolution=float(sys_res[b]), ref_inf=float(np.abs(ref["qdd64"][b]).max()), sv_rel_min=float(rel[b].min()),
+                                   undetermined=bool(undetermined[b])) for b in bad[:8]]
+        problems.append(f"{len(bad)} robot(s) outside the gate, first {bad[:5].tolist()}: err {verdict['err_inf'][bad[:5]].tolist()}, "
+                        f"omega {verdict['omega'][bad[:5]].tolist()}, cond {verdict['cond'][bad[:5]].tolist()}, resolution {res[bad[:5]].tolist()}")
+    nonfinite_ref = ~np.isfinite(ref["qdd64"]).all(axis=1)
+    nonfinite_got = ~np.isfinite(got).all(axis=1)
+    flagged = (stc & D.STATUS_NONFINITE) != 0 if hasattr(D, "STATUS_NONFINITE") else (stc & 1) != 0
+    if (nonfinite_got & ~flagged).any():
+        problems.append(f"{int((nonfinite_got & ~flagged).sum())} non-finite result(s) not flagged in the status word")
+    if (flagged & ~nonfinite_got).any():
+        problems.append(f"{int((flagged & ~nonfinite_got).sum())} robot(s) flagged non-finite with a finite result")
+    if want_system:
+        Mg, fg = M.cpu().numpy(), f.cpu().numpy()
+        okr = np.isfinite(ref["M"]).all(axis=(1, 2)) & np.isfinite(Mg).all(axis=(1, 2)) & ~nonfinite_ref
+        if okr.any():
+            sM = np.abs(ref["M"][okr]).max(axis=(1, 2))
+            eM = np.abs(Mg[okr] - ref["M"][okr]).max(axis=(1, 2)) / np.maximum(sM, 1e-30)
+            what["system_M_rel_err_max"] = float(eM.max())
+        if verbose and not ok.all():
+            # split the disagreement: the engine's accumulated system against the oracle's, and the engine's resolve against
+            # numpy's pseudo-inverse (TensorFlow's cutoff) of the ENGINE's own system
+            for b in np.nonzero(~ok)[0][:8]:
+                Mb, fb = Mg[b], fg[b]
+                svb = np.linalg.svd(Mb, compute_uv=False)
+                own = np.linalg.pinv(Mb, rcond=10.0 * n * np.finfo(np.float64).eps) @ fb
+                print(json.dumps(dict(robot=int(b), status=int(stc[b]), M_rel=float(np.abs(Mb - ref["M"][b]).max() / max(np.abs(ref["M"][b]).max(), 1e-300)),
+                                      f_rel=float(np.abs(fb - ref["f"][b]).max() / max(np.abs(ref["f"][b]).max(), 1e-300)),
+                                      sv_engine=(svb / svb[0]).tolist(), sv_oracle=rel[b].tolist(),
+                                      got=got[b].tolist(), ref=ref["qdd64"][b].tolist(), pinv_of_engine_system=own.tolist(),
+                                      M_engine_diag=np.diag(Mb).tolist(), M_oracle_diag=np.diag(ref["M"][b]).tolist(),
+                                      f_engine=fb.tolist(), f_oracle=ref["f"][b].tolist(), q=q[b].tolist())), flush=True)
+    what["gate"] = summary
+    if problems:
+        return "failed", dict(what, why="; ".join(problems))
+    return "passed", what
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, nargs=2, default=[0, 200])
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--log", default="")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    import torch
+    assert torch.cuda.is_available(), "the fuzz campaign needs a HIP device"
+    t0 = time.time()
+    counts = {"passed": 0, "declined": 0, "failed": 0}
+    by_kernel, by_obstacles, declined_why, failures = {}, {}, {}, []
+    robots = 0
+    log = open(args.log, "w") if args.log else None
+    last_note = t0
+    done = 0
+    for seed in range(args.seeds[0], args.seeds[1]):
+        if time.time() - t0 > args.minutes * 60:
+            break
+        try:
+            outcome, what = run_case(seed, torch, args.verbose)
+        except Exception as e:   # noqa: BLE001 -- a crash of the harness or the oracle on a case is a finding too
+            import traceback
+            outcome, what = "failed", dict(seed=seed, why=f"{type(e).__name__}: {e}", trace=traceback.format_exc(limit=4))
+        done += 1
+        counts[outcome] += 1
+        if outcome == "passed":
+            robots += what["robots"]
+            k = what.get("ran", "?").split("<")[0].split(" (")[0][:48]
+            by_kernel[k] = by_kernel.get(k, 0) + 1
+            o = what["obstacles"].split(" ")[0]
+            by_obstacles[o] = by_obstacles.get(o, 0) + 1
+        elif outcome == "declined":
+            w = what["why"][:90]
+            declined_why[w] = declined_why.get(w, 0) + 1
+        else:
+            failures.append(what)
+        line = json.dumps(dict(outcome=outcome, **what), default=str)
+        if log:
+            log.write(line + "\n")
+            log.flush()
+        if args.verbose or outcome == "failed":
+            print(line, flush=True)
+        if time.time() - last_note > 45:
+            print(f"[{time.time() - t0:5.0f} s] {done} cases: {counts}", flush=True)
+            last_note = time.time()
+    summary = dict(cases=done, seeds=[args.seeds[0], args.seeds[0] + done], seconds=round(time.time() - t0, 1), robots_checked=robots, **counts,
+                   passed_by_kernel=by_kernel, passed_by_obstacle_interface=by_obstacles, declined_reasons=declined_why,
+                   failed_seeds=[f.get("seed") for f in failures])
+    print(json.dumps(summary, indent=1))
+    if log:
+        log.write(json.dumps(dict(summary=summary)) + "\n")
+        log.close()
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
