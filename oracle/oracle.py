@@ -242,10 +242,11 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, 
     EVERY robot gets a bound -- none is exempted for being ill-conditioned or near contact:
 
       A  (north star)   |got - ref|_inf <= atol * max(1, |ref|_inf)
-      B  (backward)     omega = |M_ref got - f_ref|_2 / (|M_ref|_2 |got|_2 + |f_ref|_2) <= eta   and
+      B  (backward)     omega = |P (M_ref got - f_ref)|_2 / (|M_ref|_2 |got|_2 + |f_ref|_2) <= eta  (P: projector on the range the
+                        oracle's resolve kept -- the identity for a full-rank system)   and
                         |got - ref|_2 <= 4 eta cond_2(M_ref) |ref|_2            (what omega <= eta implies, with slack 2)
-                        and |got|_2 <= (1 + 1e-3) |ref|_2 when the oracle resolved by a rank-dropping pseudo-inverse
-                        (a consistent singular system: the residual is blind to null-space components, the minimum norm is not)
+                        and |N^T got|_2 <= 1e-3 |ref|_2 when the oracle resolved by a rank-dropping pseudo-inverse (N: the
+                        null directions it dropped -- the residual is blind to components there, the minimum norm is not)
       C  (fp32 resolution, only when `spread` = fp32_resolution(...) of the same robots is given)
                         |got - ref|_inf <= spread_factor * spread : within a few times what one fp32 rounding does to the
                         exact result / what the reference-precision oracle itself misses the fp64 result by
@@ -268,20 +269,27 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, 
     Mz = np.where(finite[:, None, None], M, 0.0)
     fz = np.where(finite[:, None], f, 0.0)
     qz = np.where(finite[:, None], q_ref, 0.0)
-    sv = np.linalg.svd(Mz, compute_uv=False)
-    res = np.linalg.norm(np.einsum("rij,rj->ri", Mz, g) - fz, axis=1)
-    scale = sv[:, 0] * np.linalg.norm(g, axis=1) + np.linalg.norm(fz, axis=1)
-    omega = np.where(scale > 0, res / np.where(scale > 0, scale, 1.0), 0.0)
+    U, sv, Vh = np.linalg.svd(Mz)
     # rank the oracle's own resolve kept (TF's cutoff, rmp.py:153-154: 10 n eps_f64 sigma_max)
     n = M.shape[1]
     cutoff = 10.0 * n * np.finfo(np.float64).eps * sv[:, 0]
     kept = (sv > cutoff[:, None]).sum(axis=1)
+    # the residual, measured on the RANGE the oracle's resolve kept: a rank-deficient system is in general inconsistent (f has a
+    # component outside range(M): the least-squares residual, which the oracle's own answer leaves too), and only the part of
+    # M got - f inside the range says anything about got.  For a full-rank system this is the plain residual.
+    r_vec = np.einsum("rij,rj->ri", Mz, g) - fz
+    r_rng = np.einsum("rji,rj->ri", U, r_vec) * (np.arange(n)[None, :] < kept[:, None])
+    res = np.linalg.norm(r_rng, axis=1)
+    scale = sv[:, 0] * np.linalg.norm(g, axis=1) + np.linalg.norm(fz, axis=1)
+    omega = np.where(scale > 0, res / np.where(scale > 0, scale, 1.0), 0.0)
     smin = np.take_along_axis(sv, np.maximum(kept - 1, 0)[:, None], axis=1)[:, 0]
     cond = np.where(smin > 0, sv[:, 0] / np.where(smin > 0, smin, 1.0), np.inf)
     err2 = np.linalg.norm(g - qz, axis=1)
     ref2 = np.linalg.norm(qz, axis=1)
     fwd = err2 <= 4.0 * eta * cond * np.maximum(ref2, 1e-30)
-    minnorm = (kept == n) | (np.linalg.norm(g, axis=1) <= (1.0 + 1e-3) * ref2 + 1e-12)
+    # minimum norm: the part of got inside the null space the oracle's resolve dropped (its own answer has none there)
+    null_part = np.linalg.norm(np.einsum("rij,rj->ri", Vh, g) * (np.arange(n)[None, :] >= kept[:, None]), axis=1)
+    minnorm = (kept == n) | (null_part <= 1e-3 * ref2 + 1e-12)
     b = finite & (omega <= eta) & fwd & minnorm
     c = np.zeros(len(got), bool)
     if spread is not None:
