@@ -459,9 +459,19 @@ static void pullback(int k, int n, real J[][NMAX], real A[NMAX][NMAX], const rea
  * sum_i W_i^T (G f)_i / |W_i|^2 over the rows with |W_i| > cutoff.                       */
 static int pinv_solve(int n, const double *M, const double *f, double *x) {
   double W[NMAX][NMAX + 1];
+  int finite = 1;
   for (int i = 0; i < n; ++i) {
-    for (int j = 0; j < n; ++j) W[i][j] = M[i * n + j];
+    for (int j = 0; j < n; ++j) {
+      W[i][j] = M[i * n + j];
+      finite &= isfinite(W[i][j]) != 0;
+    }
     W[i][n] = f[i];
+  }
+  if (!finite) { /* tf.linalg.pinv of a matrix holding NaN / Inf: its SVD is NaN, and so is every entry of the result  [TF-doc]
+                  * (found by tools/fuzz_parity.py: the comparisons below are all false for NaN, which read as "every singular
+                  * value dropped" and answered 0) */
+    for (int j = 0; j < n; ++j) x[j] = NAN;
+    return 0;
   }
   for (int sweep = 0; sweep < 60; ++sweep) {
     int rotated = 0;

@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLEET_SIZES = [1, 3, 16, 17, 64, 65, 257, 1000, 2049]
+BIG_FLEET_SIZES = [8192, 8193, 20481, 32769]      # around the cuts between the mappings and the register-cap builds (5 % of the cases)
 
 
 def jitter(rng, params):
@@ -49,8 +50,8 @@ def draw_robot(rng, tmpdir):
         path = os.path.join(tmpdir, "rnd.urdf")
         t = None
         for _ in range(50):
-            movable = _write_urdf(path, rng, int(rng.integers(2, 13)), branch_prob=0.25)
-            order = [m for m in movable if rng.random() < 0.9][:9]
+            movable = _write_urdf(path, rng, int(rng.integers(2, 20 if rng.random() < 0.2 else 13)), branch_prob=0.25)
+            order = [m for m in movable if rng.random() < 0.9][:(16 if rng.random() < 0.15 else 9)]   # (10 .. 16 dofs: hex mapping only)
             if not order:
                 continue
             t = urdf.compile_urdf(path, order)
@@ -164,7 +165,7 @@ def run_case(seed, torch, verbose=False):
     specs, obstacle_kind = draw_specs(rng, t, lo, hi)
     solve = str(rng.choice(["auto", "pinv"], p=[0.6, 0.4]))
     kernel = rng.choice(["", "hex", "quad", "lane"], p=[0.4, 0.2, 0.25, 0.15])
-    R = int(rng.choice(FLEET_SIZES))
+    R = int(rng.choice(BIG_FLEET_SIZES if rng.random() < 0.05 else FLEET_SIZES))
     n = t.n_dof
     what = dict(seed=seed, robot=robot_kind, dof=n, frames=t.n_frames, leaves=[(s.kind, s.taskmap, s.frame) for s in specs],
                 solve=solve, kernel=kernel or "default", robots=R)
@@ -179,6 +180,14 @@ def run_case(seed, torch, verbose=False):
         qd *= 5.0                                     # faster robots: the velocity cap's band
     goal = rng.uniform(-0.8, 0.8, (R, desc.goal_floats)).astype(np.float32) if desc.goal_floats else None
     kw, obs_label = draw_obstacles(rng, O, desc, q, obstacle_kind)
+    dead = np.zeros(R, bool)
+    if R >= 16 and rng.random() < 0.15:               # a few robots fed a non-finite state: NaN out + status bit, neighbours untouched
+        dead[rng.choice(R, size=3, replace=False)] = True
+        bad_rows = np.nonzero(dead)[0]
+        q[bad_rows[0], rng.integers(0, n)] = np.nan
+        qd[bad_rows[1], rng.integers(0, n)] = np.inf
+        q[bad_rows[2], :] = np.nan
+        obs_label += " +3 non-finite robots"
     what["obstacles"] = obs_label
     old = os.environ.get("RMP2_KERNEL")
     if kernel:
@@ -211,6 +220,35 @@ def run_case(seed, torch, verbose=False):
     except ValueError as e:
         return "declined", dict(what, why=f"host: {e}")
     got, stc = out.cpu().numpy(), st.cpu().numpy()
+    rollout_problem, rollout_first = None, None
+    if ("p_link" not in kw) and rng.random() < 0.25:
+        # the fused rollout (rmp2_rollout): K control steps in one launch must equal K launches of one control step each BIT FOR BIT
+        # (same kernel, same arithmetic; the state, the per-step resets and the loop carry nothing else), and its first q-double-dot
+        # the plain step's (another build of the same template: to the last places)
+        try:
+            K, sub, dt = int(rng.integers(2, 5)), int(rng.integers(1, 4)), 0.004
+            tq, tqd = torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()
+            tg = None if goal is None else torch.from_numpy(goal).cuda()
+            qa, qda = tq.clone(), tqd.clone()
+            la = eng.rollout(qa, qda, tg, obstacles=obstacles, n_control_steps=K, substeps=sub, dt=dt).clone()
+            qb, qdb = tq.clone(), tqd.clone()
+            first = None
+            for k in range(K):
+                lb = eng.rollout(qb, qdb, tg, obstacles=obstacles, n_control_steps=1, substeps=sub, dt=dt)
+                if k == 0:
+                    first = lb.clone()
+            torch.cuda.synchronize()
+            what["rollout"] = f"K={K} sub={sub} ({eng.last_kernel()[:40]})"
+            same = lambda a, b: bool(torch.equal(torch.nan_to_num(a, nan=12345.0, posinf=2e30, neginf=-2e30), torch.nan_to_num(b, nan=12345.0, posinf=2e30, neginf=-2e30)))
+            if not (same(qa, qb) and same(qda, qdb) and same(la, lb)):
+                rollout_problem = f"rollout of {K} control steps != {K} rollouts of one (max |dq| {float(torch.nan_to_num(qa - qb).abs().max()):.3e})"
+            else:
+                rollout_first = first.cpu().numpy().astype(np.float64)
+        except _native.Rmp2Error as e:
+            if e.code != _native.ERR_UNSUPPORTED:
+                rollout_problem = f"rollout: Rmp2Error {e.code}: {e}"
+            else:
+                what["rollout"] = "declined"
     ref = O.step(desc, q, qd, goal, **kw)
     res = O.fp32_resolution(desc, q, qd, goal, **kw)
     sys_res = O.system_resolution(ref)
@@ -239,9 +277,24 @@ def run_case(seed, torch, verbose=False):
     undetermined |= (rel <= cut).sum(axis=1) > zero_rows
     backward_ok = np.isfinite(got).all(axis=1) & (verdict["omega"] <= 1e-4)
     ok = verdict["ok"] | (undetermined & backward_ok)
+    # a robot fed a non-finite state may answer NaN + status bit although the reference's graph never reaches the value
+    # (include/rmp2.h, RMP2_STATUS_NONFINITE): allowed for the robots this harness poisoned, counted
+    nan_flagged = ~np.isfinite(got).all(axis=1) & ((stc & D.STATUS_NONFINITE) != 0)
+    summary["poisoned_input_answered_nan_where_the_oracle_stays_finite"] = int((dead & nan_flagged & ~verdict["ok"]).sum())
+    ok |= dead & nan_flagged
     summary["undetermined_at_fp32_backward_error_only"] = int((undetermined & ~verdict["ok"] & backward_ok).sum())
     summary["rejected"] = int((~ok).sum())
     problems = []
+    if rollout_first is not None:
+        # the first q-double-dot of the rollout (often ANOTHER mapping than the plain step's: rollouts of strict / singular sets run
+        # on the hex mapping at any fleet size) goes through the same gate against the oracle, every robot
+        vr = O.accuracy_gate(rollout_first, ref, spread=res, system_spread=sys_res)
+        ok_r = vr["ok"] | (undetermined & np.isfinite(rollout_first).all(axis=1) & (vr["omega"] <= 1e-4)) | (dead & ~np.isfinite(rollout_first).all(axis=1))
+        what["rollout_gate"] = {k: int(vr[k].sum()) for k in ("a", "b", "c", "d")}
+        if not ok_r.all():
+            badr = np.nonzero(~ok_r)[0]
+            problems.append(f"rollout's first control step: {len(badr)} robot(s) outside the gate, first {badr[:5].tolist()}: err {vr['err_inf'][badr[:5]].tolist()}, "
+                            f"omega {vr['omega'][badr[:5]].tolist()}, cond {vr['cond'][badr[:5]].tolist()}")
     if not ok.all():
         bad = np.nonzero(~ok)[0]
         what["bad_detail"] = [dict(robot=int(b), err=float(verdict["err_inf"][b]), omega=float(verdict["omega"][b]), cond=float(verdict["cond"][b]),
@@ -252,6 +305,10 @@ def run_case(seed, torch, verbose=False):
     nonfinite_ref = ~np.isfinite(ref["qdd64"]).all(axis=1)
     nonfinite_got = ~np.isfinite(got).all(axis=1)
     flagged = (stc & D.STATUS_NONFINITE) != 0 if hasattr(D, "STATUS_NONFINITE") else (stc & 1) != 0
+    if rollout_problem:
+        problems.append(rollout_problem)
+    if (nonfinite_ref & ~nonfinite_got).any():       # (the gate's both_nan branch covers the converse)
+        problems.append(f"{int((nonfinite_ref & ~nonfinite_got).sum())} robot(s) the oracle resolves to NaN came back finite")
     if (nonfinite_got & ~flagged).any():
         problems.append(f"{int((nonfinite_got & ~flagged).sum())} non-finite result(s) not flagged in the status word")
     if (flagged & ~nonfinite_got).any():
