@@ -121,8 +121,46 @@ def draw_obstacles(rng, O, desc, q, obstacle_kind):
         nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
         d = rng.uniform(0.05, 1.3, (R, P))
         return dict(p_link=rel.astype(np.float32), p_obs=nv.astype(np.float32), dist=d.astype(np.float32), pair_counts=counts), f"point records {counts}"
-    mode = rng.choice(["spheres", "capsules", "ragged", "ragged_capsules", "pairs"], p=[0.3, 0.15, 0.2, 0.1, 0.25])
+    mode = rng.choice(["spheres", "capsules", "ragged", "ragged_capsules", "pairs", "link"], p=[0.27, 0.13, 0.18, 0.09, 0.2, 0.13])
     lo, hi = org.reshape(-1, 3).min(axis=0) - 0.4, org.reshape(-1, 3).max(axis=0) + 0.4
+    if mode == "link":
+        # link geometry: a capsule per distance leaf in its frame's coordinates; the engine forms the closest points of link capsule
+        # and table primitive inside the step (fp32), the oracle reads them as explicit pairs formed here in fp64 (closed form of
+        # configs.pairs_from_link_capsules on the oracle's fp64 forward kinematics; taskmap.py:124-129: the Jacobian stays the
+        # frame origin's)
+        from riemannian_motion_policies_amd import configs as Cf
+        L = len(dl)
+        K = int(rng.choice([1, 5, 32, 100]))
+        la = rng.uniform(-0.05, 0.05, (L, 3))
+        lb = la + rng.uniform(-0.15, 0.15, (L, 3))
+        lc = np.concatenate([la, rng.uniform(0.02, 0.05, (L, 1)), lb, np.zeros((L, 1))], axis=1).astype(np.float32)
+        c = rng.uniform(lo, hi, (K, 3))
+        rad = rng.uniform(0.03, 0.1, (K, 1))
+        if rng.random() < 0.5:
+            tab = np.concatenate([c, rad, c + rng.normal(size=(K, 3)) * 0.25, np.zeros((K, 1))], axis=1).astype(np.float32)
+        else:
+            tab = np.concatenate([c, rad], axis=1).astype(np.float32)
+        frames = [desc.leaves[i].frame for i in dl]
+        pl, po = Cf.pairs_from_link_capsules(T[:, frames], lc, tab)
+        eng_kw = dict(spheres=tab, link_capsules=lc)
+        label = f"link geometry K={K} ({'capsules' if tab.shape[1] == 8 else 'spheres'})"
+        if rng.random() < 0.4:        # ragged lists over the table (no duplicates: a list entry is a pair)
+            counts = rng.integers(0, K + 1, size=R)
+            off = np.zeros(R + 1, np.int32)
+            off[1:] = np.cumsum(counts)
+            idx = np.concatenate([rng.permutation(K)[: int(k)] for k in counts] + [np.zeros(0, np.int64)]).astype(np.int32)
+            kmax = max(int(counts.max()), 1)
+            pl2 = np.zeros((R, L * kmax, 3), np.float32)
+            po2 = np.full((R, L * kmax, 3), 1.0e3, np.float32)
+            for r in range(R):
+                lst = idx[off[r]:off[r + 1]]
+                for l in range(L):
+                    pl2[r, l * kmax:l * kmax + len(lst)] = pl[r, l * K + lst]
+                    po2[r, l * kmax:l * kmax + len(lst)] = po[r, l * K + lst]
+            pl, po = pl2, po2
+            eng_kw.update(csr_offset=off, csr_index=idx)
+            label += " ragged"
+        return dict(p_link=pl, p_obs=po, _engine=eng_kw), label
     if mode == "pairs":
         counts = [int(rng.integers(1, 40)) for _ in dl] if rng.random() < 0.6 else [int(rng.choice([1, 4, 32]))] * len(dl)
         pl, po = [], []
@@ -180,6 +218,7 @@ def run_case(seed, torch, verbose=False):
         qd *= 5.0                                     # faster robots: the velocity cap's band
     goal = rng.uniform(-0.8, 0.8, (R, desc.goal_floats)).astype(np.float32) if desc.goal_floats else None
     kw, obs_label = draw_obstacles(rng, O, desc, q, obstacle_kind)
+    eng_kw = kw.pop("_engine", None) or kw       # (link geometry: the engine gets table + link capsules, the oracle the pairs)
     dead = np.zeros(R, bool)
     if R >= 16 and rng.random() < 0.15:               # a few robots fed a non-finite state: NaN out + status bit, neighbours untouched
         dead[rng.choice(R, size=3, replace=False)] = True
@@ -200,10 +239,10 @@ def run_case(seed, torch, verbose=False):
                 os.environ.pop("RMP2_KERNEL", None)
             else:
                 os.environ["RMP2_KERNEL"] = old
-        dev = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in kw.items() if k != "pair_counts"}
-        if "pair_counts" in kw:
-            dev["pair_counts"] = kw["pair_counts"]
-        obstacles = eng.obstacles(**dev) if kw else None
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in eng_kw.items() if k != "pair_counts"}
+        if "pair_counts" in eng_kw:
+            dev["pair_counts"] = eng_kw["pair_counts"]
+        obstacles = eng.obstacles(**dev) if eng_kw else None
         st = torch.zeros(R, dtype=torch.int32, device="cuda")
         want_system = (rng.random() < 0.3) or verbose
         M = torch.empty((R, n, n), dtype=torch.float64, device="cuda") if want_system else None
@@ -221,7 +260,7 @@ def run_case(seed, torch, verbose=False):
         return "declined", dict(what, why=f"host: {e}")
     got, stc = out.cpu().numpy(), st.cpu().numpy()
     rollout_problem, rollout_first = None, None
-    if ("p_link" not in kw) and rng.random() < 0.25:
+    if ("p_link" not in eng_kw) and rng.random() < 0.25:
         # the fused rollout (rmp2_rollout): K control steps in one launch must equal K launches of one control step each BIT FOR BIT
         # (same kernel, same arithmetic; the state, the per-step resets and the loop carry nothing else), and its first q-double-dot
         # the plain step's (another build of the same template: to the last places)
