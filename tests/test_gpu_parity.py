@@ -508,3 +508,33 @@ def test_structural_zero_columns_of_the_position_jacobian(torch_mod, kernel):
             # reference too): bounded the only way it can be -- the engine's answer solves the oracle's system
             verdict = O.accuracy_gate(got, ref, system_spread=O.system_resolution(ref))
             assert np.isfinite(got).all() and (verdict["omega"] <= 1e-4).all(), f"{what}: backward error {verdict['omega'].max():.2e}"
+
+
+@pytest.mark.parametrize("kernel", ["", "hex", "quad", "lane"])
+def test_all_empty_ragged_lists(torch_mod, kernel):
+    """A fleet whose robots ALL list zero obstacles (config 5 with k_r = 0 everywhere): an empty index array is a legitimate input
+    (round 4: Engine.obstacles handed the C ABI a null pointer for it and the step was refused -- tools/fuzz_parity.py); the
+    result is the set without its distance leaves' contribution, as the oracle has it."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    _, desc = Cf.config3()
+    R = 70
+    s = Cf.sample_panda_states(np.random.default_rng(5), R)
+    sph = Cf.sample_spheres(np.random.default_rng(7))
+    off, idx = np.zeros(R + 1, np.int32), np.zeros(0, np.int32)
+    old = os.environ.get("RMP2_KERNEL")
+    if kernel:
+        os.environ["RMP2_KERNEL"] = kernel
+    try:
+        from riemannian_motion_policies_amd.engine import Engine
+        eng = Engine(desc, 0)
+    finally:
+        if old is None:
+            os.environ.pop("RMP2_KERNEL", None)
+        else:
+            os.environ["RMP2_KERNEL"] = old
+    obs = eng.obstacles(spheres=torch.from_numpy(sph), csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx))
+    got = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=obs).cpu().numpy()
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], spheres=sph, csr_offset=off, csr_index=idx)["qdd64"]
+    _check(got, ref, f"all lists empty ({kernel or 'default'})")

@@ -393,3 +393,19 @@ def _ancestors(t, frame):
         out.append(j)
         j = int(t.parent[j])
     return out
+
+
+def test_pinv_of_a_non_finite_system_is_nan():
+    """tf.linalg.pinv of a matrix holding NaN / Inf is NaN in every entry (its SVD is) [TF-doc]: a robot with a NaN joint position
+    resolves to NaN on every joint (rmp.py:153-154).  Round 4 (tools/fuzz_parity.py): the C oracle's Jacobi sweeps compared with
+    NaN -- every comparison false, read as "every singular value dropped" -- and answered 0."""
+    _, desc = Cf.config2()
+    s = Cf.sample_panda_states(np.random.default_rng(0), 4)
+    s["q"][1, 2] = np.nan
+    s["qd"][2, 3] = np.inf
+    s["q"][3, :] = np.nan
+    r = O.step(desc, s["q"], s["qd"], s["goal"])
+    assert np.isfinite(r["qdd64"][0]).all() and r["status"][0] == 0
+    assert np.isnan(r["qdd64"][1:]).all() and (r["status"][1:] & D.STATUS_NONFINITE).all()
+    x, _ = O.pinv_solve(np.array([[1.0, np.nan], [0.0, 1.0]]), np.array([1.0, 1.0]))
+    assert np.isnan(x).all()
