@@ -190,12 +190,13 @@ typedef struct rmp2_obstacles {
 } rmp2_obstacles;
 
 /* ---- outputs ----------------------------------------------------------------------- */
-#define RMP2_STATUS_NONFINITE 1u /* qdd contains NaN/Inf (e.g. JointVelocityCap pole, quirk Q4).  A robot fed a NaN / Inf in q, qd or
-                                  * its goal resolves to NaN on EVERY joint with this bit whenever the reference's result is non-finite
-                                  * (tf.linalg.pinv of a non-finite system); where the reference stays finite because the value cannot
-                                  * reach any leaf (a joint that moves no leaf frame, in a set without identity-map leaves), the engine
-                                  * returns either that finite result or NaN with this bit (its ancestor sums weight non-members by 0,
-                                  * and 0 * Inf is NaN) -- never a finite value that differs */
+#define RMP2_STATUS_NONFINITE 1u /* qdd contains NaN/Inf (e.g. JointVelocityCap pole, quirk Q4).  A robot fed a NaN / Inf in q or qd
+                                  * resolves to NaN on EVERY joint with this bit: the non-finite dof's force is made non-finite by
+                                  * construction, so that neither the culling (an out-of-range pair -- metric 0, acceleration NaN in
+                                  * the reference: 0 * NaN -- is never evaluated here) nor a set that never reads the joint can return
+                                  * a finite answer for it.  This is the reference's result wherever its own arithmetic carries the
+                                  * value into the system (tf.linalg.pinv of a non-finite system is NaN), and stricter where it does
+                                  * not (a joint that moves no leaf frame in a set without identity-map leaves). */
 #define RMP2_STATUS_RANK_DROP 2u /* the pseudo-inverse dropped at least one singular value  */
 #define RMP2_STATUS_PINV_PATH 4u /* AUTO mode: this robot was resolved on the PINV path      */
 #define RMP2_STATUS_JACOBI 8u    /* PINV mode, certifying step (symmetric sets with an inertia leaf): the elimination could not

@@ -466,6 +466,7 @@ static int pinv_solve(int n, const double *M, const double *f, double *x) {
       finite &= isfinite(W[i][j]) != 0;
     }
     W[i][n] = f[i];
+    finite &= isfinite(f[i]) != 0; /* pinv(M) @ f with a NaN / Inf in f: every sum holds 0 * NaN or x * Inf -- non-finite throughout */
   }
   if (!finite) { /* tf.linalg.pinv of a matrix holding NaN / Inf: its SVD is NaN, and so is every entry of the result  [TF-doc]
                   * (found by tools/fuzz_parity.py: the comparisons below are all false for NaN, which read as "every singular

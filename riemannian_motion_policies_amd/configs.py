@@ -281,18 +281,21 @@ def sample_ragged(rng: np.random.Generator, R: int, K: int = N_SPHERES):
     return offset, index
 
 
-def pairs_from_link_capsules(T: np.ndarray, link_capsules: np.ndarray, table: np.ndarray):
+def pairs_from_link_capsules(T: np.ndarray, link_capsules: np.ndarray, table: np.ndarray, dtype=np.float64):
     """Closest points of LINK capsules and obstacle primitives in fp64 numpy (independent of the engine): T [R, C, 4, 4]
     world transforms of the distance leaves' frames, link_capsules [C, 8] in frame coordinates, table [K, 4] spheres or
     [K, 8] capsules -> p_link, p_obs [R, C*K, 3].  Segment-segment closest points by the clamped normal equations."""
-    T = T.astype(np.float64)
+    # (dtype = np.float32: the same closed form in fp32 arithmetic -- what ANY fp32 evaluation of it can resolve; tools/fuzz_parity.py
+    #  takes the difference of the oracle's results on the two pair sets as the resolution of a link-geometry case: nearly parallel
+    #  segments make the normal equations ill-conditioned)
+    T = T.astype(dtype)
     R, Cn = T.shape[:2]
     K = table.shape[0]
-    lc = link_capsules.astype(np.float64)
+    lc = link_capsules.astype(dtype)
     A = T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 0:3])
     B = T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 4:7])
     rl = lc[:, 3]
-    tb = table.astype(np.float64)
+    tb = table.astype(dtype)
     Cc = tb[:, 0:3]
     Dd = tb[:, 4:7] if tb.shape[1] == 8 else tb[:, 0:3]
     ro = tb[:, 3]

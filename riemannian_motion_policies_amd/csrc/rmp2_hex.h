@@ -966,6 +966,11 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   }
   RMP2_LSTAMP();  // 4: identity leaves done
 
+  // a dof whose state is not finite (after the quarantine: its velocity) makes the robot's system non-finite by construction:
+  // every resolve then answers NaN with RMP2_STATUS_NONFINITE, also where no leaf would have carried the value into the system
+  // (rmp2_quad.h, same place; tools/fuzz_parity.py seed 504944)
+  if (s < N) fv = (fabsf(my_qd[s]) < 3.0e38f) ? fv : (double)__builtin_nanf("");
+
   // optional outputs: the combined metric / force before the resolve
   if (live && s < n_dof) {
     if (out.M) {

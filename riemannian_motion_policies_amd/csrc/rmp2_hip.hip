@@ -460,6 +460,12 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
       }
     }
 
+    // a dof whose state is not finite makes the robot's system non-finite by construction (rmp2_quad.h, same place): the
+    // resolve answers NaN with RMP2_STATUS_NONFINITE also where no leaf carried the value into the system (an Inf velocity
+    // behind out-of-range pairs only)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      fv[i] = (fabsf(ql[i]) < 3.0e38f && fabsf(qdl[i]) < 3.0e38f) ? fv[i] : (double)__builtin_nanf("");
 #undef ql
 #undef qdl
     // optional debug outputs: the combined metric / force before the resolve

@@ -2080,6 +2080,21 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     if (!(ident_first && pass == 0)) identity_leaves();
 
     RMP2_STAMP();  // 4: identity leaves done
+    // A robot whose state is not finite resolves to NaN (status NONFINITE) whatever its leaves see of it.  The reference gets
+    // there by arithmetic -- NaN FK, or 0 * NaN of an out-of-range pair's (metric 0, acceleration NaN), rmp.py:165-167 -- which
+    // the quarantine (rmp2_device.h: a non-finite position becomes q = 0 with a NaN velocity) and the culling (an out-of-range
+    // pair is never evaluated) can both cut short: a set of distance leaves only, every obstacle out of range, answered 0 for a
+    // NaN joint (tools/fuzz_parity.py, seed 504944).  So the non-finiteness is put into the force of the dof it sits on: the
+    // velocity tile holds it after the quarantine (a fed Inf / NaN velocity too), the system is then non-finite by construction
+    // and every resolve -- pass 0's settle, the closed-form 2 x 2, rmp2_pinv_kernel behind the exported system -- answers NaN.
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int i = sub + kQuad * m;
+      if (i < N) {  // (padding dofs read as 0)
+        const float qdv = my_qd[i];
+        fv[m] = (fabsf(qdv) < 3.0e38f) ? fv[m] : (double)__builtin_nanf("");
+      }
+    }
     // optional debug outputs: the combined metric / force before the resolve
     if (!LEAN && pass == 0 && live && (out.M || out.f)) {
       // (the 64-bit row addresses are formed HERE, from an opaque copy of the robot index: hoisted to the prologue -- where

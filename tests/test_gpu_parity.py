@@ -538,3 +538,67 @@ def test_all_empty_ragged_lists(torch_mod, kernel):
     got = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]), obstacles=obs).cpu().numpy()
     ref = O.step(desc, s["q"], s["qd"], s["goal"], spheres=sph, csr_offset=off, csr_index=idx)["qdd64"]
     _check(got, ref, f"all lists empty ({kernel or 'default'})")
+
+
+@pytest.mark.parametrize("solve", ["auto", "pinv"])
+@pytest.mark.parametrize("kernel", ["", "hex", "quad", "lane"])
+def test_non_finite_state_behind_out_of_range_obstacles(torch_mod, kernel, solve):
+    """A set made of distance leaves ONLY, every obstacle out of range: no leaf carries a joint's value into the system here (the
+    culling never evaluates an out-of-range pair; the quarantine of rmp2_device.h reads a NaN position as q = 0 with a NaN velocity),
+    and round 4's fuzz campaign (seed 504944) got q-double-dot = 0 for a robot with a NaN joint.  The reference answers NaN -- NaN
+    forward kinematics, or 0 * NaN of the pair's (metric 0, acceleration NaN), rmp.py:165-167, then tf.linalg.pinv of a
+    non-finite system -- and so does the engine now, with RMP2_STATUS_NONFINITE: the non-finite dof's force is made non-finite
+    by construction in every mapping.  The neighbours are untouched."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    for table_fn, frames, sampler in ((Cf.two_joint_table, ["joint_2", "link_23"], Cf.sample_two_joint_states),
+                                      (Cf.panda_table, ["panda_joint4", "panda_hand_joint"], Cf.sample_panda_states)):
+        t = table_fn()
+        desc = D.build_desc(t, [D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, t.frame_index(f), Cf.OBSTACLE_AVOIDANCE_PARAMS)
+                                for f in frames], solve)
+        n = t.n_dof
+        R = 40
+        s = sampler(np.random.default_rng(1), R)
+        q, qd = s["q"].copy(), s["qd"].copy()
+        q[3, 1] = np.nan
+        qd[5, 0] = np.inf
+        q[7, :] = np.nan
+        qd[9, 1] = -np.inf
+        sph = np.array([[30.0, 30.0, 30.0, 0.1]], np.float32)                      # far out of every control point's range
+        old = os.environ.get("RMP2_KERNEL")
+        if kernel:
+            os.environ["RMP2_KERNEL"] = kernel
+        try:
+            from riemannian_motion_policies_amd.engine import Engine
+            eng = Engine(desc, 0)
+        finally:
+            if old is None:
+                os.environ.pop("RMP2_KERNEL", None)
+            else:
+                os.environ["RMP2_KERNEL"] = old
+        for mode in ("shared", "ragged"):
+            kw = dict(spheres=sph)
+            if mode == "ragged":
+                kw.update(csr_offset=np.arange(R + 1, dtype=np.int32), csr_index=np.zeros(R, np.int32))
+            st = torch.zeros(R, dtype=torch.int32, device="cuda")
+            got = eng.step(torch.from_numpy(q), torch.from_numpy(qd), obstacles=eng.obstacles(**{k: torch.from_numpy(v) for k, v in kw.items()}),
+                           status=st).cpu().numpy()
+            stc = st.cpu().numpy()
+            ref = O.step(desc, q, qd, None, **kw)
+            dead = np.zeros(R, bool)
+            dead[[3, 5, 7, 9]] = True
+            what = f"{t.frame_names[-1]} / {solve} / {kernel or 'default'} / {mode} ({eng.last_kernel()})"
+            assert np.isnan(ref["qdd64"][dead]).all() and np.isfinite(ref["qdd64"][~dead]).all(), what       # the oracle (= the reference)
+            assert np.isnan(got[dead]).all() and (stc[dead] & D.STATUS_NONFINITE).all(), f"{what}: {got[dead]} {stc[dead]}"
+            assert np.isfinite(got[~dead]).all() and not (stc[~dead] & D.STATUS_NONFINITE).any(), what
+            assert np.abs(got[~dead] - ref["qdd64"][~dead]).max() <= 1e-5, what
+        if n == 9:
+            # ... and stricter than the reference where ITS arithmetic never reaches the value (include/rmp2.h): a NaN on a finger
+            # joint, which moves neither leaf frame -- the oracle stays finite, the engine answers NaN + status bit
+            q2 = s["q"].copy()
+            q2[4, 8] = np.nan
+            st = torch.zeros(R, dtype=torch.int32, device="cuda")
+            got = eng.step(torch.from_numpy(q2), torch.from_numpy(s["qd"]), obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st).cpu().numpy()
+            assert np.isfinite(O.step(desc, q2, s["qd"], None, spheres=sph)["qdd64"][4]).all()
+            assert np.isnan(got[4]).all() and (int(st[4]) & D.STATUS_NONFINITE) and np.isfinite(np.delete(got, 4, axis=0)).all()
