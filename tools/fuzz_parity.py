@@ -201,6 +201,31 @@ def draw_obstacles(rng, O, desc, q, obstacle_kind):
     return kw, f"{mode} K={K}"
 
 
+def known_classes(O, desc, specs, n, q, qd, goal, kw, ref):
+    """(undetermined, tiny_alone) per robot -- the two classes of robots no fp32 evaluation of the reference's formulae pins down
+    (see run_case for the reasoning): `undetermined` = a singular value of the oracle's M (fp32 or fp64 evaluation) inside
+    (1e-18, 1e-6] sigma_max, or rank deficiency beyond the all-zero rows; `tiny_alone` = a positive diagonal entry of M below 1e-6
+    of the largest obstacle-leaf metric scale the descriptor can produce (the documented componentwise limit of J^T S J)."""
+    from riemannian_motion_policies_amd import descriptor as D
+    ref64 = O.step(desc, q, qd, goal, precision="f64", **kw)
+    with np.errstate(invalid="ignore"):
+        sv = np.linalg.svd(np.where(np.isfinite(ref["M"]), ref["M"], 0.0), compute_uv=False)
+        sv64 = np.linalg.svd(np.where(np.isfinite(ref64["M"]), ref64["M"], 0.0), compute_uv=False)
+    rel = sv / np.maximum(sv[:, :1], 1e-300)
+    rel64 = sv64 / np.maximum(sv64[:, :1], 1e-300)
+    und = ((rel > 1e-18) & (rel <= 1e-6)).any(axis=1) | ((rel64 > 1e-18) & (rel64 <= 1e-6)).any(axis=1)
+    cut = 10.0 * n * np.finfo(np.float64).eps
+    zero_rows = ((ref["M"] == 0).all(axis=2) & (ref["M"] == 0).all(axis=1)).sum(axis=1)
+    und |= (rel <= cut).sum(axis=1) > zero_rows
+    # a pair within an fp32 rounding of a leaf's cutoff radius: metric exactly 0 in one evaluation, +-1e-12 in another -- when it is
+    # the ONLY metric of the system, the oracle's M is all zero while its fp64 evaluation is not (or the other way round)
+    und |= (sv[:, 0] == 0) != (sv64[:, 0] == 0)
+    diag = np.einsum("rii->ri", np.where(np.isfinite(ref["M"]), ref["M"], 0.0))
+    scale_m = max([float(sp.params[8]) / max(float(sp.params[10]), 1e-30) for sp in specs if sp.kind == D.LEAF_OBSTACLE_AVOIDANCE] + [0.0])
+    tiny = ((diag > 0) & (diag < 1e-6 * max(scale_m, 1e-30))).any(axis=1) & (scale_m > 0)
+    return und, tiny, rel
+
+
 def draw_case(seed):
     """Everything one seed fixes, drawn in ONE order (tools/diag_fuzz_*.py replay through this too): dict with table, specs,
     solve, kernel, R, desc (None: the descriptor compiler declined, `why`), q, qd, goal, oracle kwargs, engine kwargs, the
@@ -332,22 +357,7 @@ def run_case(seed, torch, verbose=False):
     # (rmp.py:153-154): a direction whose singular value is fp32 noise is KEPT, and contributes (noise of f) / (noise of M) -- in the
     # reference as here, with different noise.  Such a robot is held to what a solver can promise it: the backward error against the
     # oracle's system (omega <= 1e-4) and a finite answer.  Counted separately; every other robot passes the full gate.
-    # (the band is looked for in the oracle's reference-precision system AND in its fp64 evaluation: a pair within an fp32 rounding
-    #  of a leaf's cutoff radius has a metric of exactly 0 in one fp32 evaluation, +-1e-12 in another and +1e-11 in exact arithmetic
-    #  -- rmp2.py:170-174: the gate x^2 / r^2 - 2 x / r + 1 has a double root at the cutoff)
-    ref64 = O.step(desc, q, qd, goal, precision="f64", **kw)
-    with np.errstate(invalid="ignore"):
-        sv = np.linalg.svd(np.where(np.isfinite(ref["M"]), ref["M"], 0.0), compute_uv=False)
-        sv64 = np.linalg.svd(np.where(np.isfinite(ref64["M"]), ref64["M"], 0.0), compute_uv=False)
-    rel = sv / np.maximum(sv[:, :1], 1e-300)
-    rel64 = sv64 / np.maximum(sv64[:, :1], 1e-300)
-    undetermined = ((rel > 1e-18) & (rel <= 1e-6)).any(axis=1) | ((rel64 > 1e-18) & (rel64 <= 1e-6)).any(axis=1)
-    # ... and a system that is rank-deficient beyond its all-zero rows (seven active rank-one leaves on eight moving dofs): the
-    # exact singular value is 0, what an fp32 evaluation leaves of it is rounding noise around the cutoff (the oracle's per-pair
-    # outer products leave 1e-20, the engine's pull-back of the summed 3 x 3 leaf metric 1e-15; the cutoff sits at 6e-16)
-    cut = 10.0 * n * np.finfo(np.float64).eps
-    zero_rows = ((ref["M"] == 0).all(axis=2) & (ref["M"] == 0).all(axis=1)).sum(axis=1)
-    undetermined |= (rel <= cut).sum(axis=1) > zero_rows
+    undetermined, tiny_alone, rel = known_classes(O, desc, specs, n, q, qd, goal, kw, ref)
     backward_ok = np.isfinite(got).all(axis=1) & (verdict["omega"] <= 1e-4)
     ok = verdict["ok"] | (undetermined & backward_ok)
     # a robot fed a non-finite state may answer NaN + status bit although the reference's graph never reaches the value
@@ -366,10 +376,6 @@ def run_case(seed, torch, verbose=False):
     # m rho^2 |J_j|^2 is then off by eps32 / rho^2 relative.  Beside any other metric on the dof that is 6e-8 of the total; alone
     # it is the dof's whole answer.  Criterion here: a positive diagonal entry of the oracle's M below 1e-6 times the largest
     # leaf-metric scale the descriptor can produce (metric_scalar / exploder_eps) and no larger entry in its row; counted, not hidden.
-    diag = np.einsum("rii->ri", np.where(np.isfinite(ref["M"]), ref["M"], 0.0))
-    offmax = np.abs(np.where(np.isfinite(ref["M"]), ref["M"], 0.0) - diag[:, :, None] * np.eye(n)[None]).max(axis=2)
-    scale_m = max([float(sp.params[8]) / max(float(sp.params[10]), 1e-30) for sp in specs if sp.kind == D.LEAF_OBSTACLE_AVOIDANCE] + [0.0])
-    tiny_alone = ((diag > 0) & (diag < 1e-6 * max(scale_m, 1e-30)) & (offmax <= 2.0 * np.sqrt(np.abs(diag) * np.abs(diag).max(axis=1, keepdims=True)))).any(axis=1) & (scale_m > 0)
     lim2 = tiny_alone & ~ok & np.isfinite(got).all(axis=1)
     summary["tiny_projection_alone_on_a_dof_componentwise_limit"] = int(lim2.sum())
     ok |= lim2
@@ -432,12 +438,95 @@ def run_case(seed, torch, verbose=False):
     return "passed", what
 
 
+def run_pair_case(seed, torch):
+    """The one-grid step of TWO engines (rmp2_step_pair: a TwoJoint and a Panda shard of one mixed rank, BASELINE config 5): random
+    RMP sets for both (distance leaves on random frames, parameters jittered per leaf; the Panda's with an inertia leaf, the
+    TwoJoint's with or without), a shared or ragged sphere table, fleets just over the fused grid's threshold -- each part against
+    its oracle through the gate."""
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    from riemannian_motion_policies_amd.engine import Engine, bind_pair
+    rng = np.random.default_rng(seed)
+    solve = str(rng.choice(["auto", "pinv"], p=[0.7, 0.3]))
+    ragged = bool(rng.random() < 0.6)
+    K = int(rng.choice([1, 8, 32, 100, 256]))
+    parts = []
+    for name, table_fn, lo, hi in (("two_joint", Cf.two_joint_table, Cf.TWO_JOINT_Q_LOW, Cf.TWO_JOINT_Q_HIGH), ("panda", Cf.panda_table, Cf.PANDA_Q_LOW, Cf.PANDA_Q_HIGH)):
+        t = table_fn()
+        lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+        for _ in range(20):
+            specs, kind = draw_specs(rng, t, lo, hi)
+            specs = [s for s in specs if s.taskmap != D.TASKMAP_FK_POINT]
+            if name == "panda" and not any(s.kind == D.LEAF_JOINT_DAMPING for s in specs):
+                specs.append(D.LeafSpec(D.LEAF_JOINT_DAMPING, D.TASKMAP_IDENTITY, -1, jitter(rng, Cf.JOINT_DAMPING_PARAMS)))
+            if any(s.taskmap == D.TASKMAP_FK_DISTANCE for s in specs) and sum(s.goal_len for s in specs) <= 16:
+                break
+        else:
+            return "declined", dict(seed=seed, why="no set with distance leaves drawn")
+        desc = D.build_desc(t, specs, solve)
+        R = int(rng.choice([8193, 8200, 9001]))
+        n = t.n_dof
+        span = hi - lo
+        q = rng.uniform(lo + 0.05 * span, hi - 0.05 * span, (R, n)).astype(np.float32)
+        qd = rng.uniform(-0.1, 0.1, (R, n)).astype(np.float32)
+        goal = rng.uniform(-0.8, 0.8, (R, desc.goal_floats)).astype(np.float32) if desc.goal_floats else None
+        parts.append(dict(name=name, table=t, specs=specs, desc=desc, R=R, q=q, qd=qd, goal=goal))
+    sph = np.concatenate([rng.uniform([-1.0, -1.0, -0.2], [1.0, 1.0, 1.2], (K, 3)), rng.uniform(0.03, 0.1, (K, 1))], axis=1).astype(np.float32)
+    what = dict(seed=seed, solve=solve, ragged=ragged, K=K, leaves={p["name"]: [(s.kind, s.taskmap, s.frame) for s in p["specs"]] for p in parts},
+                robots=[p["R"] for p in parts])
+    try:
+        for p in parts:
+            p["eng"] = Engine(p["desc"], 0)
+            kw = dict(spheres=sph)
+            if ragged:
+                counts = rng.integers(0, min(K, 24) + 1, size=p["R"])
+                off = np.zeros(p["R"] + 1, np.int32)
+                off[1:] = np.cumsum(counts)
+                idx = np.concatenate([rng.integers(0, K, size=int(k)) for k in counts] + [np.zeros(0, np.int64)]).astype(np.int32)
+                kw.update(csr_offset=off, csr_index=idx)
+            p["kw"] = kw
+            p["obs"] = p["eng"].obstacles(**{k: torch.from_numpy(v) for k, v in kw.items()})
+            p["dev"] = [torch.from_numpy(p[k]).cuda() if p[k] is not None else None for k in ("q", "qd", "goal")]
+            p["out"] = torch.empty((p["R"], p["table"].n_dof), dtype=torch.float32, device="cuda")
+        a, b = parts
+        launch = bind_pair(a["eng"], a["dev"][0], a["dev"][1], a["dev"][2], a["obs"], a["out"], b["eng"], b["dev"][0], b["dev"][1], b["dev"][2], b["obs"], b["out"])
+        for p in parts:
+            p["out"].fill_(float("nan"))
+        launch()
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        from riemannian_motion_policies_amd import _native
+        if isinstance(e, _native.Rmp2Error) and e.code == _native.ERR_UNSUPPORTED:
+            return "declined", dict(what, why=str(e))
+        return "failed", dict(what, why=f"{type(e).__name__}: {e}")
+    what["ran"] = b["eng"].last_kernel()
+    problems = []
+    for p in parts:
+        got = p["out"].cpu().numpy()
+        ref = O.step(p["desc"], p["q"], p["qd"], p["goal"], **p["kw"])
+        res = O.fp32_resolution(p["desc"], p["q"], p["qd"], p["goal"], **p["kw"])
+        v = O.accuracy_gate(got, ref, spread=res, system_spread=O.system_resolution(ref))
+        what[p["name"]] = O.gate_summary(v)
+        und, tiny, _ = known_classes(O, p["desc"], p["specs"], p["table"].n_dof, p["q"], p["qd"], p["goal"], p["kw"], ref)
+        fin = np.isfinite(got).all(axis=1)
+        ok = v["ok"] | (und & fin & (v["omega"] <= 1e-4)) | (tiny & fin)
+        what[p["name"]]["undetermined_at_fp32_backward_error_only"] = int((und & ~v["ok"] & fin & (v["omega"] <= 1e-4)).sum())
+        what[p["name"]]["tiny_projection_alone_on_a_dof_componentwise_limit"] = int((tiny & ~v["ok"] & fin).sum())
+        if not ok.all():
+            bad = np.nonzero(~ok)[0]
+            problems.append(f"{p['name']}: {len(bad)} robot(s) outside the gate, first {bad[:4].tolist()}: err {v['err_inf'][bad[:4]].tolist()}, cond {v['cond'][bad[:4]].tolist()}")
+    if problems:
+        return "failed", dict(what, why="; ".join(problems))
+    return "passed", what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs=2, default=[0, 200])
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--log", default="")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--pairs", action="store_true", help="run the seeds as PAIR cases (two engines in one grid, rmp2_step_pair)")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available(), "the fuzz campaign needs a HIP device"
@@ -452,17 +541,17 @@ def main():
         if time.time() - t0 > args.minutes * 60:
             break
         try:
-            outcome, what = run_case(seed, torch, args.verbose)
+            outcome, what = run_pair_case(seed, torch) if args.pairs else run_case(seed, torch, args.verbose)
         except Exception as e:   # noqa: BLE001 -- a crash of the harness or the oracle on a case is a finding too
             import traceback
             outcome, what = "failed", dict(seed=seed, why=f"{type(e).__name__}: {e}", trace=traceback.format_exc(limit=4))
         done += 1
         counts[outcome] += 1
         if outcome == "passed":
-            robots += what["robots"]
+            robots += sum(what["robots"]) if isinstance(what["robots"], list) else what["robots"]
             k = what.get("ran", "?").split("<")[0].split(" (")[0][:48]
             by_kernel[k] = by_kernel.get(k, 0) + 1
-            o = what["obstacles"].split(" ")[0]
+            o = what["obstacles"].split(" ")[0] if "obstacles" in what else ("ragged" if what.get("ragged") else "spheres")
             by_obstacles[o] = by_obstacles.get(o, 0) + 1
         elif outcome == "declined":
             w = what["why"][:90]
