@@ -34,3 +34,22 @@ def test_fuzz_slice(hip_lib, seeds):
             failures.append((seed, what.get("why", "")[:300]))
     assert not failures, failures
     assert outcomes["passed"] >= 0.9 * len(seeds), outcomes
+
+
+def test_fuzz_slice_pair_grid(hip_lib):
+    """The one-grid step of two engines (rmp2_step_pair: a TwoJoint and a Panda shard of one mixed rank, BASELINE config 5) on
+    random RMP sets, shared / ragged sphere tables, fleets just over the fused grid's threshold -- each part against its oracle."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import fuzz_parity as F
+    finally:
+        sys.path.pop(0)
+    ran, failures = [], []
+    for seed in range(12):
+        outcome, what = F.run_pair_case(seed, torch)
+        ran.append(what.get("ran", ""))
+        if outcome == "failed":
+            failures.append((seed, what.get("why", "")[:300]))
+    assert not failures, failures
+    assert any("pair" in r for r in ran), ran          # the fused grid did run in some of them
