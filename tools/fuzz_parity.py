@@ -321,16 +321,29 @@ def run_case(seed, torch, verbose=False):
             K, sub, dt = int(rng.integers(2, 5)), int(rng.integers(1, 4)), 0.004
             tq, tqd = torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()
             tg = None if goal is None else torch.from_numpy(goal).cuda()
+            # half of the table cases: the obstacles MOVE between control steps (Engine.obstacle_trajectory: control step k reads
+            # table k) -- K rollouts of one step, each on its own table, must still be what one rollout of K steps does
+            moving = ("spheres" in eng_kw) and ("link_capsules" not in eng_kw) and rng.random() < 0.5
+            per_step = [obstacles] * K
+            traj = obstacles
+            if moving:
+                base = eng_kw["spheres"]
+                drift = rng.normal(size=(1, base.shape[1])).astype(np.float32) * 0.02
+                drift[:, 3] = 0.0
+                tables = np.stack([base + k * drift for k in range(K)]).astype(np.float32)
+                lists = {k: torch.from_numpy(eng_kw[k]) for k in ("csr_offset", "csr_index") if k in eng_kw}
+                traj = eng.obstacle_trajectory(torch.from_numpy(tables), **lists)
+                per_step = [eng.obstacles(spheres=torch.from_numpy(tables[k]), **lists) for k in range(K)]
             qa, qda = tq.clone(), tqd.clone()
-            la = eng.rollout(qa, qda, tg, obstacles=obstacles, n_control_steps=K, substeps=sub, dt=dt).clone()
+            la = eng.rollout(qa, qda, tg, obstacles=traj, n_control_steps=K, substeps=sub, dt=dt).clone()
             qb, qdb = tq.clone(), tqd.clone()
             first = None
             for k in range(K):
-                lb = eng.rollout(qb, qdb, tg, obstacles=obstacles, n_control_steps=1, substeps=sub, dt=dt)
+                lb = eng.rollout(qb, qdb, tg, obstacles=per_step[k], n_control_steps=1, substeps=sub, dt=dt)
                 if k == 0:
                     first = lb.clone()
             torch.cuda.synchronize()
-            what["rollout"] = f"K={K} sub={sub} ({eng.last_kernel()[:40]})"
+            what["rollout"] = f"K={K} sub={sub}{' moving tables' if moving else ''} ({eng.last_kernel()[:40]})"
             same = lambda a, b: bool(torch.equal(torch.nan_to_num(a, nan=12345.0, posinf=2e30, neginf=-2e30), torch.nan_to_num(b, nan=12345.0, posinf=2e30, neginf=-2e30)))
             if not (same(qa, qb) and same(qda, qdb) and same(la, lb)):
                 rollout_problem = f"rollout of {K} control steps != {K} rollouts of one (max |dq| {float(torch.nan_to_num(qa - qb).abs().max()):.3e})"
