@@ -467,16 +467,55 @@ __device__ __forceinline__ void link_pair_fields(const float LA[3], const float 
   }
 }
 
+// Rank-one form of a leaf's summed metric.  A distance leaf pulls back S = sum_k m_k n_k n_k^T (one 3 x 3 per frame instead of
+// one scalar per pair: the reason the pair loop is cheap) as J^T S J, accurate to eps32 |S| |J_j|^2 ABSOLUTELY -- backward stable
+// in S, not componentwise: where a column is nearly perpendicular to the pair direction (rho = |n . J_j| / |J_j| below
+// sqrt(eps32)) the entry m rho^2 |J_j|^2 comes out off by eps32 / rho^2 RELATIVE, while the reference, which squares the projected
+// scalar n . J_j (taskmap.py:150-160, rmp.py:165-167), has it to 2 eps32 / rho.  Beside any other metric on the dof that is
+// 6e-8 of the total; in a set without an inertia leaf it can be the dof's whole answer (tools/fuzz_parity.py seed 402914: 22 %).
+// When S is rank one to fp32 resolution -- one pair in range, the case that matters -- its factor is recovered,
+// n_i = S_ik / sqrt(S_kk tr S) from the dominant column k, m = tr S, and S c is formed as m (n . c) n: the projection is then
+// computed ONCE and squared, as the reference does.  Used where the set has no positive-definite identity leaf (QuadHdr::rank1)
+// and by the lane-per-robot kernel.
+struct RankOne {
+  float n[3], tr;
+  bool on;
+};
+__device__ __forceinline__ RankOne rank_one_of(const float S[6]) {
+  RankOne r;
+  const float tr = S[0] + S[3] + S[5];
+  const float f2 = S[0] * S[0] + S[3] * S[3] + S[5] * S[5] + 2.f * (S[1] * S[1] + S[2] * S[2] + S[4] * S[4]);
+  r.on = tr > 0.f && (tr * tr - f2) <= 4e-7f * (tr * tr);  // 2 lambda_1 lambda_2 <= 4e-7 tr^2 (NaN compares false)
+  const bool k0 = S[0] >= S[3] && S[0] >= S[5], k1 = !k0 && S[3] >= S[5];
+  const float dk = k0 ? S[0] : (k1 ? S[3] : S[5]);
+  const float inv = r.on ? rsqrtf(dk * tr) : 0.f;
+  r.n[0] = (k0 ? S[0] : (k1 ? S[1] : S[2])) * inv;
+  r.n[1] = (k0 ? S[1] : (k1 ? S[3] : S[4])) * inv;
+  r.n[2] = (k0 ? S[2] : (k1 ? S[4] : S[5])) * inv;
+  r.tr = tr;
+  return r;
+}
+// u = S c, in the rank-one form where it applies
+__device__ __forceinline__ void metric_times_column(const float S[6], const RankOne& r1, const float c[3], float u[3]) {
+  u[0] = S[0] * c[0] + S[1] * c[1] + S[2] * c[2];
+  u[1] = S[1] * c[0] + S[3] * c[1] + S[4] * c[2];
+  u[2] = S[2] * c[0] + S[4] * c[1] + S[5] * c[2];
+  const float a = r1.tr * (r1.n[0] * c[0] + r1.n[1] * c[1] + r1.n[2] * c[2]);
+  u[0] = r1.on ? a * r1.n[0] : u[0];
+  u[1] = r1.on ? a * r1.n[1] : u[1];
+  u[2] = r1.on ? a * r1.n[2] : u[2];
+}
+
 template <int N>
 __device__ __forceinline__ void pull_position(const float (&col)[N][3], uint32_t active, const float S[6],
                                               const float h[3], double (&Ms)[N * (N + 1) / 2], double (&fv)[N]) {
+  const RankOne r1 = rank_one_of(S);  // (the lane-per-robot kernel: always)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     if (!((active >> j) & 1u)) continue;  // wave-uniform: dof j does not move this frame
     fv[j] += (double)dot3(col[j], h);
-    const float t[3] = {S[0] * col[j][0] + S[1] * col[j][1] + S[2] * col[j][2],
-                        S[1] * col[j][0] + S[3] * col[j][1] + S[4] * col[j][2],
-                        S[2] * col[j][0] + S[4] * col[j][1] + S[5] * col[j][2]};
+    float t[3];
+    metric_times_column(S, r1, col[j], t);
 #pragma unroll
     for (int i = 0; i <= j; ++i)
       if ((active >> i) & 1u) Ms[sym_idx<N>(i, j)] += (double)dot3(col[i], t);

@@ -693,9 +693,14 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     };
     // pull-back into MY row:  f_s += col_s . h ;  A[s][j] += (S col_s) . col_j   (rmp.py:165-167)
     auto pull_back = [&](const float S[6], const float h[3]) {
-      const float u[3] = {S[0] * mycol[0] + S[1] * mycol[1] + S[2] * mycol[2],
-                          S[1] * mycol[0] + S[3] * mycol[1] + S[4] * mycol[2],
-                          S[2] * mycol[0] + S[4] * mycol[1] + S[5] * mycol[2]};
+      float u[3];
+      if (hdr.rank1) {  // (wave-uniform) sets without an inertia leaf: the rank-one form of the leaf metric (rmp2_device.h)
+        metric_times_column(S, rank_one_of(S), mycol, u);
+      } else {
+        u[0] = S[0] * mycol[0] + S[1] * mycol[1] + S[2] * mycol[2];
+        u[1] = S[1] * mycol[0] + S[3] * mycol[1] + S[4] * mycol[2];
+        u[2] = S[2] * mycol[0] + S[4] * mycol[1] + S[5] * mycol[2];
+      }
       fv += (double)dot3(mycol, h);
 #pragma unroll
       for (int j = 0; j < N; ++j) A[j] += (double)dot3(u, col[j]);

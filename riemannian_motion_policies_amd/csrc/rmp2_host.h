@@ -103,7 +103,7 @@ inline bool hex_certifies_strict(const rmp2_handle* h) { return h->strict && h->
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                  h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, h->strict ? 1 : 0,
-                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0, h->has_point ? 1 : 0};
+                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0, h->has_point ? 1 : 0, h->likely_singular ? 1 : 0};
 }
 // rmp2_hex_tu.hip (false: the working set does not fit the CU's LDS -- the caller falls back to the quad mapping)
 bool launch_hex_n2(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,

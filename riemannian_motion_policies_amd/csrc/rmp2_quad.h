@@ -1010,6 +1010,8 @@ struct QuadHdr {
   int32_t skip_resolve; // 1 (rmp2_quad.h, general flavour): the step stops behind the combined metric / force (out.M, out.f);
                         // rmp2_pinv_kernel resolves every robot by the pseudo-inverse (solve = PINV, rank-deficient sets)
   int32_t has_point;    // the set carries attached-point leaves (full 16-float rotation records even when link geometry is given)
+  int32_t rank1;        // the set has no positive-definite identity leaf: a leaf metric that is rank one is pulled back in its
+                        // rank-one form (rmp2_device.h rank_one_of)
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -1965,6 +1967,9 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         // entries for n = 9, so 24 fewer live registers through the pair loops and 45 % fewer products; mirrored once
         // below.  Column j lives in lane (j & 3) as its local row j >> 2: it is broadcast right where it is consumed.
         RMP2_SEG(3);  // Jacobian columns of my rows
+        RankOne r1;
+        r1.on = false, r1.tr = 0.f, r1.n[0] = r1.n[1] = r1.n[2] = 0.f;
+        if (hdr.rank1) r1 = rank_one_of(S);
         float u[ROWS][3];
         float myz[PT ? ROWS : 1][3], tz[PT ? ROWS : 1][3];   // (attached-point leaves: my rows' revolute axes, and Q z_i - c_i x rho)
         if (PT) {
@@ -1975,9 +1980,13 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         for (int m = 0; m < ROWS; ++m) {
           u[m][0] = u[m][1] = u[m][2] = 0.f;
           if (((op.anc_mask >> (kQuad * m)) & 0xfu) == 0u) continue;  // wave-uniform: no row of this block moves the frame
-          u[m][0] = S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2];
-          u[m][1] = S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2];
-          u[m][2] = S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2];
+          if (hdr.rank1) {  // (wave-uniform) sets without an inertia leaf: componentwise accuracy matters there
+            metric_times_column(S, r1, mycol[m], u[m]);
+          } else {
+            u[m][0] = S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2];
+            u[m][1] = S[1] * mycol[m][0] + S[3] * mycol[m][1] + S[4] * mycol[m][2];
+            u[m][2] = S[2] * mycol[m][0] + S[4] * mycol[m][1] + S[5] * mycol[m][2];
+          }
           fv[m] += (double)dot3(mycol[m], h);
           if (PT) {  // attached-point leaf:  A_ij += c_j . (W c_i - rho x z_i) + z_j . (Q z_i - c_i x rho),  f_i += z_i . tau
             const bool actz = pt_leaf && rjrev[m] && ((op.anc_mask >> (sub + kQuad * m)) & 1u);

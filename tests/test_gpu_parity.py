@@ -602,3 +602,55 @@ def test_non_finite_state_behind_out_of_range_obstacles(torch_mod, kernel, solve
             got = eng.step(torch.from_numpy(q2), torch.from_numpy(s["qd"]), obstacles=eng.obstacles(spheres=torch.from_numpy(sph)), status=st).cpu().numpy()
             assert np.isfinite(O.step(desc, q2, s["qd"], None, spheres=sph)["qdd64"][4]).all()
             assert np.isnan(got[4]).all() and (int(st[4]) & D.STATUS_NONFINITE) and np.isfinite(np.delete(got, 4, axis=0)).all()
+
+
+@pytest.mark.parametrize("kernel", ["", "hex", "quad", "lane"])
+def test_a_dof_whose_only_metric_is_a_nearly_perpendicular_projection(torch_mod, kernel):
+    """A distance leaf is pulled back as J^T S J with S = sum m n n^T summed per frame -- accurate to eps32 |S| |J_j|^2 absolutely, not
+    componentwise: where the pair direction is nearly perpendicular to a dof's column (rho = |n . J_j| / |J_j| << 1) the entry
+    m rho^2 |J_j|^2 was off by eps32 / rho^2 relative (tools/fuzz_parity.py seed 402914: 22 % at rho = 2.3e-4), and in a set that gives
+    the dof no other metric that entry is the dof's whole answer.  The reference squares the projected scalar (taskmap.py:150-160).
+    Sets without an inertia leaf now pull a rank-one leaf metric back in its rank-one form (rmp2_device.h rank_one_of): the TwoJoint
+    arm with ONE distance leaf on joint_2's frame (moved by dof 0 only), one sphere placed so that the pair direction makes the angle
+    pi/2 - rho with the frame's path, agrees with the oracle's fp64 evaluation to a small multiple of what the oracle's own fp32
+    evaluation resolves, down to rho = 5e-5 (where the old form was 20x off)."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    t = Cf.two_joint_table()
+    fr = t.frame_index("joint_2")
+    desc = D.build_desc(t, [D.LeafSpec(D.LEAF_OBSTACLE_AVOIDANCE, D.TASKMAP_FK_DISTANCE, fr, Cf.OBSTACLE_AVOIDANCE_PARAMS)], "pinv")
+    R = 64
+    rng = np.random.default_rng(2)
+    q = np.tile(np.array([[0.7, -0.4]], np.float32), (R, 1))
+    qd = rng.uniform(-0.3, 0.3, (R, 2)).astype(np.float32)
+    T = O.forward_kinematics(desc, q[:1], "f64")[0]
+    p2, o1 = T[fr, :3, 3], T[t.frame_index("joint_1"), :3, 3]
+    radial = (p2 - o1) / np.linalg.norm(p2 - o1)
+    tangent = np.cross(T[t.frame_index("joint_1"), :3, 2], radial)
+    old = os.environ.get("RMP2_KERNEL")
+    if kernel:
+        os.environ["RMP2_KERNEL"] = kernel
+    try:
+        from riemannian_motion_policies_amd.engine import Engine
+        eng = Engine(desc, 0)
+    finally:
+        if old is None:
+            os.environ.pop("RMP2_KERNEL", None)
+        else:
+            os.environ["RMP2_KERNEL"] = old
+    for rho in (1e-2, 1e-3, 2e-4, 5e-5):
+        c = p2 + 0.3 * (np.cos(rho) * radial + np.sin(rho) * tangent)
+        sph = np.array([[c[0], c[1], c[2], 0.1]], np.float32)                         # surface distance 0.2 < metric_modulation_radius
+        got = eng.step(torch.from_numpy(q), torch.from_numpy(qd), obstacles=eng.obstacles(spheres=torch.from_numpy(sph))).cpu().numpy()
+        ref = O.step(desc, q, qd, None, spheres=sph)
+        ref64 = O.step(desc, q, qd, None, spheres=sph, precision="f64")["qdd64"]
+        assert (np.abs(ref["M"][:, 0, 0]) > 0).all() and (ref["M"][:, 1, 1] == 0).all()          # dof 0 alone, through the projection
+        scale = np.abs(ref64[:, 0])
+        # the reference-precision oracle itself resolves the projection to ~eps32 / rho: that is the yardstick
+        own = np.abs(ref["qdd64"][:, 0] - ref64[:, 0]) / scale
+        err = np.abs(got[:, 0] - ref64[:, 0]) / scale
+        # (x 20: the mappings' own forward kinematics -- pointer jumping, hardware sine / cosine -- move the control point by another
+        #  few 1e-7 m, which the projection sees like the oracle's rounding; the old form was at eps32 / rho^2 = 6 % .. 2 400 % here)
+        assert (err <= np.maximum(2e-3, 20.0 * own)).all(), f"rho = {rho:g} ({eng.last_kernel()}): worst {err.max():.2e} (oracle's own {own.max():.2e})"
+        assert (got[:, 1] == 0).all()
