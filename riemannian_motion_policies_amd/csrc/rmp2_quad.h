@@ -1071,6 +1071,11 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   const int obs_mode = OBS == kObsAny ? obs.mode : (LINKSEG ? RMP2_OBS_SHARED_SPHERES : OBS);
   constexpr bool PLAIN = FLAVOR == kPlainStep;   // no rollout loop
   constexpr bool LEAN = FLAVOR != kGeneral;      // no debug outputs
+  // the rank-one pull-back of sets without an inertia leaf (QuadHdr::rank1) is compiled into every build such a set can reach:
+  // the general flavour (two-kernel step, debug outputs), the rollout builds, the 2-dof builds -- not into the plain step of the
+  // 3..9-dof template, which dispatch_solve never gives them (measured: the two wave-uniform branches per leaf frame and the
+  // longer live ranges cost the headline kernel 2.5 %)
+  constexpr bool kRank1 = FLAVOR != kPlainStep || N == 2;
   const RolloutArgs ro = PLAIN ? RolloutArgs{1, 0, 0.f, nullptr, nullptr, 0} : ro_arg;
 #ifdef RMP2_STAMPS
   if (LEAN) out.M = nullptr;  // (diagnostic build: the stamps travel behind the f rows, so the plain build keeps that pointer)
@@ -1969,7 +1974,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         RMP2_SEG(3);  // Jacobian columns of my rows
         RankOne r1;
         r1.on = false, r1.tr = 0.f, r1.n[0] = r1.n[1] = r1.n[2] = 0.f;
-        if (hdr.rank1) r1 = rank_one_of(S);
+        if (kRank1 && hdr.rank1) r1 = rank_one_of(S);
         float u[ROWS][3];
         float myz[PT ? ROWS : 1][3], tz[PT ? ROWS : 1][3];   // (attached-point leaves: my rows' revolute axes, and Q z_i - c_i x rho)
         if (PT) {
@@ -1980,7 +1985,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         for (int m = 0; m < ROWS; ++m) {
           u[m][0] = u[m][1] = u[m][2] = 0.f;
           if (((op.anc_mask >> (kQuad * m)) & 0xfu) == 0u) continue;  // wave-uniform: no row of this block moves the frame
-          if (hdr.rank1) {  // (wave-uniform) sets without an inertia leaf: componentwise accuracy matters there
+          if (kRank1 && hdr.rank1) {  // (wave-uniform) sets without an inertia leaf: componentwise accuracy matters there
             metric_times_column(S, r1, mycol[m], u[m]);
           } else {
             u[m][0] = S[0] * mycol[m][0] + S[1] * mycol[m][1] + S[2] * mycol[m][2];

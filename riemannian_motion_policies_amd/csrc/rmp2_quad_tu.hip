@@ -126,7 +126,8 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     // link geometry of the distance leaves over a SHARED table, plain control step, throughput grid: the lean builds (OBS =
     // kObsSharedLink: the link's world segment formed in the walk, 8 floats per leaf-bearing frame -- no rotation records, no
     // rollout loop, no debug outputs): three waves per SIMD by registers, ten waves per CU by LDS for the Panda
-    if (o.link_caps && !h->has_point && h->link_rows_ok && o.mode == RMP2_OBS_SHARED_SPHERES && !latency && ro.n_iters == 1 &&
+    // (sets without an inertia leaf keep the general build: it carries the rank-one pull-back, rmp2_quad.h kRank1)
+    if (o.link_caps && !h->has_point && !h->likely_singular && h->link_rows_ok && o.mode == RMP2_OBS_SHARED_SPHERES && !latency && ro.n_iters == 1 &&
         ro.substeps == 0 && !ro.q_out && !out.M && !out.f) {
       bytes = lds_bytes + sizeof(float) * kLinkSeg * kRobotsPerWave * h->n_leaf_ops;
       const int lw = h->quad_minw == 2 ? 2 : 3;
