@@ -186,8 +186,11 @@ __device__ __forceinline__ void segment_segment(const float p1[3], const float q
 // the whole robot, in the reference (NaN FK -> NaN metric -> pinv of a NaN matrix, rmp.py:153) and here.  Left in place it also
 // makes every range test of the robot's control points come out "in range" (NaN compares false): 256 pairs instead of ~55, and
 // the robot's whole wave waits for it -- a fleet with 6 % dead robots stepped 25 % slower.  The non-finiteness is therefore
-// moved from the position to the velocity of the same joint: FK and the range tests see q_i = 0, the NaN velocity reaches the
-// metric through every velocity-dependent leaf and the resolve settles the robot to NaN with RMP2_STATUS_NONFINITE as before.
+// moved from the position to the velocity of the same joint: FK and the range tests see q_i = 0, and the kernels make the FORCE of
+// a dof with a non-finite velocity non-finite by construction before any export or resolve (rmp2_quad.h / rmp2_hex.h behind the
+// identity leaves): the resolve settles the robot to NaN with RMP2_STATUS_NONFINITE whatever the leaves see of the joint.  (Until
+// round 4 the NaN velocity was left to reach the system through the velocity-dependent leaves -- which a set of distance leaves
+// with every obstacle out of range does not have: tools/fuzz_parity.py seed 504944.)
 // (A plant tick turns a NaN velocity into a NaN position, so "velocity NaN" identifies the quarantined joints when the state
 // is written back.)
 __device__ __forceinline__ void quarantine(float& qv, float& qdv) {
