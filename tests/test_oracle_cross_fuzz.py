@@ -3,7 +3,8 @@ Jacobians, closed-form curvature terms, its own pseudo-inverse) and the autodiff
 (oracle/torch_autodiff_oracle.py: the reference's tensor ops, derivatives by nested autograd, numpy's pinv with TensorFlow's
 cutoff) share no derivation -- the fixtures pin one to the other on the reference's own experiment sets; this does it on sets
 nobody wrote down: both reference robots, a random subset of the leaf kinds in random order with parameters jittered per leaf
-on random frames (tools/fuzz_parity.draw_specs), explicit closest-point pairs / attached-point records with uneven counts,
+on random frames (tools/fuzz_parity.draw_specs), sphere / capsule tables (shared and ragged) against the equivalent explicit
+pairs, explicit closest-point pairs / attached-point records with uneven counts,
 both resolves.  An inertia leaf is forced so that the systems are the kind fp32 determines.  (120 seeds in
 the suite; `pytest tests/test_oracle_cross_fuzz.py -n 6` with the range raised to 1 500 ran clean in round 4: 4 500 robots.)"""
 import json
@@ -60,6 +61,34 @@ def test_c_oracle_against_autodiff_oracle_on_random_sets(golden_dir, seed):
                 for k, li in enumerate(dl):
                     sl = slice(begin[k], begin[k + 1])
                     pairs_of[r][li] = (rel[r, sl], nv[r, sl], dist[r, sl])
+        elif rng.random() < 0.5:
+            # a primitive TABLE for the C oracle (shared, or a ragged list per robot: its own closest-point code for spheres and
+            # capsules) against the autodiff restatement fed the equivalent explicit pairs, formed here in numpy
+            K = int(rng.integers(1, 6))
+            T = O.forward_kinematics(desc, q, "f64")
+            org = T[:, [desc.leaves[li].frame for li in dl]][:, :, :3, 3]
+            ctr = org.reshape(-1, 3)[rng.integers(0, R * len(dl), K)] + rng.normal(size=(K, 3)) * 0.35     # near the control points
+            rad = rng.uniform(0.03, 0.08, (K, 1))
+            capsules = rng.random() < 0.5
+            tab = (np.concatenate([ctr, rad, ctr + rng.normal(size=(K, 3)) * 0.2, np.zeros((K, 1))], axis=1) if capsules
+                   else np.concatenate([ctr, rad], axis=1)).astype(np.float32)
+            pl, po = (Cf.pairs_from_capsules if capsules else Cf.pairs_from_spheres)(org.astype(np.float32), tab)
+            # keep the fixture rule (clear of contact): drop tables that come within 0.06 m of a control point
+            if (np.linalg.norm(pl.astype(np.float64) - po, axis=-1) < 0.06).any():
+                tab[:, :3] += 5.0
+                if capsules:
+                    tab[:, 4:7] += 5.0
+                pl, po = (Cf.pairs_from_capsules if capsules else Cf.pairs_from_spheres)(org.astype(np.float32), tab)
+            kw = dict(spheres=tab)
+            lists = [np.arange(K)] * R
+            if rng.random() < 0.5:
+                lists = [rng.permutation(K)[: int(rng.integers(0, K + 1))] for _ in range(R)]
+                kw.update(csr_offset=np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32),
+                          csr_index=np.concatenate(lists + [np.zeros(0, np.int64)]).astype(np.int32))
+            for r in range(R):
+                for k, li in enumerate(dl):
+                    cols = k * K + lists[r]
+                    pairs_of[r][li] = (pl[r, cols], po[r, cols])
         else:
             T = O.forward_kinematics(desc, q, "f64")
             pl = np.zeros((R, P, 3), np.float32)
