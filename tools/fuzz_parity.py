@@ -312,6 +312,22 @@ def run_case(seed, torch, verbose=False):
     except ValueError as e:
         return "declined", dict(what, why=f"host: {e}")
     got, stc = out.cpu().numpy(), st.cpu().numpy()
+    entry_problem = None
+    if rng.random() < 0.1 and not dead.any():
+        # the kinematics entry points of the ABI on this robot (rmp2_forward_kinematics, rmp2_differentiate: SURVEY 8(a) a3 / a4) --
+        # every frame's transform, and (x, xd, J, c) of a random frame, against the oracle, with the structural zeros of J exact
+        m = min(R, 64)
+        Tg = eng.forward_kinematics(torch.from_numpy(q[:m])).cpu().numpy()
+        dT = float(np.abs(Tg - O.forward_kinematics(desc, q[:m])).max())
+        fr = int(rng.integers(0, t.n_frames))
+        gd = [x.cpu().numpy() for x in eng.differentiate(torch.from_numpy(q[:m]), torch.from_numpy(qd[:m]), fr)]
+        wd = O.differentiate(desc, q[:m], qd[:m], fr)
+        scale = 1.0 + float(np.abs(qd[:m]).max()) ** 2
+        dd = [float(np.abs(a - b).max()) for a, b in zip(gd, wd)]
+        zeros_differ = bool(((gd[2][:, [3, 7, 11]] == 0).all(axis=(0, 1)) != (wd[2][:, [3, 7, 11]] == 0).all(axis=(0, 1))).any())
+        what["entry_points"] = dict(frame=fr, T=dT, x=dd[0], xd=dd[1], J=dd[2], c=dd[3])
+        if dT > 5e-6 or dd[0] > 5e-6 or dd[1] > 5e-6 * scale or dd[2] > 5e-6 or dd[3] > 2e-5 * scale or zeros_differ:
+            entry_problem = f"kinematics entry points: {what['entry_points']}, zero columns differ: {zeros_differ}"
     rollout_problem, rollout_first = None, None
     if ("p_link" not in eng_kw) and rng.random() < 0.25:
         # the fused rollout (rmp2_rollout): K control steps in one launch must equal K launches of one control step each BIT FOR BIT
@@ -419,6 +435,8 @@ def run_case(seed, torch, verbose=False):
     flagged = (stc & D.STATUS_NONFINITE) != 0 if hasattr(D, "STATUS_NONFINITE") else (stc & 1) != 0
     if rollout_problem:
         problems.append(rollout_problem)
+    if entry_problem:
+        problems.append(entry_problem)
     if (nonfinite_ref & ~nonfinite_got & ~finite_where_oracle_nan).any():       # (the gate's both_nan branch covers the converse)
         problems.append(f"{int((nonfinite_ref & ~nonfinite_got & ~finite_where_oracle_nan).sum())} robot(s) the oracle resolves to NaN came back finite")
     if (nonfinite_got & ~flagged).any():
