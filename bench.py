@@ -81,16 +81,32 @@ def host_cores() -> int:
 
 
 def lscpu_summary() -> str:
+    """What `lscpu` prints about the host, read from /proc/cpuinfo -- NO child process: this runs in a process that may hold a
+    HIP context, and such a process must not fork + exec on this pool (count_gpus_without_hip).  main() also calls it once
+    before anything can touch a GPU and keeps the string (HOST_SUMMARY)."""
     try:
-        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
-        keep = {}
-        for line in txt.splitlines():
+        model, sockets, cores_per_socket, siblings, cpus = "", set(), 0, 0, 0
+        for line in open("/proc/cpuinfo"):
             k, _, v = line.partition(":")
-            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
-                keep[k.strip()] = v.strip()
-        return "; ".join(f"{k}={v}" for k, v in keep.items())
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpus += 1
+            elif k == "model name" and not model:
+                model = v
+            elif k == "physical id":
+                sockets.add(v)
+            elif k == "cpu cores":
+                cores_per_socket = int(v)
+            elif k == "siblings":
+                siblings = int(v)
+        tpc = max(1, siblings // cores_per_socket) if cores_per_socket else 1
+        return (f"Model name={model}; Socket(s)={max(len(sockets), 1)}; Core(s) per socket={cores_per_socket}; "
+                f"Thread(s) per core={tpc}; CPU(s)={cpus}")
     except Exception:
-        return "lscpu unavailable"
+        return "/proc/cpuinfo unavailable"
+
+
+HOST_SUMMARY = None   # filled by main() before any HIP initialisation
 
 
 def cpu_baseline(workload: str, desc, table, s, spheres):
@@ -127,7 +143,7 @@ def cpu_baseline(workload: str, desc, table, s, spheres):
            "sample": f"{itN} steps of {R} robots, oracle/rmp2_oracle.c (gcc -O3 -march=native, OpenMP {cores} threads), {dtN:.1f} s",
            "threads_1": {"value": v1, "cores": 1,
                          "sample": f"{it1} steps of {min(R, 512)} robots, same C restatement, 1 thread, {dt1:.1f} s"},
-           "host": lscpu_summary() + f"; usable by this process: {cores}"}
+           "host": (HOST_SUMMARY or lscpu_summary()) + f"; usable by this process: {cores}"}
     try:
         import torch_autodiff_oracle as TA
         from riemannian_motion_policies_amd import configs as Cf, descriptor as D
@@ -321,7 +337,7 @@ class Timed:
                     host_issue_ms_per_step=t_host / steps * 1e3)
 
 
-def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs, workload, R, bound="valu"):
+def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs, workload, R, bound="valu", exe=None):
     """Top level = the BINDING roof of the dominant kernel (`bound`); the other roof is nested.  `achieved` is ALGORITHMIC
     work per second of kernel time: for the flop count that is the UN-CULLED count of SURVEY 8(d)
     (all 256 pairs of a robot), which the culling kernel does not execute -- `executed` says what the silicon did."""
@@ -344,10 +360,48 @@ def roofline_obj(kernel, kern, per_launch_bytes, per_launch_flops, bytes_rs, flo
            "hbm" if bound == "valu" else "valu": hbm if bound == "valu" else valu,
            "binding": ("fp32 VALU issue: 120 B per robot-step cannot load HBM (DESIGN.md section 5)" if bound == "valu" else
                        "HBM: the explicit closest-point pairs are 24 B each, read once per step")}
+    if exe is not None:
+        # beside the algorithmic fraction: the work the culling kernel cannot avoid on this fleet, against the same peak
+        out["executed_flops_per_robot_step"] = exe["flops_per_robot_step"]
+        out["executed_frac"] = exe["flops_per_robot_step"] * R / (kern["kernel_ms"] * 1e-3) / VALU_PEAK
+        out["executed_flops"] = exe
     ex = executed_of(workload, R)
     if ex is not None:
         out["executed"] = ex
     return out
+
+
+CULL_TEST_FLOPS = 7.0     # per (control point, primitive) range test: 3 FMAs + a compare (rmp2_quad.h pair_loop_culled, pass 1)
+
+
+def executed_flops(eng, desc, q, spheres_np, workload):
+    """What the culling kernel has to EXECUTE per robot-step on THIS fleet, counted from the inputs (outside the timed region, on
+    the device through the library's own forward kinematics -- nothing stored, nothing to go stale): the non-pair part of SURVEY
+    8(d)'s count (everything but 256 x 240), 240 flops for every pair that is IN RANGE of its leaf's metric
+    (x - margin <= metric_modulation_radius: beyond it rmp2.py:191-195 makes the metric exactly 0 and the kernel skips the
+    pair) and a range test for every pair.  Sphere tables only (config 3 / 4): returns None elsewhere."""
+    import numpy as np
+    import torch
+    from riemannian_motion_policies_amd import descriptor as D
+    if spheres_np is None or spheres_np.shape[1] != 4 or workload not in ("config3", "config4"):
+        return None
+    dl = D.distance_leaf_indices(desc)
+    frames = [desc.leaves[i].frame for i in dl]
+    margin, radius = float(desc.leaves[dl[0]].params[0]), float(desc.leaves[dl[0]].params[7])
+    sph = torch.from_numpy(spheres_np).to(q.device)
+    n_in = 0
+    for lo in range(0, q.shape[0], 8192):
+        T = eng.forward_kinematics(q[lo:lo + 8192])
+        p = T[:, frames, :3, 3]                                           # [r, C, 3]
+        x = (p[:, :, None, :] - sph[None, None, :, :3]).norm(dim=-1) - sph[None, None, :, 3] - margin
+        n_in += int((x <= radius).sum().item())
+    pairs = len(frames) * spheres_np.shape[0]
+    in_range = n_in / q.shape[0]
+    non_pair = WORKLOADS["config3"]["flops"] - pairs * PAIR_FLOPS
+    return {"pairs_per_robot": pairs, "in_range_pairs_per_robot_step": in_range, "in_range_pair_fraction": in_range / pairs,
+            "non_pair_flops": non_pair, "cull_test_flops_per_pair": CULL_TEST_FLOPS,
+            "flops_per_robot_step": non_pair + in_range * PAIR_FLOPS + pairs * CULL_TEST_FLOPS,
+            "how": "counted from this run's inputs (all robots of the fleet, library FK + torch on the device, outside the timed region)"}
 
 
 def _stored(name):
@@ -491,6 +545,44 @@ def build_config34(workload, args, dev, local_rank, rank, world, R, seed_rank=No
         exch.consumed(attached=True)
     keep += [exch, local, bound]
     return one_step, eng, desc, table, s, spheres_np, keep
+
+
+def world1_leg(args, dev, local_rank, rank, world, R, timer):
+    """The like-for-like base of a weak-scaling figure: the SAME workload (config 4: this rank's 65 536 robots, the whole sphere
+    table gathered through an exchange every step) with a communicator of ONE rank -- every rank times its own shard with a
+    world-1 exchange of its own, at the same moment, after the N-rank timed region; the line carries the MAX over ranks
+    (`ms_per_step` of the N-rank job divided by this is the weak-scaling efficiency, whatever the driver compares N = 1 with).
+    Never a reason to lose the line: any failure is reported as null with the reason."""
+    import torch
+    import torch.distributed as dist
+    info = {"what": "config 4 at world 1 on every rank's own shard (own one-rank RCCL communicator), MAX over ranks",
+            "exchange": args.exchange, "steps": min(args.steps, 500)}
+    ms, err = float("nan"), None
+    try:
+        exch1 = None
+        if args.exchange == "native":
+            from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
+            from riemannian_motion_policies_amd import configs as Cf
+            exch1 = NativeObstacleExchange(Cf.N_SPHERES, dev, depth=args.exchange_depth, rank=0, world=1,
+                                           uid=NativeObstacleExchange.unique_id())
+        import copy
+        a1 = copy.copy(args)
+        one_step, eng1, *_rest = build_config34("config4", a1, dev, local_rank, 0, 1, R, seed_rank=rank, exch=exch1)
+        k1 = Timed(dev, False).run(one_step, min(args.steps, 500), min(args.warmup, 50))
+        ms = k1["dt"] / min(args.steps, 500) * 1e3
+        info["kernel"] = eng1.last_kernel()
+        del one_step, eng1, _rest
+    except Exception as e:   # noqa: BLE001
+        err = repr(e)
+    t = torch.tensor([ms if err is None else float("inf")], dtype=torch.float64, device=dev)
+    if timer.use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    v = float(t.item())
+    if err is not None or v == float("inf"):
+        info["error"] = err or "another rank failed"
+        return None, info
+    info["this_rank_ms"] = ms
+    return v, info
 
 
 TOLERANCE_RULE = ("every checked robot must pass one of: (A) |qdd - oracle|_inf <= 1e-5 * max(1, |oracle|_inf) [north star]; "
@@ -734,8 +826,12 @@ def worker(args) -> int:
             line_extra["rccl_nranks"] = int(ex.nranks) if args.exchange == "native" else (
                 None if args.rehearse_one_gpu else int(dist.get_world_size()))     # (a rehearsal's process group is gloo's)
             line_extra["exchange_depth"] = int(args.exchange_depth) if args.exchange == "native" else 1
+        if workload == "config4" and world > 1:
+            line_extra["world1_same_workload_ms"], line_extra["world1_same_workload"] = world1_leg(
+                args, dev, local_rank, rank, world, R, timer)
         bytes_rs, flops_rs = wl["bytes"], wl["flops"]
         per_launch_bytes, per_launch_flops = bytes_rs * R, flops_rs * R
+        exe = executed_flops(eng, desc, keep[0], spheres_np, workload)
         kernel_name = eng.last_kernel() + " (chosen by fleet size, rmp2_hip.hip dispatch_solve)"
         total_robots = R * world
         bound = wl.get("bound", "valu")
@@ -764,6 +860,7 @@ def worker(args) -> int:
         # step, profiles/r03_config5_graph_ab.txt: its cross-stream edges become full barriers -- so eager is the default)
         line_extra["step_issue"] = "hip graph replay" if (args.graph and shard.capture()) else "eager (<= 6 host calls)"
         one_step = shard.step
+        exe = None
         kern = timer.run(one_step, args.steps, args.warmup)
         # the dominant kernel (the Panda engine's) timed on its own right after the timed region, same buffers
         kk = Timed(dev, False).run(shard.step_dominant, min(args.steps, 200), 10)
@@ -821,7 +918,7 @@ def worker(args) -> int:
             "config": {"workload": wl["name"], "workload_key": workload, "robots_per_gpu": R, "solve": args.solve,
                        "parallelism": parallelism},
             "roofline": roofline_obj(kernel_name, kern, per_launch_bytes, per_launch_flops, bytes_rs, flops_rs,
-                                     "config3" if workload == "config4" else workload, R, bound),
+                                     "config3" if workload == "config4" else workload, R, bound, exe),
         }
         line.update(line_extra)
         if args.rehearse_one_gpu:
@@ -846,22 +943,25 @@ def worker(args) -> int:
                 "roofline": roofline_obj(eng2.last_kernel(), k2, w2["bytes"] * 4096, w2["flops"] * 4096, w2["bytes"], w2["flops"],
                                          "config2", 4096, "valu"),
                 "note": "latency regime: 1024 waves on 1024 SIMDs, ~3 us of the launch is dispatch floor (DESIGN.md section 5)"}
-        if workload == "config3" and args.solve == "auto" and not args.no_secondary:
-            # the same workload under the reference's ONLY resolve (solve = "pinv", rmp.py:153-154), same process, same inputs:
-            # one certifying launch -- what reference semantics cost over the line's solve = "auto"
-            _, dp = Cf.config3("pinv")
+        if workload == "config3" and not args.no_secondary:
+            # the same workload under the OTHER resolve, same process, same inputs.  The line's `value` is on solve = "pinv", the
+            # reference's only resolve (rmp.py:153-154: one certifying launch); "auto" (plain elimination,
+            # pseudo-inverse for flagged robots only) rides along so that what reference semantics cost stays visible
+            other = "auto" if args.solve == "pinv" else "pinv"
+            _, dp = Cf.config3(other)
             engp = Engine(dp, local_rank)
             qp, qdp, gp = keep[0], keep[1], keep[2]
             op = torch.empty_like(qp)
             launchp, _ = engp.bind(qp, qdp, gp, obstacles=engp.obstacles(spheres=torch.from_numpy(spheres_np).to(dev)), out=op)
             kp = Timed(dev, False).run(launchp, min(args.steps, 1000), min(args.warmup, 100))
             torch.cuda.synchronize(dev)
-            line["solve_pinv"] = {
-                "workload": wl["name"] + ', solve = "pinv" (the reference\'s resolve)', "robots": R,
+            line["solve_" + other] = {
+                "workload": wl["name"] + f', solve = "{other}"', "robots": R,
                 "ms_per_step": kp["dt"] / min(args.steps, 1000) * 1e3, "value": R * min(args.steps, 1000) / kp["dt"],
-                "unit": "robot control steps/s", "kernel": engp.last_kernel(),
-                "max_abs_diff_to_auto": float((op - keep[3]).abs().nan_to_num(0.0).max().item()),
-                "note": "full rank certified per robot inside the elimination (pinv = inv there), Jacobi pseudo-inverse for the rest"}
+                "unit": "robot control steps/s", "kernel": engp.last_kernel(), "kernel_ms": kp["kernel_ms"],
+                "max_abs_diff_to_" + args.solve: float((op - keep[3]).abs().nan_to_num(0.0).max().item()),
+                "note": ("plain elimination; the pseudo-inverse only for robots the elimination flags" if other == "auto" else
+                         "full rank certified per robot inside the elimination (pinv = inv there), Jacobi pseudo-inverse for the rest")}
         if not args.no_cpu_baseline and world == 1 and desc is not None:
             line["cpu_baseline"] = cpu_baseline(workload, desc, table, s, spheres_np)
         print(json.dumps(line), flush=True)
@@ -871,6 +971,21 @@ def worker(args) -> int:
     return rc
 
 
+def preflight():
+    """Everything that may start a child process or read the host, done BEFORE this process can hold a HIP context (a process
+    with one must not fork + exec on this pool): the host summary, the library build (hipcc, only when the sources changed;
+    rank 0 of a launcher, or the lone process) and the checker's library (oracle/: `make`, only when stale -- loading the
+    checker here is not using it; it is called after the timed region, in check_against_oracle / cpu_baseline)."""
+    global HOST_SUMMARY
+    HOST_SUMMARY = lscpu_summary()
+    if os.environ.get("RANK", "0") == "0":
+        import __graft_entry__ as ge
+        ge.build_hip()
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        O.lib()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -878,7 +993,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--robots", type=int, default=0, help="robots per GPU (default: the workload's)")
-    ap.add_argument("--solve", default="auto", choices=["auto", "pinv"])
+    ap.add_argument("--solve", default="pinv", choices=["auto", "pinv"],
+                    help='pinv (default): the reference\'s only resolve, tf.linalg.pinv(M) f (rmp.py:153-154); auto: elimination with '
+                         'the pseudo-inverse kept for flagged robots -- rides along as the nested "solve_auto" leg of the default line')
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="config4 / config5 on ONE GPU: build and time each of the N rank shards in turn, report per-rank "
                          "times and the predicted N-GPU throughput (clearly labelled as an emulation)")
@@ -909,6 +1026,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    preflight()
     sys.exit(worker(args))
 
 
