@@ -10,8 +10,12 @@ is a *descriptor*: `chain_taskmaps([...])` records the stages and the RMP-set co
     [FK(frame), TaskmapJointFrame4x4ToDistance(...)]  -> RMP2_TASKMAP_FK_DISTANCE
 
 whose (x, xd, J, c) the HIP kernels compute analytically in one pass over the kinematic tree.
-`forward` / `differentiate` stay callable for the FK-only and FK->position chains and run on
-the GPU (rmp2_forward_kinematics / rmp2_differentiate); there is no CPU path.
+`forward` / `differentiate` stay callable for the FK-only, FK->position and FK->Euler chains and run on
+the GPU (rmp2_forward_kinematics / rmp2_differentiate / rmp2_differentiate_euler); there is no CPU path for
+those.  `TaskmapByFunction(forward_fn, differentiate_fn)` has the reference's signature (taskmap.py:33-42): a map
+made of two closures chains with the others through the reference's chain rule (host arithmetic on whatever the
+closures return), and one whose closures are exactly `fkine.forward` / `fkine.differentiate` of a frame compiles
+like TaskmapByForwardKinematic.
 """
 from __future__ import annotations
 
@@ -69,6 +73,9 @@ class TaskmapFrom4x4ToPosition(Taskmap):
         T = np.asarray(input, dtype=np.float32).reshape(-1, 4, 4)
         return T[:, :3, 3]
 
+    def differentiate(self, q, qd):
+        return _selector_differentiate(self.ROWS, np.reshape(_host(q), (-1, 16)), np.reshape(_host(qd), (-1, 16)))
+
 
 class TaskmapFrom4x4ToEuler(Taskmap):
     """vec(T) -> (theta_x, theta_y, theta_z) with R = Rz Ry Rx (taskmap.py:57-67, euler_from_rotation_matrix
@@ -85,6 +92,35 @@ class TaskmapFrom4x4ToEuler(Taskmap):
         tz = np.arctan2(r10 / safe, r00 / safe)
         tx = np.arctan2(r21 / safe, r22 / safe)
         return np.stack((tx, ty, tz), axis=-1).astype(np.float32)
+
+    def differentiate(self, q, qd):
+        """(x, xd, J, c) of the 16 -> 3 map itself (what rmp_differentiate gives the reference, taskmap.py:62-67), closed form
+        on the host: J2 [B,3,16], c2 = xd^T (Hessian) xd.  Only what a chain behind a HAND-MADE FK map needs (the chain behind
+        TaskmapByForwardKinematic runs on the GPU: rmp2_differentiate_euler).  atan2(y / s, x / s) does not depend on s, so the
+        gimbal guard's `safe` carries no derivative."""
+        x = np.reshape(_host(q), (-1, 16)).astype(np.float64)
+        xd = np.reshape(_host(qd), (-1, 16)).astype(np.float64)
+        B = x.shape[0]
+        J = np.zeros((B, 3, 16))
+        c = np.zeros((B, 3))
+        r00, r10, r20, r21, r22 = x[:, 0], x[:, 4], x[:, 8], x[:, 9], x[:, 10]
+
+        def atan2_terms(yi, xi):
+            y, xx, yd, xxd = x[:, yi], x[:, xi], xd[:, yi], xd[:, xi]
+            rho = xx * xx + y * y
+            gy, gx = xx / rho, -y / rho
+            curv = (2 * xx * y / rho ** 2) * (xxd * xxd - yd * yd) + 2 * xxd * yd * (y * y - xx * xx) / rho ** 2
+            return gy, gx, curv
+
+        gy, gx, cx = atan2_terms(9, 10)      # theta_x = atan2(r21, r22)
+        J[:, 0, 9], J[:, 0, 10], c[:, 0] = gy, gx, cx
+        one = 1.0 - r20 * r20
+        J[:, 1, 8] = -1.0 / np.sqrt(one)     # theta_y = -asin(r20)
+        c[:, 1] = -r20 / one ** 1.5 * xd[:, 8] ** 2
+        gy, gx, cz = atan2_terms(4, 0)       # theta_z = atan2(r10, r00)
+        J[:, 2, 4], J[:, 2, 0], c[:, 2] = gy, gx, cz
+        out = self.forward(x.astype(np.float32))
+        return out, np.einsum("bkm,bm->bk", J, xd).astype(np.float32), J.astype(np.float32), c.astype(np.float32)
 
 
 class TaskmapFrom4x4ToQuaternions(Taskmap):
@@ -138,39 +174,149 @@ class TaskmapSphereDistance(Taskmap):
 
 
 class TaskmapByFunction(Taskmap):
-    """Result of chain_taskmaps (taskmap.py:33-42): keeps the stage list."""
+    """A task map given by two closures, with the reference's constructor (taskmap.py:33-42;
+    tests/test_taskmaps.py:33-36 builds one over `fkine.forward` / `fkine.differentiate`):
 
-    def __init__(self, stage_list):
-        self._stages = list(stage_list)
+        TaskmapByFunction(forward_fn=lambda q: fkine.forward(q, frame=name),
+                          differentiate_fn=lambda q, qd: fkine.differentiate(q, qd, frame=name))
 
-    def stages(self):
-        return self._stages
+    `.forward` / `.differentiate` call the closures, and the object chains with the other maps through the reference's chain
+    rule (`chain_taskmaps`: J = J2 J1, xd = J2 xd1, c = c2 + J2 c1, taskmap.py:150-160).  `chain_taskmaps` itself returns
+    one of these, as in the reference; the ones it builds also carry the list of stages they were made of, which is what the
+    RMP-set compiler reads.  A hand-made one has no stage list: `stages()` then finds out what the closures do by CALLING
+    them once with a recording stand-in for the kinematics' methods -- a pair of closures that hands `q` (and `qd`) to ONE
+    `UrdfForwardKinematic`'s forward / differentiate with the same frame and returns the result untouched is the map
+    TaskmapByForwardKinematic(fkine, frame) and compiles to the kernels' built-in FK map; anything else has no kernel and
+    RmpCore says which spellings have."""
+
+    def __init__(self, forward_fn, differentiate_fn):
+        self.forward_fn = forward_fn
+        self.differentiate_fn = differentiate_fn
+        self._stages = None
 
     def forward(self, q):
-        out = q
-        for s in self._stages:
-            out = s.forward(out)
-        return out
+        return self.forward_fn(q)
 
     def differentiate(self, q, qd):
-        st = self.stages()
-        if len(st) == 2 and isinstance(st[0], TaskmapByForwardKinematic) and isinstance(st[1], TaskmapFrom4x4ToEuler):
-            return st[0].fkine.differentiate_euler(q, qd, st[0].frame)
-        kind, fk = classify(self)[:2]
-        if kind == D.TASKMAP_FK_POSITION:
-            x, xd, J, c = fk.differentiate(q, qd)
-            rows = list(TaskmapFrom4x4ToPosition.ROWS)
-            return x[:, rows], xd[:, rows], J[:, rows, :], c[:, rows]
-        raise NotImplementedError("differentiate() is offered for FK, FK->position and FK->Euler chains; "
-                                  "distance chains are differentiated inside RmpCore.evaluate")
+        return self.differentiate_fn(q, qd)
+
+    def stages(self):
+        if self._stages is not None:
+            return self._stages
+        fk = _recognise_fk_closures(self.forward_fn, self.differentiate_fn)
+        if fk is None:
+            return [self]          # opaque: classify() refuses it with the supported spellings
+        last = getattr(self, "_recognised", None)
+        if last is not None and last.fkine is fk.fkine and last.frame == fk.frame:
+            return [last]          # (the same stage object as long as the closures mean the same map: RmpCore's quick signature)
+        self._recognised = fk
+        return [fk]
+
+
+def _closure_values(fn):
+    import inspect
+    try:
+        cv = inspect.getclosurevars(fn)
+    except TypeError:
+        return []
+    return list(cv.nonlocals.values()) + list(cv.globals.values())
+
+
+def _recognise_fk_closures(forward_fn, differentiate_fn):
+    """TaskmapByForwardKinematic(fkine, frame) if the two closures are exactly `fkine.forward(q, frame)` and
+    `fkine.differentiate(q, qd, frame)` of one UrdfForwardKinematic -- decided by running them once against recording
+    stand-ins (instance attributes shadowing the methods for the duration of the call): each must call its method exactly once,
+    with the probe arrays it was given, and return the stand-in's result object itself.  The frame is read at this moment (a
+    closure over a loop variable sees the variable's current value -- the reference would read it at every evaluate)."""
+    from .kinematics import UrdfForwardKinematic
+    cands = []
+    for v in _closure_values(forward_fn) + _closure_values(differentiate_fn):
+        if isinstance(v, UrdfForwardKinematic) and all(v is not c for c in cands):
+            cands.append(v)
+    for fk in cands:
+        n = fk.n_joints
+        q_probe, qd_probe = np.zeros((1, n), np.float32), np.zeros((1, n), np.float32)
+        calls = []
+        token_f, token_d = np.zeros((1, 4, 4), np.float32), (object(), object(), object(), object())
+
+        def rec_forward(q, frame=None, _c=calls, **kw):
+            _c.append(("forward", q, frame if frame is not None else kw.get("frame")))
+            return token_f
+
+        def rec_diff(q, qd, frame=None, _c=calls, **kw):
+            _c.append(("differentiate", q, qd, frame if frame is not None else kw.get("frame")))
+            return token_d
+
+        saved = {k: fk.__dict__.get(k) for k in ("forward", "differentiate", "__call__")}
+        fk.forward, fk.differentiate = rec_forward, rec_diff
+        try:
+            try:
+                out_f = forward_fn(q_probe)
+                out_d = differentiate_fn(q_probe, qd_probe)
+            except Exception:
+                continue
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    fk.__dict__.pop(k, None)
+                else:
+                    fk.__dict__[k] = v
+        if (len(calls) == 2 and calls[0][0] == "forward" and calls[1][0] == "differentiate" and out_f is token_f
+                and out_d is token_d and calls[0][1] is q_probe and calls[1][1] is q_probe and calls[1][2] is qd_probe
+                and calls[0][2] is not None and _to_str(calls[0][2]) == _to_str(calls[1][3])
+                and _to_str(calls[0][2]) in fk.frame_names):
+            return TaskmapByForwardKinematic(fk, calls[0][2])
+    return None
+
+
+def _selector_differentiate(rows, x, xd):
+    """A constant row selector as a task map of its own (what rmp_differentiate gives the reference for
+    TaskmapFrom4x4ToPosition, taskmap.py:45-54): x[rows], xd[rows], J = the 0/1 selector, c = 0."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float32))
+    xd = np.atleast_2d(np.asarray(xd, dtype=np.float32))
+    J = np.zeros((x.shape[0], len(rows), x.shape[1]), np.float32)
+    J[:, np.arange(len(rows)), list(rows)] = 1.0
+    return x[:, list(rows)], xd[:, list(rows)], J, np.zeros((x.shape[0], len(rows)), np.float32)
+
+
+def _host(a):
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a)
 
 
 def _chain_taskmaps(taskmap_1, taskmap_2):
-    return TaskmapByFunction(taskmap_1.stages() + taskmap_2.stages())
+    """taskmap.py:142-162.  Known chains keep their kernels (FK -> Euler: rmp2_differentiate_euler; FK -> position: rows of
+    rmp2_differentiate); every other pair goes through the reference's chain rule on the two maps' own differentiate()."""
+    st = taskmap_1.stages() + taskmap_2.stages()
+
+    def combined_forward(q):
+        return taskmap_2.forward(taskmap_1.forward(q))
+
+    def combined_differentiate(q, qd):
+        if len(st) == 2 and isinstance(st[0], TaskmapByForwardKinematic) and isinstance(st[1], TaskmapFrom4x4ToEuler):
+            return st[0].fkine.differentiate_euler(q, qd, st[0].frame)
+        if len(st) == 2 and isinstance(st[0], TaskmapByForwardKinematic) and isinstance(st[1], TaskmapFrom4x4ToPosition):
+            x, xd, J, c = st[0].fkine.differentiate(q, qd, st[0].frame)
+            rows = list(TaskmapFrom4x4ToPosition.ROWS)
+            return x[:, rows], xd[:, rows], J[:, rows, :], c[:, rows]
+        out_1, dout1_dt, J_1, c_1 = (_host(a) for a in taskmap_1.differentiate(q, qd))
+        out_2, _, J_2, c_2 = (_host(a) for a in taskmap_2.differentiate(out_1, dout1_dt))
+        dout_dt = np.einsum("bkm,bm->bk", J_2, np.broadcast_to(dout1_dt, (J_2.shape[0], dout1_dt.shape[-1])))
+        J = J_2 @ J_1
+        c = c_2 + np.einsum("bkm,bm->bk", J_2, np.broadcast_to(c_1, (J_2.shape[0], c_1.shape[-1])))
+        return out_2, dout_dt, J, c
+
+    chained = TaskmapByFunction(combined_forward, combined_differentiate)
+    chained._stages = st
+    return chained
 
 
-def chain_taskmaps(taskmap_list):
-    """taskmap.py:164-168 (one list argument)."""
+def chain_taskmaps(taskmap_list, *more):
+    """taskmap.py:164-168 (one list argument); the reference's own test still calls it with the maps as positional arguments
+    (tests/test_taskmaps.py:39-40), so that form is taken too."""
+    if more or not isinstance(taskmap_list, (list, tuple)):
+        taskmap_list = [taskmap_list, *more]
     chained = taskmap_list[0]
     for tm in taskmap_list[1:]:
         chained = _chain_taskmaps(chained, tm)
@@ -202,4 +348,7 @@ def classify(taskmap):
     names = " -> ".join(type(s).__name__ for s in st)
     raise NotImplementedError(
         f"task-map chain [{names}] has no kernel; supported: IdentityTaskmap, "
-        "[FK, 4x4->position], [FK, 4x4->distance], [FK, relative 4x4, 4x4->position] (SURVEY 8(b))")
+        "[FK, 4x4->position], [FK, 4x4->distance], [FK, relative 4x4, 4x4->position] (SURVEY 8(b)), where FK is "
+        "TaskmapByForwardKinematic(fkine, frame) or TaskmapByFunction(forward_fn=lambda q: fkine.forward(q, frame), "
+        "differentiate_fn=lambda q, qd: fkine.differentiate(q, qd, frame)) -- closures that do anything else to q or to the "
+        "result cannot be compiled (their .forward / .differentiate still work on the host)")
