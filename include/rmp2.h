@@ -303,7 +303,9 @@ int rmp2_exchange_create(const char *rccl_library, const rmp2_rccl_uid *uid, int
 int rmp2_exchange_destroy(rmp2_exchange *x);
 const char *rmp2_exchange_last_error(const rmp2_exchange *x);
 int rmp2_exchange_pending(const rmp2_exchange *x);
-/* Ranks of the communicator this exchange was created on (what ncclCommInitRank was given and joined; 0 for NULL). */
+/* Ranks of the communicator this exchange joined: ncclCommCount of the communicator itself, queried at create time -- which
+ * also REFUSES a communicator whose ncclCommCount / ncclCommUserRank differ from the (rank, nranks) it was asked to join with --;
+ * the `nranks` of the call only where the collective library does not export the two queries; 0 for NULL. */
 int rmp2_exchange_nranks(const rmp2_exchange *x);
 /* Pipeline depth (before the first rmp2_exchange_start): depth + 1 gathers may be outstanding.  1 (default): the table of step
  * k is gathered from slices produced before step k - 1 was issued -- the obstacles a step sees are ONE control step old, as in

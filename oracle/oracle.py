@@ -297,8 +297,10 @@ def accuracy_gate(got, ref, eta: float = 1e-4, atol: float = 1e-5, spread=None, 
     d = np.zeros(len(got), bool)
     if system_spread is not None:
         d = finite & (err_inf <= spread_factor * np.asarray(system_spread))
-    # a robot the oracle itself resolves to NaN (non-finite state): the engine must answer NaN too
-    both_nan = ~np.isfinite(q_ref).all(axis=1) & ~np.isfinite(got).all(axis=1)
+    # a robot the oracle itself resolves to NaN (non-finite state): tf.linalg.pinv of a system holding NaN / Inf is NaN in EVERY
+    # entry (rmp2_oracle.c pinv_solve), so the engine must answer non-finite in every dof too -- one NaN joint beside finite
+    # ones against an all-NaN reference is a different answer, not the same one
+    both_nan = (~np.isfinite(q_ref)).all(axis=1) & (~np.isfinite(got)).all(axis=1)
     return {"a": a, "b": b & ~a, "c": c & ~a & ~b, "d": d & ~a & ~b & ~c, "ok": a | b | c | d | both_nan, "both_nan": both_nan,
             "omega": omega, "cond": cond, "err_inf": err_inf}
 

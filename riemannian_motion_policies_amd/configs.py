@@ -318,7 +318,9 @@ def pairs_from_link_capsules(T: np.ndarray, link_capsules: np.ndarray, table: np
     X = p1 + s[..., None] * d1
     Y = p2 + t[..., None] * d2
     n = X - Y
-    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    nn = np.linalg.norm(n, axis=-1, keepdims=True)
+    # intersecting axes: no common normal -- the fixed direction +z (as the device form, rmp2_device.h link_pair_fields)
+    n = np.where(nn == 0, np.array([0.0, 0.0, 1.0], dtype=n.dtype), n / np.where(nn == 0, 1.0, nn))
     p_link = X - rl[None, :, None, None] * n
     p_obs = Y + ro[None, None, :, None] * n
     return p_link.reshape(R, Cn * K, 3).astype(np.float32), p_obs.reshape(R, Cn * K, 3).astype(np.float32)

@@ -459,7 +459,13 @@ __device__ __forceinline__ void link_pair_fields(const float LA[3], const float 
   for (int c = 0; c < 3; ++c) X[c] = fmaf(sl, LD[c], LA[c]);
   diff[0] = X[0] - fmaf(to, d2v[0], ca.x), diff[1] = X[1] - fmaf(to, d2v[1], ca.y), diff[2] = X[2] - fmaf(to, d2v[2], ca.z);
   const float dn = sqrtf(dot3(diff, diff));
-  const float inv0 = 1.0f / dn;
+  // the axes INTERSECT (a sphere centred on the link's axis, two crossing segments): there is no common normal.  The shapes
+  // overlap by the sum of their radii whatever direction is taken; a fixed one (+z, as configs.pairs_from_link_capsules) keeps the
+  // fields finite and the same on every evaluation -- 1 / 0 would make normal and lever arm NaN (round-4 advisor finding).  A NaN
+  // distance is not this case (dn == 0 is false for it) and propagates as before.
+  const bool crossing = dn == 0.f;
+  diff[2] = crossing ? 1.f : diff[2];
+  const float inv0 = crossing ? 1.f : 1.0f / dn;
   const float sgap = dn - ca.w - lrad;
   dd = fabsf(sgap);
   const float inv = copysignf(inv0, sgap);

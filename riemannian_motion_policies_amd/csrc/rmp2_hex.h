@@ -976,15 +976,6 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // (rmp2_quad.h, same place; tools/fuzz_parity.py seed 504944)
   if (s < N) fv = (fabsf(my_qd[s]) < 3.0e38f) ? fv : (double)__builtin_nanf("");
 
-  // optional outputs: the combined metric / force before the resolve
-  if (live && s < n_dof) {
-    if (out.M) {
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        if (j < n_dof) out.M[((size_t)robot * n_dof + s) * n_dof + j] = A[j];
-    }
-    if (out.f) out.f[(size_t)robot * n_dof + s] = fv;
-  }
   // padding dofs of the template: identity rows so that they resolve to qdd = 0
 #pragma unroll
   for (int j = 0; j < N; ++j)
@@ -995,6 +986,33 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
 #pragma unroll
     for (int j = 0; j < N; ++j) SYS[s * (N + 1) + j] = A[j];
     SYS[s * (N + 1) + N] = fv;
+  }
+  if (hdr.strict == 3) {  // (wave-uniform) solve = PINV on a symmetric set, certified from the LDL^T form
+    // This mapping accumulates FULL rows: A[s][j] = (S c_s) . c_j and A[j][s] = (S c_j) . c_s are rounded independently, equal
+    // only to ~1e-7 |M| -- while the symmetric certificate below bounds sigma_min of M = U^T D^-1 U, i.e. it assumes the matrix it
+    // eliminates IS symmetric (round-4 advisor finding: the slack of that assumption, 1e-7 sigma_max, is far above the
+    // certificate's margin).  The upper triangle is the matrix (as in the quad mapping's symmetric form): every lane takes the
+    // part of its row left of the diagonal from the other lanes' parked rows, and the parked (and exported) system is the
+    // symmetric one the elimination then factors.
+    hex_sync();
+    if (s < N) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[j] = (j < s) ? SYS[j * (N + 1) + s] : A[j];
+    }
+    hex_sync();  // every lane has read the rows above its own before they are rewritten
+    if (s < N) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) SYS[s * (N + 1) + j] = A[j];
+    }
+  }
+  // optional outputs: the combined metric / force before the resolve
+  if (live && s < n_dof) {
+    if (out.M) {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (j < n_dof) out.M[((size_t)robot * n_dof + s) * n_dof + j] = A[j];
+    }
+    if (out.f) out.f[(size_t)robot * n_dof + s] = fv;
   }
 
   // ---- resolve: Gauss-Jordan in fp64 without row exchanges, one row per lane ------------------------------

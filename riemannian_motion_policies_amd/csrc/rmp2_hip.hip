@@ -2054,6 +2054,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, rmp2_rccl_uid, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;      // optional: what the communicator itself says about its size and this rank
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
@@ -2067,6 +2069,8 @@ int load_rccl(const char* path, RcclApi& api, std::string& err) {
   api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+  api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy)
     return err = std::string(path) + " does not export the RCCL entry points", RMP2_ERR_HIP;
   return RMP2_OK;
@@ -2078,6 +2082,7 @@ struct rmp2_exchange {
   RcclApi api;
   void* comm = nullptr;
   int device = 0, rank = 0, world = 1, per_rank = 0;
+  int comm_count = 0, comm_rank = -1;              // ncclCommCount / ncclCommUserRank of the communicator that formed (0 / -1: not exported)
   int depth = 1;                                   // gathers that may be outstanding minus one ... see rmp2_exchange_set_depth
   int nbuf = kBuf;                                 // table buffers in rotation: all kBuf; depth + 1 with RMP2_EXCHANGE_BUFFERS=2 (A/B)
   bool all_buffers = true;
@@ -2140,6 +2145,15 @@ int rmp2_exchange_create(const char* rccl_library, const rmp2_rccl_uid* uid, int
   if (rc == RMP2_OK) {
     const int r = x->api.CommInitRank(&x->comm, nranks, *uid, rank);
     if (r != 0) rc = RMP2_ERR_HIP, err = std::string("ncclCommInitRank: ") + (x->api.GetErrorString ? x->api.GetErrorString(r) : "?");
+  }
+  if (rc == RMP2_OK && x->api.CommCount && x->api.CommUserRank) {
+    // the communicator's own word on its size and this rank: the table is laid out for `nranks` slices, so one that formed with
+    // another size (or put this rank elsewhere) would gather into the wrong offsets -- refuse it here, not in the first step
+    if (x->api.CommCount(x->comm, &x->comm_count) != 0 || x->api.CommUserRank(x->comm, &x->comm_rank) != 0)
+      x->comm_count = 0, x->comm_rank = -1;
+    else if (x->comm_count != nranks || x->comm_rank != rank)
+      rc = RMP2_ERR_HIP, err = "the communicator formed with " + std::to_string(x->comm_count) + " rank(s), this one as rank " +
+                               std::to_string(x->comm_rank) + "; asked for rank " + std::to_string(rank) + " of " + std::to_string(nranks);
   }
   if (rc != RMP2_OK) {
     rmp2_exchange_destroy(x);
@@ -2269,7 +2283,9 @@ int rmp2_exchange_step(rmp2_exchange* x, rmp2_handle* h, const float* q, const f
   return RMP2_OK;
 }
 
-int rmp2_exchange_nranks(const rmp2_exchange* x) { return x ? x->world : 0; }
+// ncclCommCount of the communicator the exchange joined (queried once, at create); the `nranks` it was created with only where the
+// collective library does not export the query.
+int rmp2_exchange_nranks(const rmp2_exchange* x) { return !x ? 0 : (x->comm_count > 0 ? x->comm_count : x->world); }
 
 // Two engines, one launch (include/rmp2.h): the fused grid when an instantiation exists for the pair, else two launches.
 int rmp2_step_pair(rmp2_handle* ha, const float* qa, const float* qda, const float* goala, int32_t gsa,

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -138,6 +139,23 @@ int ncclCommDestroy(void* comm) {
       if (it->second == g) { g_groups.erase(it); break; }
     delete g;
   }
+  return 0;
+}
+
+int ncclCommCount(void* comm, int* count) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c || !count) return 4;
+  // test hook: STUB_RCCL_LIE_ABOUT_COUNT=1 makes the communicator report one rank more than it has (a communicator that formed
+  // with another size than the caller asked for must be refused by rmp2_exchange_create)
+  const char* lie = std::getenv("STUB_RCCL_LIE_ABOUT_COUNT");
+  *count = c->g->nranks + ((lie && lie[0] == '1') ? 1 : 0);
+  return 0;
+}
+
+int ncclCommUserRank(void* comm, int* rank) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c || !rank) return 4;
+  *rank = c->rank;
   return 0;
 }
 

@@ -130,13 +130,25 @@ def test_step_with_all_buffers_outstanding_launches_before_it_gathers(hip_lib, g
     q, qd, goal = (torch.from_numpy(np.tile(g[k], (reps, 1))).to(dev) for k in ("q", "qd", "goal"))
     out = torch.empty_like(q)
     n = g["q"].shape[0]
-    for depth in (1, 2):
+    # (buffers in rotation, depth): with three buffers only depth 2 has every buffer outstanding (x->next == b: the gather goes out
+    # AFTER the launch); with RMP2_EXCHANGE_BUFFERS=2 -- the documented A/B knob: depth + 1 buffers -- depth 1 takes that branch too
+    # (round-4 advisor: the knob's modulo was never run).  The variable is read in rmp2_exchange_create.
+    for buffers, depth in (("3", 1), ("3", 2), ("2", 1)):
         steps = 8
         ahead = depth + 1
         tables = _tables(g, steps + ahead)
         dev_tables = [torch.from_numpy(t).to(dev) for t in tables]
         bufs = [torch.empty_like(dev_tables[0]) for _ in range(ahead + 1)]
-        exch = NativeObstacleExchange(len(g["spheres"]), dev, depth=depth)
+        saved_env = os.environ.get("RMP2_EXCHANGE_BUFFERS")
+        os.environ["RMP2_EXCHANGE_BUFFERS"] = buffers
+        try:
+            exch = NativeObstacleExchange(len(g["spheres"]), dev, depth=depth)
+        finally:
+            if saved_env is None:
+                os.environ.pop("RMP2_EXCHANGE_BUFFERS", None)
+            else:
+                os.environ["RMP2_EXCHANGE_BUFFERS"] = saved_env
+        seen = []
         for k in range(ahead):
             bufs[k % (ahead + 1)].copy_(dev_tables[k])
             exch.start(bufs[k % (ahead + 1)])
@@ -147,12 +159,35 @@ def test_step_with_all_buffers_outstanding_launches_before_it_gathers(hip_lib, g
             sl.copy_(dev_tables[k + ahead])
             exch.step(eng, q, qd, goal, out, next_local=sl)
             assert exch.pending == depth + 1
+            seen.append(exch._table.value)
             outs.append(torch.stack((out[:n], out[-n:])).clone())   # first and last wave of the grid
         torch.cuda.synchronize(dev)
+        # which rotation ran: the tables the steps read cycle through 3 buffers, or through depth + 1 = 2 under the knob
+        nbuf = 3 if buffers == "3" else depth + 1
+        assert len(set(seen)) == nbuf and all(seen[k] == seen[k % nbuf] for k in range(steps)), (buffers, depth, seen)
         for k in range(steps):
             ref = O.step(desc, g["q"], g["qd"], g["goal"], spheres=tables[k])["qdd64"]
             for part in outs[k].cpu().numpy():
                 err = np.abs(part - ref).max(axis=1)
                 tol = 1e-4 * np.maximum(1.0, np.abs(ref).max(axis=1))
-                assert (err <= tol).all(), f"depth {depth} step {k}: worst {err.max():.3e}"
+                assert (err <= tol).all(), f"buffers {buffers} depth {depth} step {k}: worst {err.max():.3e}"
         exch.close()
+
+
+def test_a_communicator_of_another_size_is_refused(hip_lib, stub_rccl):
+    """rmp2_exchange_nranks is ncclCommCount of the communicator that FORMED, and rmp2_exchange_create refuses one whose size or
+    rank differs from what it was asked to join with (round-4 advisor: the function used to echo its own argument)."""
+    import torch
+    from riemannian_motion_policies_amd import _native
+    from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
+    dev = torch.device("cuda", 0)
+    uid = NativeObstacleExchange.unique_id(stub_rccl)
+    exch = NativeObstacleExchange(4, dev, rank=0, world=1, uid=uid, rccl_library=stub_rccl)
+    assert exch.nranks == 1
+    exch.close()
+    os.environ["STUB_RCCL_LIE_ABOUT_COUNT"] = "1"       # the stand-in's communicator now reports one rank more than it has
+    try:
+        with pytest.raises(_native.Rmp2Error, match="formed with 2 rank"):
+            NativeObstacleExchange(4, dev, rank=0, world=1, uid=NativeObstacleExchange.unique_id(stub_rccl), rccl_library=stub_rccl)
+    finally:
+        os.environ.pop("STUB_RCCL_LIE_ABOUT_COUNT", None)

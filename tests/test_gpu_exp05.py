@@ -321,3 +321,35 @@ def test_attached_point_leaves_roll_out(torch_mod, robot, prim, kernel):
         eng.rollout(torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda(), goal,
                     obstacles=eng.obstacles(p_link=torch.from_numpy(rel), p_obs=torch.from_numpy(nvec), dist=torch.from_numpy(dist)),
                     n_control_steps=2, substeps=sub, dt=dt)
+
+
+@pytest.mark.parametrize("kernel", ["quad", "hex"])
+def test_attached_point_leaf_with_a_sphere_centred_on_the_link_axis(torch_mod, kernel):
+    """Round-4 advisor finding: the nearest points of link axis and primitive coincide (a sphere centred ON the axis) -- there is no
+    common normal, and 1 / |X - Y| made normal and lever arm NaN.  The fields take the fixed direction +z instead: finite, and the
+    same as the explicit arrays built with that convention (configs.pairs_from_link_capsules)."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import descriptor as D
+    from riemannian_motion_policies_amd.engine import Engine
+    table, desc, s, lc, prims = _exp05_case("tj", "spheres", 64)
+    eng = Engine(desc, 0) if kernel == "quad" else _engine(desc, kernel)
+    # robot 0 at q = 0 (its kinematics are exact in fp32: products with 0 and 1): the origin of link_23 -- a zero-length link
+    # capsule -- is (2, 0, 0.075 + 0.05) = (2, 0, 0.125) in fp32, and sphere 0 is centred exactly there
+    s["q"][0] = 0.0
+    prims = prims.copy()
+    prims[0, :3] = [2.0, 0.0, np.float32(0.075) + np.float32(0.05)]
+    assert (lc[2, 0:3] == 0).all() and (lc[2, 4:7] == 0).all() and prims[0, 2] == np.float32(0.125)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    st = torch.zeros(64, dtype=torch.int32, device="cuda")
+    fused = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=torch.from_numpy(prims), link_capsules=torch.from_numpy(lc)), status=st)
+    torch.cuda.synchronize()
+    got = fused.cpu().numpy()
+    assert np.isfinite(got).all() and not (st.cpu().numpy() & D.STATUS_NONFINITE).any()
+    rel, nvec, dist = _point_fields(desc, lc, prims, s["q"])
+    assert np.isfinite(rel).all() and np.isfinite(nvec).all()
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], p_link=rel, p_obs=nvec, dist=dist)
+    # (the fp64 kinematics put the origin at z = 0.1250000037: 3.7e-9 above the sphere's centre -- the same +z the convention takes)
+    assert abs(dist[0, 2 * len(prims)] - (0.075 + 0.12)) < 1e-6 and np.allclose(nvec[0, 2 * len(prims)], [0.0, 0.0, -1.0])
+    verdict = O.accuracy_gate(got, ref)
+    assert (verdict["a"] | verdict["b"]).all(), O.gate_summary(verdict)

@@ -27,13 +27,26 @@ def test_fuzz_slice(hip_lib, seeds):
         sys.path.pop(0)
     outcomes = {"passed": 0, "declined": 0, "failed": 0}
     failures = []
+    weaker = {"undetermined_at_fp32_backward_error_only": 0, "tiny_projection_alone_on_a_dof_componentwise_limit": 0,
+              "poisoned_input_answered_nan_where_the_oracle_stays_finite": 0, "oracle_nan_answered_finite": 0}
+    robots = 0
     for seed in seeds:
         outcome, what = F.run_case(seed, torch)
         outcomes[outcome] += 1
         if outcome == "failed":
             failures.append((seed, what.get("why", "")[:300]))
+        for k in weaker:
+            weaker[k] += int(what.get("gate", {}).get(k, 0))
+        robots += int(what.get("gate", {}).get("robots", 0))
     assert not failures, failures
     assert outcomes["passed"] >= 0.9 * len(seeds), outcomes
+    # the classes that get a weaker bound than the gate's stay what they were when the slices were recorded (round 4's campaign:
+    # ~4e-5 of the robots undetermined at fp32, ~3e-7 in the componentwise-limit class, ~1e-5 poisoned-and-NaN): a kernel
+    # regression that hides in one of them moves these counts by orders of magnitude
+    assert weaker["oracle_nan_answered_finite"] == 0, weaker
+    assert weaker["undetermined_at_fp32_backward_error_only"] <= max(20, 2e-3 * robots), (weaker, robots)
+    assert weaker["tiny_projection_alone_on_a_dof_componentwise_limit"] <= 2, (weaker, robots)
+    assert weaker["poisoned_input_answered_nan_where_the_oracle_stays_finite"] <= 3 * len(seeds), (weaker, robots)
 
 
 def test_fuzz_slice_pair_grid(hip_lib):
