@@ -248,6 +248,9 @@ int rmp2_validate(const rmp2_desc *desc);
  *                                         compaction of the in-range pairs (built and parity-tested in round 4; measured no faster than
  *                                         the register loads -- the mode is bound by the bytes a CU can keep in flight beside the frame
  *                                         records in LDS --, so it is off by default)
+ *   RMP2_EXPLICIT_STREAM = 0 | 1          (rmp2_create) EXPLICIT_PAIRS, plain control step: never / at every throughput grid take the
+ *                                         streamed form (pair phase of all leaf frames before the pull-back, pair arrays by LDS-DMA
+ *                                         through the frame records' LDS, four waves per SIMD); unset: from four waves per SIMD on
  *   RMP2_STRICT_CERTIFY = 0               (rmp2_create) solve = PINV: the Jacobi pseudo-inverse on EVERY robot (two kernels) instead of
  *                                         the certifying one-launch step -- the A/B the equality test of the two is built on
  * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with

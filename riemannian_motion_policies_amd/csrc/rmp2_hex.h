@@ -987,7 +987,8 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     for (int j = 0; j < N; ++j) SYS[s * (N + 1) + j] = A[j];
     SYS[s * (N + 1) + N] = fv;
   }
-  if (hdr.strict == 3) {  // (wave-uniform) solve = PINV on a symmetric set, certified from the LDL^T form
+  if (hdr.strict == 3 || hdr.strict == 5) {  // (wave-uniform) solve = PINV on a symmetric set (3: certified from the LDL^T form;
+                                             //  5: the pseudo-inverse on every robot -- the same stored system, RMP2_STRICT_CERTIFY=0)
     // This mapping accumulates FULL rows: A[s][j] = (S c_s) . c_j and A[j][s] = (S c_j) . c_s are rounded independently, equal
     // only to ~1e-7 |M| -- while the symmetric certificate below bounds sigma_min of M = U^T D^-1 U, i.e. it assumes the matrix it
     // eliminates IS symmetric (round-4 advisor finding: the slack of that assumption, 1e-7 sigma_max, is far above the
@@ -1018,10 +1019,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
   // ---- resolve: Gauss-Jordan in fp64 without row exchanges, one row per lane ------------------------------
   // (certification as lu_solve<N>, rmp2_solve.h: tiny pivot, multiplier growth, non-finite result -> careful path)
   bool flagged = true;
-  // hdr.strict: 0 AUTO; 1 solve = PINV, the pseudo-inverse on every robot (no elimination); 2 / 3 solve = PINV with the
+  // hdr.strict: 0 AUTO; 1 / 5 solve = PINV, the pseudo-inverse on every robot (no elimination; 5: symmetric set); 2 / 3 solve = PINV with the
   // round-4 certificate (3: symmetric set): the elimination's result stands for the robots it certifies as full rank above
   // TensorFlow's cutoff -- pinv = inv there, rmp2_quad.h has the derivation --, the careful path's Jacobi for the rest
-  const bool certify = hdr.strict >= 2;
+  const bool certify = hdr.strict == 2 || hdr.strict == 3;
   if (!hdr.strict || certify) {
     // magnitudes are compared on the HIGH WORD of the doubles (monotone for non-negative values, NaN / Inf on top):
     // integer max at fp32 rate instead of dependent fp64 max chains.  scale = max |M_ij| rounded down to its high word.

@@ -21,7 +21,7 @@ bool launch_hex_w(const rmp2_handle* h, const float* q, const float* qd, const f
   const QuadHdr hdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                     h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0,
                     // 0 AUTO; 1 the pseudo-inverse on every robot; 2 / 3 (symmetric set) the certifying elimination (rmp2_hex.h)
-                    !h->strict ? 0 : (hex_certifies_strict(h) ? (h->symmetric ? 3 : 2) : 1),
+                    !h->strict ? 0 : (hex_certifies_strict(h) ? (h->symmetric ? 3 : 2) : (h->symmetric ? 5 : 1)),
                     /*prio_tail*/ 0, /*skip_resolve*/ 0, /*has_point*/ h->has_point ? 1 : 0, /*rank1*/ h->likely_singular ? 1 : 0};
   const uint4* blob = static_cast<const uint4*>(h->d_hex_blob);
   h->last_kernel = h->strict ? (hex_certifies_strict(h)

@@ -1795,6 +1795,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
 #endif
   if (const char* ce = std::getenv("RMP2_STRICT_CERTIFY")) h->strict_certify = std::atoi(ce) != 0;
   if (const char* ge = std::getenv("RMP2_EXPLICIT_GLDS")) h->explicit_glds = std::atoi(ge) != 0;
+  if (const char* se = std::getenv("RMP2_EXPLICIT_STREAM")) h->explicit_stream = std::atoi(se) != 0 ? 1 : 0;
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // 0 = general form (include/rmp2.h)
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;

@@ -34,6 +34,7 @@ struct rmp2_handle {
   bool strict_certify = true;  // RMP2_STRICT_CERTIFY=0: the Jacobi pseudo-inverse on every robot (A/B)
   bool link_rows_ok = false;   // <= 1 distance leaf per frame: link geometry may take the lean builds (segments formed in the walk)
   bool explicit_glds = false;  // RMP2_EXPLICIT_GLDS=1: explicit pairs streamed half a leaf ahead by LDS-DMA (measured: no gain)
+  int explicit_stream = -1;  // RMP2_EXPLICIT_STREAM=0|1: never / at any throughput grid take the streamed explicit-pair step (A/B; -1: by grid size)
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
   int hex_levels = 0;

@@ -97,6 +97,18 @@ __device__ __forceinline__ float rsq1(float x) {  // 1/sqrt(x), one Newton step 
 }
 __device__ __forceinline__ float rcp0(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
 __device__ __forceinline__ float rsq0(float x) { return __builtin_amdgcn_rsqf(x); }   // 1 ulp
+// |v| and 1 / |v| from d2 = |v|^2 where the norm goes into a CANCELLATION: x = |p - c| - r at millimetre clearances is 1e-3 of |p - c|,
+// so the ~1.5 ulp of d2 * v_rsq_f32(d2) are 1e-4 of x -- and the leaf differentiates exp(-x / 0.01) and 1 / x^2 of it.  One Newton
+// step on the square root (the residual d2 - d0^2 is exact in an fma) brings the norm to the correctly rounded one within a few
+// hundredths of an ulp -- what sqrtf gives the reference.  Measured on the BASELINE perf fleets (profiles/r05_accuracy_survey.txt):
+// the engine's error on near-contact robots was 1.4-1.9x that of an fp32 evaluation with sqrtf at the 90th percentile; three
+// more VALU instructions per in-range pair.  The reciprocal stays the 1-ulp one: it only scales the unit normal.
+__device__ __forceinline__ void norm_and_inverse(float d2, float& d, float& inv) {
+  inv = __builtin_amdgcn_rsqf(d2);
+  const float d0 = d2 * inv;
+  const float e = fmaf(-d0, d0, d2);
+  d = fmaf(0.5f * inv, e, d0);  // (d2 = 0: inv = inf, d0 = NaN -- as d2 * rsq(d2) always was: a point ON the centre has no normal)
+}
 __device__ __forceinline__ float exp1(float x) {  // e^x: v_exp_f32 on a compensated x*log2(e)
   const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
   const float ph = x * L2E_HI;
@@ -248,8 +260,9 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
       }
       const float diff[3] = {P3[0] - ctr[0], P3[1] - ctr[1], P3[2] - ctr[2]};
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
-      const float inv = rsq0(d2);
-      d = d2 * inv - ca.w;
+      float dn, inv;
+      norm_and_inverse(d2, dn, inv);
+      d = dn - ca.w;
 #pragma unroll
       for (int c = 0; c < 3; ++c) nh[c] = diff[c] * inv;
     }
@@ -436,8 +449,9 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
         diff[0] = fmaf(0.5f, a.x, P3[0]), diff[1] = fmaf(0.5f, a.y, P3[1]), diff[2] = fmaf(0.5f, a.z, P3[2]);  // p - c, exactly
       }
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
-      const float inv = rsq0(d2);
-      const float d = d2 * inv - r;
+      float dn, inv;
+      norm_and_inverse(d2, dn, inv);
+      const float d = dn - r;
       const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
       const float xdot = dot3(nh, V3);
       const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
@@ -575,11 +589,12 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
       }
       const float diff[3] = {X[0] - Y[0], X[1] - Y[1], X[2] - Y[2]};
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
-      const float inv0 = rsq0(d2);
+      float dn, inv0;
+      norm_and_inverse(d2, dn, inv0);
       // surface to surface along the axes' common normal.  The explicit form sees the two surface points only:
       // x = |p_link - p_obs| and n = (p_link - p_obs) / x -- for overlapping capsules the points have crossed, the distance
       // reads positive and the normal points the other way (taskmap.py:126-129 on PyBullet's points); same here.
-      const float sgap = d2 * inv0 - r - lr;
+      const float sgap = dn - r - lr;
       const float d = fabsf(sgap);
       const float inv = copysignf(inv0, sgap);
       const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
@@ -1050,6 +1065,21 @@ constexpr int kObsAny = -1;
 // leaf (8 floats per leaf frame): 15.6 KB of LDS per wave for the Panda, ten waves per CU at 168 registers.
 constexpr int kObsSharedLink = 4;
 constexpr int kLinkSeg = 8;  // floats per (robot, leaf frame): A.xyz, -, B.xyz, -
+// OBS = kObsExplicitStream (plain builds, four waves per SIMD): interface B -- explicit closest-point pairs, 6 264 B per robot-step,
+// the one HBM-bound form of the step -- with the PAIR PHASE SEPARATED FROM THE PULL-BACK.  The single-loop form (per leaf frame:
+// pairs, quad sums, Jacobian columns, pull-back into the fp64 system) keeps the whole system and the frame records live through the
+// pair loop: 256 registers and 18 KB of LDS per wave, i.e. two waves per SIMD, and at two waves the step is bound by the latencies
+// two waves cannot cover (round 4: 104.5 us at 65 536 robots = 49 % of the HBM roof; six loader variants, none faster).  Here:
+//   walk            as before; then every lane takes what the later phases need of the frame records into REGISTERS -- the
+//                   (z, o) records of the joints that own its rows (18), and three floats per leaf-bearing frame of [p v a] (27) --
+//   pair phase      and the frame records' LDS becomes the LDS-DMA buffer: the pair arrays stream half a leaf ahead
+//                   (pair_loop_explicit_glds, as the opt-in two-wave form did) while NO fp64 system exists yet; per frame the
+//                   quad's sums S = sum m n n^T, h = sum m (xdd - c) n replace [v a] in the same registers;
+//   pull-back       the sums go back to LDS (the DMA is done), and the frame loop runs as in the table modes minus the pair loops.
+// 128 registers and 9.6 KB of LDS per wave: sixteen waves per CU, every one of them with half a leaf (6 KB) in flight through its
+// pair phase -- the latency-hiding the two-wave form could not buy with any loader.
+constexpr int kObsExplicitStream = 5;
+constexpr int kStreamMaxFrames = 9;  // leaf-bearing frames the streamed form holds in registers (the Panda's cluttered set: 8 + 1)
 // FLAVOR: kGeneral = everything at run time (debug outputs M / f, rollout loop, any obstacle mode); kPlainStep = one control
 // step, no debug outputs, OBS fixed; kPlainRollout = the fused rollout loop, no debug outputs, OBS fixed (sphere-table modes).
 constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
@@ -1068,7 +1098,9 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
                                                const RolloutArgs& ro_arg, int R, const int block_idx) {
   constexpr bool LINKSEG = OBS == kObsSharedLink;
   static_assert(!LINKSEG || (FLAVOR == kPlainStep && !PT && !STAGE), "link segments: the lean plain builds");
-  const int obs_mode = OBS == kObsAny ? obs.mode : (LINKSEG ? RMP2_OBS_SHARED_SPHERES : OBS);
+  constexpr bool STREAM = OBS == kObsExplicitStream;
+  static_assert(!STREAM || (FLAVOR == kPlainStep && !PT && !STAGE && !CAP && N == 9 && MINW == 4), "streamed explicit pairs: the plain four-wave build");
+  const int obs_mode = OBS == kObsAny ? obs.mode : (LINKSEG ? RMP2_OBS_SHARED_SPHERES : (STREAM ? RMP2_OBS_EXPLICIT_PAIRS : OBS));
   constexpr bool PLAIN = FLAVOR == kPlainStep;   // no rollout loop
   constexpr bool LEAN = FLAVOR != kGeneral;      // no debug outputs
   // the rank-one pull-back of sets without an inertia leaf (QuadHdr::rank1) is compiled into every build such a set can reach:
@@ -1217,7 +1249,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   bool flagged = false;
   // explicit pairs by LDS-DMA (pair_loop_explicit_glds): the plain two-wave build of the explicit-pair mode only -- its launch
   // carries the 6 KiB chunk buffer behind the other regions (stage_base: no staged program, no sphere table in this build)
-  constexpr bool kGlds = OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2 && !STAGE && !PT;
+  constexpr bool kGlds = STREAM || (OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2 && !STAGE && !PT);
   int pf_pb = -1;  // (wave-uniform) pair_begin of the leaf whose first half is in the chunk buffer / in flight
 
   // ---- ragged lists over a small table: the robot's list as a membership mask (built once, by its quad) -----------------
@@ -1653,6 +1685,98 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   }
   RMP2_STAMP();  // 2: walk done
 
+  // ---- explicit pairs, streamed (OBS = kObsExplicitStream): the pair phase of ALL leaf frames, before any pull-back ----------
+  // (see kObsExplicitStream above).  sh_[t] = this lane's floats {sub, 4 + sub, 8 + sub} of the twelve [p v a -] of leaf frame t
+  // before its pairs ran, of [p S h] after; rj*_s = the (z, o) records of the joints that own my rows.
+  float sh_[STREAM ? kStreamMaxFrames : 1][3];
+  float rjz_s[STREAM ? ROWS : 1][3], rjo_s[STREAM ? ROWS : 1][3];
+  if constexpr (STREAM) {
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int i = sub + kQuad * m;
+      const int ii = i < N ? i : 0;
+      const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
+      const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
+      const float4* rj = reinterpret_cast<const float4*>(loc + kSlot * fo);
+      const float4 j0 = rj[0], j2 = rj[2];
+      rjz_s[m][0] = j2.y, rjz_s[m][1] = j2.z, rjz_s[m][2] = j2.w;
+      rjo_s[m][0] = j0.x, rjo_s[m][1] = j0.y, rjo_s[m][2] = j0.z;
+    }
+#pragma unroll
+    for (int t = 0; t < kStreamMaxFrames; ++t) {
+      sh_[t][0] = sh_[t][1] = sh_[t][2] = 0.f;
+      if (t < hdr.n_leaf_ops) {  // (wave-uniform)
+        const float* fr = loc + kSlot * prog->leaf_frames[t].op;
+        sh_[t][0] = fr[sub], sh_[t][1] = fr[4 + sub], sh_[t][2] = fr[8 + sub];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records are in registers: the DMA may overwrite their LDS
+    float* const dma = lds + QuadLds<N>::kLoc;           // [chunk image kGldsBuf | the quads' lists kGldsList] (checked on the host)
+#pragma unroll
+    for (int t = 0; t < kStreamMaxFrames; ++t) {
+      if (t < hdr.n_leaf_ops) {  // (wave-uniform)
+        if (3 * t >= hdr.n_leaf_ops && 3 * (t - 1) < hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(2);      // (thirds, as the frame loop)
+        if (3 * t >= 2 * hdr.n_leaf_ops && 3 * (t - 1) < 2 * hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
+        const int4 lfr = *reinterpret_cast<const int4*>(&prog->leaf_frames[t]);
+        const float r0v = sh_[t][0], r1v = sh_[t][1], r2v = sh_[t][2];
+        const float P3[3] = {bcast<0>(r0v), bcast<1>(r0v), bcast<2>(r0v)};
+        const float V3[3] = {bcast<3>(r0v), bcast<0>(r1v), bcast<1>(r1v)};
+        const float A3[3] = {bcast<2>(r1v), bcast<3>(r1v), bcast<0>(r2v)};
+        // the frame's leaves share its Jacobian, and the pull-back is linear in (S, h): their sums are pulled back ONCE
+        float Ss[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hs[3] = {0.f, 0.f, 0.f};
+        for (int li = 0; li < lfr.w; ++li) {
+          const DevLeaf& lf = prog->exec_leaves[lfr.z + li];
+          const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
+          float S[6], h[3];
+          if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+            float gl[3], xdd[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
+            if (lh.kind == RMP2_LEAF_TARGET_ATTRACTOR)
+              target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
+            else
+              leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
+            const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
+            h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
+            h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
+            h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+          } else {  // distance leaf on explicit pairs: 32 pairs per robot (checked on the host), streamed
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[c] = 0.f;
+            h[0] = h[1] = h[2] = 0.f;
+            const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
+            const int pb = obs.pair_begin[lf.index];
+            const int nxt = lf.next_pair_leaf;
+            const int pb_next = nxt >= 0 ? obs.pair_begin[nxt] : -1;
+            const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
+            pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, dma, lane, g, sub, P3, V3, A3, lh.P,
+                                    IP, thr * thr * kCullSlack, S, h);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 6; ++c) Ss[c] += S[c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) hs[c] += h[c];
+        }
+        // [p S h]: float `sub`, 4 + sub, 8 + sub of the twelve (every lane of the quad holds all of them)
+        sh_[t][0] = sub == 0 ? P3[0] : (sub == 1 ? P3[1] : (sub == 2 ? P3[2] : Ss[0]));
+        sh_[t][1] = sub == 0 ? Ss[1] : (sub == 1 ? Ss[2] : (sub == 2 ? Ss[3] : Ss[4]));
+        sh_[t][2] = sub == 0 ? Ss[5] : (sub == 1 ? hs[0] : (sub == 2 ? hs[1] : hs[2]));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no chunk in flight any more: slots 1 .. n_leaf_ops take the sums
+#pragma unroll
+    for (int t = 0; t < kStreamMaxFrames; ++t) {
+      if (t < hdr.n_leaf_ops) {
+        float* dst = loc + kSlot * (1 + t);   // (slot 0 stays the robot's qdd tile)
+        dst[sub] = sh_[t][0], dst[4 + sub] = sh_[t][1], dst[8 + sub] = sh_[t][2];
+      }
+    }
+  }
+
   // One accumulation + resolve pass over the wave's robots.  PASS 0 is the fast path (elimination without row exchanges);
   // PASS 1 re-accumulates and runs the careful solver for the robots PASS 0 flagged.  Two INSTANTIATIONS of one body, not a
   // two-trip loop: inside a loop every lane predicate of the resolve (sub == c, i < n_dof, ...) is loop invariant, gets
@@ -1665,7 +1789,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     // row-joint records: world axis z_i and origin o_i of the joints that own MY rows (slot [p = o | v | a | z] of the
     // joint's frame), read once per pass instead of once per leaf frame
     // (the 128-register build keeps only the records' LDS addresses and re-reads them per frame: 18 registers)
-    constexpr bool kRowRecsInRegs = MINW < 4;
+    constexpr bool kRowRecsInRegs = MINW < 4 || STREAM;  // (streamed explicit pairs: taken before the DMA overwrote the records)
     float rjz[ROWS][3], rjo[ROWS][3];
     const float4* rjs[ROWS];
     bool rjrev[ROWS];
@@ -1676,7 +1800,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       const uint32_t dw = ii < 6 ? hdr.dof_ops[0] : (ii < 12 ? hdr.dof_ops[1] : hdr.dof_ops[2]);
       const int fo = (int)((dw >> (5 * (ii - 6 * (ii / 6)))) & 31u);
       rjs[m] = reinterpret_cast<const float4*>(loc + kSlot * fo);
-      if (kRowRecsInRegs) {
+      if constexpr (STREAM) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rjz[m][c] = rjz_s[m][c], rjo[m][c] = rjo_s[m][c];
+      } else if (kRowRecsInRegs) {
         const float4 j0 = rjs[m][0], j2 = rjs[m][2];
         rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
         rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
@@ -1716,7 +1843,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       }
       RMP2_SEG_BEGIN();
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
-      const float4* fr4 = reinterpret_cast<const float4*>(floc + kSlot * k);
+      const float4* fr4 = reinterpret_cast<const float4*>(floc + kSlot * (STREAM ? 1 + t : k));
       const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
       const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
       // Jacobian columns of the frame: formed AFTER the first leaf's (S, h) -- the pair loop is where the time goes and
@@ -1726,221 +1853,228 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
 #pragma unroll       //  nine registers live through the pair loop; the 256-register build has them to spare)
         for (int m = 0; m < ROWS; ++m) mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;
       }
-      for (int li = 0; li < op.leaf_count; ++li) {
-        const DevLeaf& lf = STAGE ? leaves[uni<STAGE>(fk_list[op.leaf_begin + li])] : prog->exec_leaves[op.leaf_begin + li];
-        LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
-        lh.kind = uni<STAGE>(lh.kind);
-        lh.taskmap = uni<STAGE>(lh.taskmap);
-        lh.goal_offset = uni<STAGE>(lh.goal_offset);
-        const int lf_kind = lh.kind;
+      for (int li = 0; li < (STREAM ? 1 : op.leaf_count); ++li) {
         float S[6], h[3];
-        RMP2_SEG(0);  // frame record + leaf head on chip
         // attached-point leaf: the sums over its pairs that the pull-back below needs (see there)
         bool pt_leaf = false;
         float ptW = 0.f, ptRho[3] = {0.f, 0.f, 0.f}, ptQ[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ptTau[3] = {0.f, 0.f, 0.f};
-        if (PT && lh.taskmap == RMP2_TASKMAP_FK_POINT) {
-          // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position] + CollisionAvoidance (metric w(d) I), pair b:
-          //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J_b = J_p + [z_j x r]_j (revolute dofs).
-          // Every pair has its OWN Jacobian, but it differs from the frame origin's by a term linear in r, so the sums over
-          // the pairs collapse into 16 numbers and ONE pull-back per frame:
-          //   M += W J_p^T J_p - J_p^T [rho]x Z - (..)^T + Z^T Q Z ,   f += J_p^T h + Z^T tau
-          //   W = sum w_b, rho = sum w_b r_b, Q = sum w_b (|r_b|^2 I - r_b r_b^T), h = sum w_b e_b, tau = sum w_b r_b x e_b,
-          //   e_b = xdd_b - c_b, Z = the revolute dofs' world axes (zero columns for prismatic dofs and non-ancestors).
-          // (The hex and lane mappings pull every pair back through its own columns; same sums to fp32 rounding.)
-          pt_leaf = true;
-          const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * kPtSlot);
-          const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2], q3 = pr4[3];
-          const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
-          const float W3[3] = {q2.y, q2.z, q2.w}, AL3[3] = {q3.x, q3.y, q3.z};
-          // The leaf's pairs: (relative_position, normal_vec, distance) per pair from the caller's arrays (the reference's
-          // Datamanager fields, data_management.py:22-53) -- or, with a primitive table and link capsules (obs.link_caps), formed
-          // HERE per control step: the closest points of the leaf's link capsule and every primitive, as PyBullet reports them
-          // to the reference's loop each step (simulation.py:462-484; 05_obstacle_avoidance.py:51-72 re-feeds them); this is
-          // what lets such a set roll out inside one launch.
-          const bool from_table = obs.link_caps != nullptr;  // (wave-uniform)
-          int count;
-          size_t pbase = 0;
-          float LA[3] = {0.f, 0.f, 0.f}, LD[3] = {0.f, 0.f, 0.f}, lrad = 0.f, laa = 0.f, inv_laa = 0.f;
-          if (from_table) {
-            count = obs.n_spheres;
-            const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
-            lrad = lc[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              LA[c] = P3[c] + Rm[3 * c] * lc[0] + Rm[3 * c + 1] * lc[1] + Rm[3 * c + 2] * lc[2];
-              LD[c] = Rm[3 * c] * (lc[4] - lc[0]) + Rm[3 * c + 1] * (lc[5] - lc[1]) + Rm[3 * c + 2] * (lc[6] - lc[2]);
-            }
-            laa = dot3(LD, LD);
-            inv_laa = laa > 0.f ? 1.0f / laa : 0.f;
-          } else {
-            const int lidx = uni<STAGE>(lf.index);
-            const int pb = obs.pair_begin[lidx];
-            count = obs.pair_begin[lidx + 1] - pb;
-            pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
-          }
-          h[0] = h[1] = h[2] = 0.f;
-          for (int t = 0; kQuad * t < count; ++t) {  // (the pair layout is shared by the fleet: wave-uniform trip count)
-            const int b_raw = kQuad * t + sub;
-            const bool on = b_raw < count;
-            float r[3], nv[3], dd, t1[3], t2[3], xdp[3], cp[3];
-            if (from_table) {
-              const int bi = on ? b_raw : 0;
-              const float4* rec = reinterpret_cast<const float4*>(step_table) + (obs.capsule ? 2 * bi : bi);
-              const float4 ca = rec[0];
-              const float4 cb = obs.capsule ? rec[1] : ca;
-              link_pair_fields(LA, LD, laa, inv_laa, lrad, ca, cb, P3, r, nv, dd);
-            } else {
-              const size_t b = pbase + (on ? b_raw : 0);
-              const float rel[3] = {obs.p_link[3 * b], obs.p_link[3 * b + 1], obs.p_link[3 * b + 2]};
-              nv[0] = obs.p_obs[3 * b], nv[1] = obs.p_obs[3 * b + 1], nv[2] = obs.p_obs[3 * b + 2];
-              dd = obs.dist[b];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * rel[0] + Rm[3 * c + 1] * rel[1] + Rm[3 * c + 2] * rel[2];
-            }
-            cross3(W3, r, t1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
-            cross3(W3, t1, t2);
-            cross3(AL3, r, t1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) cp[c] = A3[c] + t1[c] + t2[c];
-            float xdd[3], wgt;
-            leaf_collision_avoidance(lh.P, dd, nv, xdp, xdd, wgt);
-            if (!on) wgt = 0.f;
-            const float e[3] = {xdd[0] - cp[0], xdd[1] - cp[1], xdd[2] - cp[2]};
-            float re[3];
-            cross3(r, e, re);
-            const float rr = dot3(r, r);
-            ptW += wgt;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              ptRho[c] = fmaf(wgt, r[c], ptRho[c]);
-              h[c] = fmaf(wgt, e[c], h[c]);
-              ptTau[c] = fmaf(wgt, re[c], ptTau[c]);
-            }
-            ptQ[0] = fmaf(wgt, rr - r[0] * r[0], ptQ[0]);
-            ptQ[1] = fmaf(wgt, -r[0] * r[1], ptQ[1]);
-            ptQ[2] = fmaf(wgt, -r[0] * r[2], ptQ[2]);
-            ptQ[3] = fmaf(wgt, rr - r[1] * r[1], ptQ[3]);
-            ptQ[4] = fmaf(wgt, -r[1] * r[2], ptQ[4]);
-            ptQ[5] = fmaf(wgt, rr - r[2] * r[2], ptQ[5]);
-          }
-          ptW = quad_sum(ptW);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            ptRho[c] = quad_sum(ptRho[c]);
-            h[c] = quad_sum(h[c]);
-            ptTau[c] = quad_sum(ptTau[c]);
-          }
-#pragma unroll
-          for (int c = 0; c < 6; ++c) ptQ[c] = quad_sum(ptQ[c]);
-          S[0] = S[3] = S[5] = ptW;   // (the metric of the origin term: W I)
-          S[1] = S[2] = S[4] = 0.f;
-        } else if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
-          float gl[3], xdd[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
-          if (lf_kind == RMP2_LEAF_TARGET_ATTRACTOR)
-            target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
-          else
-            leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
-          const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
-          h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
-          h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
-          h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+        if constexpr (STREAM) {
+          // streamed explicit pairs: the pair phase ran before this pass and left [p S h] of the frame -- the sums over ALL its
+          // leaves -- in slot 1 + t (read above as f0, f1, f2)
+          S[0] = f0.w, S[1] = f1.x, S[2] = f1.y, S[3] = f1.z, S[4] = f1.w, S[5] = f2.x;
+          h[0] = f2.y, h[1] = f2.z, h[2] = f2.w;
         } else {
-          // distance leaf: this lane takes pairs b = sub, sub+4, ...; S and h are butterfly-summed.
-          // The obstacle mode is resolved OUTSIDE the loop (one straight-line loop body per mode).
-#pragma unroll
-          for (int c = 0; c < 6; ++c) S[c] = 0.f;
-          h[0] = h[1] = h[2] = 0.f;
-          const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
-          const float* sph_lds = sph_lds_base;
-          if (LINKSEG) {  // lean link build: the world segment was formed in the walk (slot t of this robot)
-            const float4* sg4 = reinterpret_cast<const float4*>(stage_base + (g * hdr.n_leaf_ops + t) * kLinkSeg);
-            const float4 sa = sg4[0], sb = sg4[1];
-            const float LA[3] = {sa.x, sa.y, sa.z}, LB[3] = {sb.x, sb.y, sb.z};
-            const float lrad = obs.link_caps[8 * lf.dist_ordinal + 3];
-            pair_loop_link<true, CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lrad, hdr.cull_c0, V3, A3, lh.P, IP, S, h,
-                                      step_table);
-          } else if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
-            const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * pt_slot);
-            const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2];
+          const DevLeaf& lf = STAGE ? leaves[uni<STAGE>(fk_list[op.leaf_begin + li])] : prog->exec_leaves[op.leaf_begin + li];
+          LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
+          lh.kind = uni<STAGE>(lh.kind);
+          lh.taskmap = uni<STAGE>(lh.taskmap);
+          lh.goal_offset = uni<STAGE>(lh.goal_offset);
+          const int lf_kind = lh.kind;
+          RMP2_SEG(0);  // frame record + leaf head on chip
+          if (PT && lh.taskmap == RMP2_TASKMAP_FK_POINT) {
+            // chain [FK(frame), TaskmapRelative4x4(rel), 4x4 -> position] + CollisionAvoidance (metric w(d) I), pair b:
+            //   r = R rel, x = p + r, xd = v + w x r, c = a + al x r + w x (w x r), J_b = J_p + [z_j x r]_j (revolute dofs).
+            // Every pair has its OWN Jacobian, but it differs from the frame origin's by a term linear in r, so the sums over
+            // the pairs collapse into 16 numbers and ONE pull-back per frame:
+            //   M += W J_p^T J_p - J_p^T [rho]x Z - (..)^T + Z^T Q Z ,   f += J_p^T h + Z^T tau
+            //   W = sum w_b, rho = sum w_b r_b, Q = sum w_b (|r_b|^2 I - r_b r_b^T), h = sum w_b e_b, tau = sum w_b r_b x e_b,
+            //   e_b = xdd_b - c_b, Z = the revolute dofs' world axes (zero columns for prismatic dofs and non-ancestors).
+            // (The hex and lane mappings pull every pair back through its own columns; same sums to fp32 rounding.)
+            pt_leaf = true;
+            const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * kPtSlot);
+            const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2], q3 = pr4[3];
             const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
-            const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
-            const float la[3] = {lc[0], lc[1], lc[2]}, lb[3] = {lc[4], lc[5], lc[6]};
-            float LA[3], LB[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              LA[c] = P3[c] + Rm[3 * c] * la[0] + Rm[3 * c + 1] * la[1] + Rm[3 * c + 2] * la[2];
-              LB[c] = P3[c] + Rm[3 * c] * lb[0] + Rm[3 * c + 1] * lb[1] + Rm[3 * c + 2] * lb[2];
+            const float W3[3] = {q2.y, q2.z, q2.w}, AL3[3] = {q3.x, q3.y, q3.z};
+            // The leaf's pairs: (relative_position, normal_vec, distance) per pair from the caller's arrays (the reference's
+            // Datamanager fields, data_management.py:22-53) -- or, with a primitive table and link capsules (obs.link_caps), formed
+            // HERE per control step: the closest points of the leaf's link capsule and every primitive, as PyBullet reports them
+            // to the reference's loop each step (simulation.py:462-484; 05_obstacle_avoidance.py:51-72 re-feeds them); this is
+            // what lets such a set roll out inside one launch.
+            const bool from_table = obs.link_caps != nullptr;  // (wave-uniform)
+            int count;
+            size_t pbase = 0;
+            float LA[3] = {0.f, 0.f, 0.f}, LD[3] = {0.f, 0.f, 0.f}, lrad = 0.f, laa = 0.f, inv_laa = 0.f;
+            if (from_table) {
+              count = obs.n_spheres;
+              const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
+              lrad = lc[3];
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                LA[c] = P3[c] + Rm[3 * c] * lc[0] + Rm[3 * c + 1] * lc[1] + Rm[3 * c + 2] * lc[2];
+                LD[c] = Rm[3 * c] * (lc[4] - lc[0]) + Rm[3 * c + 1] * (lc[5] - lc[1]) + Rm[3 * c + 2] * (lc[6] - lc[2]);
+              }
+              laa = dot3(LD, LD);
+              inv_laa = laa > 0.f ? 1.0f / laa : 0.f;
+            } else {
+              const int lidx = uni<STAGE>(lf.index);
+              const int pb = obs.pair_begin[lidx];
+              count = obs.pair_begin[lidx + 1] - pb;
+              pbase = (size_t)(live ? robot : 0) * obs.n_pairs + pb;
             }
-            if (obs_mode == RMP2_OBS_RAGGED_SPHERES && !use_member) {  // (wave-uniform) a list that is not a mask: the list walk
-              int rr_ = live ? robot : 0;
+            h[0] = h[1] = h[2] = 0.f;
+            for (int t = 0; kQuad * t < count; ++t) {  // (the pair layout is shared by the fleet: wave-uniform trip count)
+              const int b_raw = kQuad * t + sub;
+              const bool on = b_raw < count;
+              float r[3], nv[3], dd, t1[3], t2[3], xdp[3], cp[3];
+              if (from_table) {
+                const int bi = on ? b_raw : 0;
+                const float4* rec = reinterpret_cast<const float4*>(step_table) + (obs.capsule ? 2 * bi : bi);
+                const float4 ca = rec[0];
+                const float4 cb = obs.capsule ? rec[1] : ca;
+                link_pair_fields(LA, LD, laa, inv_laa, lrad, ca, cb, P3, r, nv, dd);
+              } else {
+                const size_t b = pbase + (on ? b_raw : 0);
+                const float rel[3] = {obs.p_link[3 * b], obs.p_link[3 * b + 1], obs.p_link[3 * b + 2]};
+                nv[0] = obs.p_obs[3 * b], nv[1] = obs.p_obs[3 * b + 1], nv[2] = obs.p_obs[3 * b + 2];
+                dd = obs.dist[b];
+  #pragma unroll
+                for (int c = 0; c < 3; ++c) r[c] = Rm[3 * c] * rel[0] + Rm[3 * c + 1] * rel[1] + Rm[3 * c + 2] * rel[2];
+              }
+              cross3(W3, r, t1);
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) xdp[c] = V3[c] + t1[c];
+              cross3(W3, t1, t2);
+              cross3(AL3, r, t1);
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) cp[c] = A3[c] + t1[c] + t2[c];
+              float xdd[3], wgt;
+              leaf_collision_avoidance(lh.P, dd, nv, xdp, xdd, wgt);
+              if (!on) wgt = 0.f;
+              const float e[3] = {xdd[0] - cp[0], xdd[1] - cp[1], xdd[2] - cp[2]};
+              float re[3];
+              cross3(r, e, re);
+              const float rr = dot3(r, r);
+              ptW += wgt;
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                ptRho[c] = fmaf(wgt, r[c], ptRho[c]);
+                h[c] = fmaf(wgt, e[c], h[c]);
+                ptTau[c] = fmaf(wgt, re[c], ptTau[c]);
+              }
+              ptQ[0] = fmaf(wgt, rr - r[0] * r[0], ptQ[0]);
+              ptQ[1] = fmaf(wgt, -r[0] * r[1], ptQ[1]);
+              ptQ[2] = fmaf(wgt, -r[0] * r[2], ptQ[2]);
+              ptQ[3] = fmaf(wgt, rr - r[1] * r[1], ptQ[3]);
+              ptQ[4] = fmaf(wgt, -r[1] * r[2], ptQ[4]);
+              ptQ[5] = fmaf(wgt, rr - r[2] * r[2], ptQ[5]);
+            }
+            ptW = quad_sum(ptW);
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              ptRho[c] = quad_sum(ptRho[c]);
+              h[c] = quad_sum(h[c]);
+              ptTau[c] = quad_sum(ptTau[c]);
+            }
+  #pragma unroll
+            for (int c = 0; c < 6; ++c) ptQ[c] = quad_sum(ptQ[c]);
+            S[0] = S[3] = S[5] = ptW;   // (the metric of the origin term: W I)
+            S[1] = S[2] = S[4] = 0.f;
+          } else if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
+            float gl[3], xdd[3];
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
+            if (lf_kind == RMP2_LEAF_TARGET_ATTRACTOR)
+              target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
+            else
+              leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
+            const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
+            h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
+            h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
+            h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
+          } else {
+            // distance leaf: this lane takes pairs b = sub, sub+4, ...; S and h are butterfly-summed.
+            // The obstacle mode is resolved OUTSIDE the loop (one straight-line loop body per mode).
+  #pragma unroll
+            for (int c = 0; c < 6; ++c) S[c] = 0.f;
+            h[0] = h[1] = h[2] = 0.f;
+            const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
+            const float* sph_lds = sph_lds_base;
+            if (LINKSEG) {  // lean link build: the world segment was formed in the walk (slot t of this robot)
+              const float4* sg4 = reinterpret_cast<const float4*>(stage_base + (g * hdr.n_leaf_ops + t) * kLinkSeg);
+              const float4 sa = sg4[0], sb = sg4[1];
+              const float LA[3] = {sa.x, sa.y, sa.z}, LB[3] = {sb.x, sb.y, sb.z};
+              const float lrad = obs.link_caps[8 * lf.dist_ordinal + 3];
+              pair_loop_link<true, CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lrad, hdr.cull_c0, V3, A3, lh.P, IP, S, h,
+                                        step_table);
+            } else if (PT && obs.link_caps) {  // (wave-uniform) link geometry: SHARED_SPHERES, table in LDS (checked on the host)
+              const float4* pr4 = reinterpret_cast<const float4*>(pt_base + (g * n_ops + k) * pt_slot);
+              const float4 q0 = pr4[0], q1 = pr4[1], q2 = pr4[2];
+              const float Rm[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+              const float* lc = obs.link_caps + 8 * uni<STAGE>(lf.dist_ordinal);
+              const float la[3] = {lc[0], lc[1], lc[2]}, lb[3] = {lc[4], lc[5], lc[6]};
+              float LA[3], LB[3];
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                LA[c] = P3[c] + Rm[3 * c] * la[0] + Rm[3 * c + 1] * la[1] + Rm[3 * c + 2] * la[2];
+                LB[c] = P3[c] + Rm[3 * c] * lb[0] + Rm[3 * c + 1] * lb[1] + Rm[3 * c + 2] * lb[2];
+              }
+              if (obs_mode == RMP2_OBS_RAGGED_SPHERES && !use_member) {  // (wave-uniform) a list that is not a mask: the list walk
+                int rr_ = live ? robot : 0;
+                const int b0 = obs.csr_offset[rr_];
+                const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
+                int max_count = count;
+  #pragma unroll
+                for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
+                pair_loop_link_list(step_table, obs.capsule != 0, obs.csr_index + b0, count, max_count, sub, LA, LB, lc[3], V3, A3, lh.P,
+                                    IP, S, h);
+              } else
+              pair_loop_link<(MINW >= 2), CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lc[3], hdr.cull_c0, V3, A3, lh.P, IP, S, h,
+                                               step_table, obs_mode == RMP2_OBS_RAGGED_SPHERES, member_lo, member_hi);
+            } else if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
+              if (spheres_in_lds)
+  #ifdef RMP2_STAMPS
+                pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                       V3, A3, lh.P, IP, S, h, &seg_[5], 0u, 0u, step_table);
+  #else
+                pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                       V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
+  #endif
+              else
+                pair_loop<kPairsSharedGlobal, CAP>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
+                                              P3, V3, A3, lh.P, IP, S, h);
+            } else if (obs_mode == RMP2_OBS_EXPLICIT_PAIRS) {
+              const int lidx = uni<STAGE>(lf.index);
+              const int pb = obs.pair_begin[lidx];
+              const int count = obs.pair_begin[lidx + 1] - pb;
+              const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
+              // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
+              const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
+              if (kGlds && obs.glds && count == 32) {  // (wave-uniform) streamed half a leaf ahead by LDS-DMA
+                const int nxt = lf.next_pair_leaf;
+                int pb_next = -1;
+                if (nxt >= 0) {
+                  const int nb = obs.pair_begin[nxt];
+                  pb_next = (obs.pair_begin[nxt + 1] - nb == 32) ? nb : -1;
+                }
+                pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, stage_base, lane, g, sub, P3,
+                                        V3, A3, lh.P, IP, thr * thr * kCullSlack, S, h);
+              } else
+              pair_loop_explicit_culled<(MINW >= 3 ? RMP2_EXPLICIT_WINDOW : 0)>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3,
+                                                                              lh.P, IP, thr * thr * kCullSlack, S, h);
+            } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
+              pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
+                                                                    V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);
+            } else {
+              int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
+              if (MINW >= 3) asm volatile("" : "+v"(rr_));
               const int b0 = obs.csr_offset[rr_];
               const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
               int max_count = count;
-#pragma unroll
+  #pragma unroll
               for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
-              pair_loop_link_list(step_table, obs.capsule != 0, obs.csr_index + b0, count, max_count, sub, LA, LB, lc[3], V3, A3, lh.P,
-                                  IP, S, h);
-            } else
-            pair_loop_link<(MINW >= 2), CAP>(sph_lds, n_sph_lds, obs.n_spheres, sub, LA, LB, lc[3], hdr.cull_c0, V3, A3, lh.P, IP, S, h,
-                                             step_table, obs_mode == RMP2_OBS_RAGGED_SPHERES, member_lo, member_hi);
-          } else if (obs_mode == RMP2_OBS_SHARED_SPHERES) {
-            if (spheres_in_lds)
-#ifdef RMP2_STAMPS
-              pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                     V3, A3, lh.P, IP, S, h, &seg_[5], 0u, 0u, step_table);
-#else
-              pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                     V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
-#endif
-            else
-              pair_loop<kPairsSharedGlobal, CAP>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
-                                            P3, V3, A3, lh.P, IP, S, h);
-          } else if (obs_mode == RMP2_OBS_EXPLICIT_PAIRS) {
-            const int lidx = uni<STAGE>(lf.index);
-            const int pb = obs.pair_begin[lidx];
-            const int count = obs.pair_begin[lidx + 1] - pb;
-            const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
-            // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
-            const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
-            if (kGlds && obs.glds && count == 32) {  // (wave-uniform) streamed half a leaf ahead by LDS-DMA
-              const int nxt = lf.next_pair_leaf;
-              int pb_next = -1;
-              if (nxt >= 0) {
-                const int nb = obs.pair_begin[nxt];
-                pb_next = (obs.pair_begin[nxt + 1] - nb == 32) ? nb : -1;
-              }
-              pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, stage_base, lane, g, sub, P3,
-                                      V3, A3, lh.P, IP, thr * thr * kCullSlack, S, h);
-            } else
-            pair_loop_explicit_culled<(MINW >= 3 ? RMP2_EXPLICIT_WINDOW : 0)>(obs.p_link + base, obs.p_obs + base, count, sub, P3, V3, A3,
-                                                                            lh.P, IP, thr * thr * kCullSlack, S, h);
-          } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
-            pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                  V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);
-          } else {
-            int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
-            if (MINW >= 3) asm volatile("" : "+v"(rr_));
-            const int b0 = obs.csr_offset[rr_];
-            const int count = live ? obs.csr_offset[rr_ + 1] - b0 : 0;
-            int max_count = count;
-#pragma unroll
-            for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
-            if (spheres_in_lds)
-              pair_loop_culled<true, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3,
-                                                                    V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
-            else
-              pair_loop<kPairsRaggedGlobal, CAP>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
-                                            P3, V3, A3, lh.P, IP, S, h);
+              if (spheres_in_lds)
+                pair_loop_culled<true, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3,
+                                                                      V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
+              else
+                pair_loop<kPairsRaggedGlobal, CAP>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
+                                              P3, V3, A3, lh.P, IP, S, h);
+            }
+            RMP2_SEG(2);  // distance leaf: cull + pair trips
+  #pragma unroll
+            for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
           }
-          RMP2_SEG(2);  // distance leaf: cull + pair trips
-#pragma unroll
-          for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
         }
         RMP2_SEG(1);  // target leaf (S, h) / the quad sums of a distance leaf
         if (li == 0) {

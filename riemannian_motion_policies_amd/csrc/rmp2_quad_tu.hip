@@ -152,6 +152,34 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
       return;
     }
   }
+  if constexpr (N == 9) {
+    // interface B (explicit closest-point pairs), plain control step, grids of at least four waves per SIMD: the STREAMED form
+    // (rmp2_quad.h kObsExplicitStream) -- pair phase before the pull-back, pair arrays by LDS-DMA through the frame records' LDS,
+    // 128 registers / 9.6 KB per wave: sixteen waves per CU.  Needs: 32 pairs per distance leaf and 16-byte aligned leaf segments
+    // (the DMA moves 16-byte pieces), at most kStreamMaxFrames leaf-bearing frames with a frame slot each behind slot 0, frame
+    // slots that hold the chunk image and the quads' lists, an inertia leaf (the rank-one pull-back lives in the general builds).
+    // RMP2_EXPLICIT_STREAM=0 keeps the single-loop two-wave form (A/B); =1 takes the streamed form at any throughput grid.
+    const int stream_env = h->explicit_stream;
+    const int bc = (blocks + h->n_simd - 1) / h->n_simd;
+    bool stream = o.mode == RMP2_OBS_EXPLICIT_PAIRS && !latency && !with_records && plain && !o.capsule && !o.dist &&
+                  !h->likely_singular && stream_env != 0 && (stream_env == 1 || (h->quad_minw == 0 && bc >= 4)) &&
+                  h->n_leaf_ops <= kStreamMaxFrames && h->n_ops_step >= h->n_leaf_ops + 1 &&
+                  kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) >= kGldsBuf + kGldsList &&
+                  (o.n_pairs % 4) == 0 && (reinterpret_cast<uintptr_t>(o.p_link) % 16) == 0 && (reinterpret_cast<uintptr_t>(o.p_obs) % 16) == 0;
+    for (int l : h->distance_leaves)
+      stream = stream && (h->h_pair_begin[l] % 4) == 0 && h->h_pair_begin[l + 1] - h->h_pair_begin[l] == 32;
+    if (stream) {
+      if (symk) RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, 4, false, false, true, kObsExplicitStream, kPlainStep>), dim3(blocks),
+                                 dim3(kWave), lds_bytes, s, h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);
+      else RMP2_STEP_LAUNCH(h, (rmp2_step_quad_kernel<N, SLOTS, 4, false, false, false, kObsExplicitStream, kPlainStep>), dim3(blocks),
+                            dim3(kWave), lds_bytes, s, h->d_prog, hdr, q, qd, goal, gs, o, out, ro, R);
+      h->last_kernel = quad_certifies_strict(h)
+                           ? "rmp2_step_quad_kernel (4 lanes per robot; explicit pairs streamed by LDS-DMA, pair phase before the pull-back; "
+                             "strict: full rank certified per robot, Jacobi pseudo-inverse for the rest)"
+                           : "rmp2_step_quad_kernel (4 lanes per robot; explicit pairs streamed by LDS-DMA, pair phase before the pull-back)";
+      return;
+    }
+  }
   if (with_records) {
     // attached-point leaves (TaskmapRelative4x4 + CollisionAvoidance) and link geometry in the table modes: the general
     // flavour with the extra per-frame records (27 floats per frame instead of 12: two waves per SIMD at most)

@@ -636,32 +636,23 @@ class MixedFleetShard:
         return cuts, ranges, work
 
     @classmethod
-    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None,
-                  fused: bool = True, link_geometry: bool = False):
-        """Synthetic config-5 fleet of `total` robots (SURVEY 8(d): k_r ~ U{0..32} as CSR lists into the type's
-        shared sphere table); builds only this rank's shard.  `cost`: see plan().
-        link_geometry: the control point of a pair is the nearest point of the LINK's capsule to the obstacle (formed inside
-        the step, rmp2_obstacles.link_capsules over the ragged lists: round 4) instead of the frame origin; the two robot
-        types then step as two launches (the one-grid build carries no link geometry)."""
+    def synthetic_host(cls, total: int, world: int, rank: int, seed: int = 5, cost=None):
+        """The HOST side of synthetic(): this rank's shard of the synthetic config-5 fleet as numpy inputs, no device touched --
+        {type: dict(n, st = {q, qd, goal}, spheres, csr_offset, csr_index, k)} for the types the rank holds, plus "work" (the
+        plan's per-robot cost estimates of the shard).  The draws are exactly synthetic()'s (which calls this), so that a
+        CPU-side tool (tests/golden/make_perf_envelope.py) sees the very robots a GPU run steps."""
         import numpy as np
         from . import configs as Cf
-        from .engine import Engine
         rng = np.random.default_rng(seed)
         counts = rng.integers(0, Cf.N_SPHERES + 1, size=total)
         _, ranges, work = cls.plan(total, world, counts, cost)
         n_tj = total // 2
-        self = cls()
-        self.parts = {}
-        self.work = 0.0
-        dev = torch.device("cuda", device)
-        for key, builder, sampler, first in (("two_joint", Cf.config5_two_joint, Cf.sample_two_joint_states, 0),
-                                             ("panda", Cf.config3, Cf.sample_panda_states, n_tj)):
+        host = {"work": {}}
+        for key, sampler, first in (("two_joint", Cf.sample_two_joint_states, 0), ("panda", Cf.sample_panda_states, n_tj)):
             lo, hi = ranges[rank][key]
             n = hi - lo
             if n <= 0:
                 continue
-            _, desc = builder(solve)
-            eng = Engine(desc, device)
             trng = np.random.default_rng([seed, first, rank])
             st = sampler(trng, n)
             sph = Cf.sample_spheres(np.random.default_rng([seed, first]))   # one table per type, same on every rank
@@ -673,6 +664,33 @@ class MixedFleetShard:
             take = np.arange(Cf.N_SPHERES)[None, :] < k[:, None]
             csr_index = order[take]
             csr_offset = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+            host[key] = dict(n=n, st=st, spheres=sph, csr_offset=csr_offset, csr_index=csr_index, k=k)
+            host["work"][key] = float(work[first + lo:first + hi].sum())
+        return host
+
+    @classmethod
+    def synthetic(cls, total: int, world: int, rank: int, device: int, seed: int = 5, solve: str = "auto", cost=None,
+                  fused: bool = True, link_geometry: bool = False):
+        """Synthetic config-5 fleet of `total` robots (SURVEY 8(d): k_r ~ U{0..32} as CSR lists into the type's
+        shared sphere table); builds only this rank's shard.  `cost`: see plan().
+        link_geometry: the control point of a pair is the nearest point of the LINK's capsule to the obstacle (formed inside
+        the step, rmp2_obstacles.link_capsules over the ragged lists: round 4) instead of the frame origin; the two robot
+        types then step as two launches (the one-grid build carries no link geometry)."""
+        import numpy as np
+        from . import configs as Cf
+        from .engine import Engine
+        host = cls.synthetic_host(total, world, rank, seed, cost)
+        self = cls()
+        self.parts = {}
+        self.work = 0.0
+        dev = torch.device("cuda", device)
+        for key, builder in (("two_joint", Cf.config5_two_joint), ("panda", Cf.config3)):
+            if key not in host:
+                continue
+            hp = host[key]
+            n, st, sph, csr_offset, csr_index, k = (hp[x] for x in ("n", "st", "spheres", "csr_offset", "csr_index", "k"))
+            _, desc = builder(solve)
+            eng = Engine(desc, device)
             q, qd, goal = (torch.from_numpy(st[x]).to(dev) for x in ("q", "qd", "goal"))
             out = torch.empty_like(q)
             lc = None
@@ -687,7 +705,7 @@ class MixedFleetShard:
             obs = eng.obstacles(spheres=torch.from_numpy(sph).to(dev), csr_offset=torch.from_numpy(csr_offset),
                                 csr_index=torch.from_numpy(csr_index), link_capsules=lc)
             # the two types' kernels are independent: the TwoJoint part runs on a side stream, beside the Pandas'
-            side = torch.cuda.Stream(dev) if key == "two_joint" and ranges[rank]["panda"][1] > ranges[rank]["panda"][0] else None
+            side = torch.cuda.Stream(dev) if key == "two_joint" and "panda" in host else None
             launch, _ = eng.bind(q, qd, goal, obstacles=obs, out=out, stream=side.cuda_stream if side is not None else None)
             if side is not None:
                 self._side, self._side_launch = side, launch
@@ -698,7 +716,7 @@ class MixedFleetShard:
                                              link_capsules=lc_host if link_geometry else None),
                                    bytes=float(n * (cls.BYTES[key] + 4) + 4 * k.sum()),
                                    flops=float(n * cls.BASE_FLOPS[key] + 240.0 * pairs))
-            self.work += float(work[first + lo:first + hi].sum())
+            self.work += host["work"][key]
         self.n_two_joint = self.parts.get("two_joint", {}).get("n", 0)
         self.n_panda = self.parts.get("panda", {}).get("n", 0)
         # both types in the shard: their two steps as ONE call -- one fused grid where the library has the instantiation

@@ -1,0 +1,273 @@
+"""Generate tests/golden/perf_envelope.npz and tests/golden/near_contact.npz: what an fp32 evaluation of the REFERENCE'S OWN GRAPH
+makes of the BASELINE perf inputs -- the data behind the accuracy envelope of tests/test_gpu_accuracy_envelope.py and
+tools/accuracy_survey.py (round-4 review, item 1).
+
+The north star asks for q-double-dot within 1e-5 of the reference's TensorFlow path in fp32.  TensorFlow cannot run here (SURVEY
+8(c)); the closest thing to it is oracle/torch_autodiff_oracle.py -- the reference's graph op for op in fp32 torch, derivatives by
+the reference's own nested-autograd trick, fp64 accumulation and numpy's pinv with TensorFlow's cutoff.  Its distance from the fp64
+evaluation of the same formulae (`err_ref32`) is what ANY fp32 evaluation of the algorithm -- TensorFlow's included -- leaves on a
+robot, whatever amplifies it (millimetre clearances under exp(-x / 0.01) and 1 / x^2, cond(M)); the C oracle's fp32-leaf build
+gives a second, independently ordered sample of the same thing (`err_c32`, computed at test time).  The engine is then held to
+`err_engine <= small multiple of max(err_ref32, err_c32)` on the robots the absolute 1e-5 cannot cover.
+
+perf_envelope.npz: the FIRST 2048 robots of every perf fleet bench.py and tools/accuracy_survey.py step (inputs regenerated from
+the seeds -- SURVEY 8(d): seed 1 -- so only the restatement's outputs are stored):
+    config2                 Panda, 3 leaves, 4 096 robots
+    config3                 Panda cluttered, 32 shared spheres (also serves interface B: the restatement reads explicit pairs anyway)
+    config3c                the same states against 32 capsules
+    config5_two_joint       rank 0 of the 8-rank cut of the 262 144-robot mixed fleet (ragged lists)
+    config5_panda           rank 7 of the same cut
+near_contact.npz: 64 robots per fleet re-drawn until their smallest surface clearance lies in [0.005, 0.05] m (the band the
+round-1..4 fixtures avoid by construction: make_fixtures.py rejects < 0.05), inputs AND expected values stored: the autograd
+fp32 restatement (`qdd_ref32`, on explicit pairs) and the fp64 evaluation of the same pairs (`qdd_pairs_f64`), the C oracle's
+fp32-leaf and fp64 evaluations on the table (`qdd_c32`, `qdd_f64`), the fp64 system (`M_f64`, `f_f64`).
+
+    python tests/golden/make_perf_envelope.py          # ~3 min on 8 cores
+"""
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+N_PERF = 2048
+N_NEAR = 64
+CLEAR_LO, CLEAR_HI = 0.005, 0.05
+
+
+def perf_fleets(n=N_PERF):
+    """{name: dict(robot, desc builder name, q, qd, goal, table (or None), csr_offset / csr_index (or None))}: the first n robots
+    of each perf fleet, drawn exactly as bench.py / tools/accuracy_survey.py / fleet.MixedFleetShard draw them."""
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    out = {}
+    s2 = Cf.sample_panda_states(np.random.default_rng(1), 4096)
+    out["config2"] = dict(robot="panda", set="config2", table=None, **{k: v[:n] for k, v in s2.items()})
+    s3 = Cf.sample_panda_states(np.random.default_rng(1), 65536)
+    sph = Cf.sample_spheres(np.random.default_rng(7), Cf.N_SPHERES)
+    caps = Cf.sample_capsules(np.random.default_rng(7), Cf.N_SPHERES)
+    out["config3"] = dict(robot="panda", set="config3", table=sph, **{k: v[:n] for k, v in s3.items()})
+    out["config3c"] = dict(robot="panda", set="config3", table=caps, **{k: v[:n] for k, v in s3.items()})
+    for rank, key, name in ((0, "two_joint", "config5_two_joint"), (7, "panda", "config5_panda")):
+        hp = MixedFleetShard.synthetic_host(262144, 8, rank)[key]
+        m = min(n, hp["n"])
+        off = hp["csr_offset"][: m + 1]
+        out[name] = dict(robot=key, set="config5_two_joint" if key == "two_joint" else "config3", table=hp["spheres"],
+                         csr_offset=off, csr_index=hp["csr_index"][: off[-1]], **{k: v[:m] for k, v in hp["st"].items()})
+    return out
+
+
+def desc_of(fleet):
+    from riemannian_motion_policies_amd import configs as Cf
+    return {"config2": Cf.config2, "config3": Cf.config3, "config5_two_joint": Cf.config5_two_joint}[fleet["set"]]()
+
+
+def obstacle_kwargs(fleet):
+    """The oracle keyword arguments of a fleet (table interface)."""
+    kw = {}
+    if fleet.get("table") is not None:
+        kw["spheres"] = fleet["table"]
+    if fleet.get("csr_offset") is not None:
+        kw.update(csr_offset=fleet["csr_offset"], csr_index=fleet["csr_index"])
+    return kw
+
+
+def explicit_pairs(fleet):
+    """Per robot {leaf index: (p_link, p_obs)} -- the restatement reads explicit closest-point pairs (data_management.py:8-37), the
+    control point being the frame origin (fp64 kinematics of the C oracle, rounded to fp32 as PyBullet's output would be)."""
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    table_, desc = desc_of(fleet)
+    tab = fleet.get("table")
+    if tab is None:
+        return None
+    dl = D.distance_leaf_indices(desc)
+    frames = [desc.leaves[i].frame for i in dl]
+    T = O.forward_kinematics(desc, fleet["q"], precision="f64")
+    origins = T[:, frames][:, :, :3, 3].astype(np.float32)
+    make = Cf.pairs_from_capsules if tab.shape[1] == 8 else Cf.pairs_from_spheres
+    off, idx = fleet.get("csr_offset"), fleet.get("csr_index")
+    per_robot = []
+    for r in range(len(fleet["q"])):
+        sel = tab if off is None else tab[idx[off[r]:off[r + 1]]]
+        k = len(sel)
+        if k == 0:
+            per_robot.append({li: (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)) for li in dl})
+            continue
+        pl, po = make(origins[r:r + 1], sel)
+        per_robot.append({li: (pl[0, c * k:(c + 1) * k], po[0, c * k:(c + 1) * k]) for c, li in enumerate(dl)})
+    return per_robot
+
+
+def pair_arrays(fleet):
+    """The same explicit pairs as dense arrays [n, L * kmax, 3] for the C oracle / the engine's explicit-pair interface: per leaf
+    kmax slots, far-away fillers (metric exactly 0) behind a robot's own pairs."""
+    from riemannian_motion_policies_amd import descriptor as D
+    _, desc = desc_of(fleet)
+    pr = explicit_pairs(fleet)
+    dl = D.distance_leaf_indices(desc)
+    kmax = max(max(len(p[dl[0]][0]) for p in pr), 1)
+    n, L = len(pr), len(dl)
+    pl = np.zeros((n, L * kmax, 3), np.float32)
+    po = np.full((n, L * kmax, 3), 1.0e3, np.float32)
+    for r, p in enumerate(pr):
+        for c, li in enumerate(dl):
+            k = len(p[li][0])
+            pl[r, c * kmax:c * kmax + k] = p[li][0]
+            po[r, c * kmax:c * kmax + k] = p[li][1]
+    return pl, po
+
+
+def truth_of_the_restatement(fleet):
+    """fp64 evaluation (C oracle, double build) of the function the restatement evaluates in fp32: the SAME explicit pairs for a
+    fleet with obstacles (the table interface means something else for a control point INSIDE a primitive -- signed distance,
+    outward normal -- where the pair form reads a positive distance and a flipped normal, taskmap.py:126-129; and its fp32
+    error includes forming the distance from the table, which the pair form holds in its inputs), the plain step otherwise."""
+    import oracle as O
+    _, desc = desc_of(fleet)
+    if fleet.get("table") is None:
+        return O.step(desc, fleet["q"], fleet["qd"], fleet["goal"], precision="f64")["qdd64"]
+    pl, po = pair_arrays(fleet)
+    return O.step(desc, fleet["q"], fleet["qd"], fleet["goal"], precision="f64", p_link=pl, p_obs=po)["qdd64"]
+
+
+_W = {}
+
+
+def _init_worker(gold_path):
+    import torch_autodiff_oracle as TA
+    gold = json.load(open(gold_path))
+    _W["TA"] = TA
+    _W["fk"] = {"panda": TA.UrdfForwardKinematicTorch(gold["panda"]), "two_joint": TA.UrdfForwardKinematicTorch(gold["two_joint"])}
+
+
+def _eval_chunk(args):
+    robot, leaves, rows = args
+    TA = _W["TA"]
+    return [TA.evaluate_one(_W["fk"][robot], leaves, q, qd, goal, pairs)[0] for q, qd, goal, pairs in rows]
+
+
+def restatement_qdd(pool, fleet, chunk=16):
+    """q-double-dot [n, dof] (fp64 values of the fp32-leaf graph) of the autograd restatement, one robot per call as the
+    reference runs."""
+    import torch_autodiff_oracle as TA
+    table, desc = desc_of(fleet)
+    leaves = TA.leaves_from_desc(desc, table.frame_names)
+    pairs = explicit_pairs(fleet)
+    n = len(fleet["q"])
+    rows = [(fleet["q"][r], fleet["qd"][r], fleet["goal"][r], None if pairs is None else pairs[r]) for r in range(n)]
+    jobs = [(fleet["robot"], leaves, rows[i:i + chunk]) for i in range(0, n, chunk)]
+    out = []
+    for part in pool.imap(_eval_chunk, jobs):
+        out.extend(part)
+    return np.asarray(out, dtype=np.float64)
+
+
+def min_clearance(fleet):
+    """Smallest surface distance (control point to primitive) per robot, over the primitives the robot sees (fp64)."""
+    import oracle as O
+    from riemannian_motion_policies_amd import descriptor as D
+    _, desc = desc_of(fleet)
+    tab = fleet["table"].astype(np.float64)
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    p = O.forward_kinematics(desc, fleet["q"], precision="f64")[:, frames][:, :, :3, 3]       # [R, C, 3]
+    if tab.shape[1] == 8:
+        a, b = tab[None, None, :, 0:3], tab[None, None, :, 4:7]
+        u = b - a
+        t = np.clip(((p[:, :, None, :] - a) * u).sum(-1) / np.maximum((u * u).sum(-1), 1e-300), 0.0, 1.0)
+        d = np.linalg.norm(p[:, :, None, :] - (a + t[..., None] * u), axis=-1) - tab[None, None, :, 3]
+    else:
+        d = np.linalg.norm(p[:, :, None, :] - tab[None, None, :, :3], axis=-1) - tab[None, None, :, 3]
+    off, idx = fleet.get("csr_offset"), fleet.get("csr_index")
+    if off is not None:
+        seen = np.zeros((len(p), len(tab)), bool)
+        for r in range(len(p)):
+            seen[r, idx[off[r]:off[r + 1]]] = True
+        d = np.where(seen[:, None, :], d, np.inf)
+    return d.min(axis=(1, 2))
+
+
+def near_contact_fleet(name, base, rng, n=N_NEAR):
+    """n robots of the fleet's own distribution whose smallest clearance lies in [CLEAR_LO, CLEAR_HI]."""
+    from riemannian_motion_policies_amd import configs as Cf
+    sampler = Cf.sample_two_joint_states if base["robot"] == "two_joint" else Cf.sample_panda_states
+    keep = {k: [] for k in ("q", "qd", "goal")}
+    lists = []
+    K = len(base["table"])
+    got = 0
+    while got < n:
+        st = sampler(rng, 4096)
+        cand = dict(base, **st)
+        if base.get("csr_offset") is not None:
+            off, idx = Cf.sample_ragged(rng, 4096, K)
+            cand.update(csr_offset=off, csr_index=idx)
+        c = min_clearance(cand)
+        ok = np.nonzero((c >= CLEAR_LO) & (c <= CLEAR_HI))[0][: n - got]
+        for k in keep:
+            keep[k].append(st[k][ok])
+        if base.get("csr_offset") is not None:
+            lists += [cand["csr_index"][cand["csr_offset"][r]:cand["csr_offset"][r + 1]] for r in ok]
+        got += len(ok)
+    out = dict(base, **{k: np.concatenate(v) for k, v in keep.items()})
+    if base.get("csr_offset") is not None:
+        out["csr_offset"] = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+        out["csr_index"] = np.concatenate(lists).astype(np.int32)
+    return out
+
+
+def main():
+    import oracle as O
+    gold = os.path.join(HERE, "kinematic_tables.json")
+    fleets = perf_fleets()
+    with mp.get_context("fork").Pool(max(1, len(os.sched_getaffinity(0))), initializer=_init_worker, initargs=(gold,)) as pool:
+        perf = {}
+        for name, fl in fleets.items():
+            perf[name + "_qdd_ref32"] = restatement_qdd(pool, fl)
+            # a checksum of the inputs the vectors belong to (the test regenerates them from the seeds and compares)
+            perf[name + "_input_sum"] = np.array([np.float64(fl["q"].astype(np.float64).sum()), np.float64(fl["qd"].astype(np.float64).sum()),
+                                                  np.float64(fl["goal"].astype(np.float64).sum())])
+            r64 = truth_of_the_restatement(fl)
+            e = np.abs(perf[name + "_qdd_ref32"] - r64).max(axis=1)
+            perf[name + "_err_ref32"] = e      # |fp32 restatement - fp64 evaluation of the same function|_inf per robot
+            perf[name + "_scale"] = np.maximum(1.0, np.abs(r64).max(axis=1))
+            a = e <= 1e-5 * perf[name + "_scale"]
+            print(f"{name:20s} robots {len(e)}  restatement within the north star of its fp64 evaluation: {int(a.sum())}  "
+                  f"worst |err| {np.nanmax(e):.3e}  worst relative {np.nanmax(e / perf[name + '_scale']):.3e}", flush=True)
+        np.savez_compressed(os.path.join(HERE, "perf_envelope.npz"), **perf)
+
+        rng = np.random.default_rng(50)
+        near = {}
+        for name in ("config3", "config3c", "config5_two_joint", "config5_panda"):
+            fl = near_contact_fleet(name, fleets[name], rng)
+            _, desc = desc_of(fl)
+            kw = obstacle_kwargs(fl)
+            r32 = O.step(desc, fl["q"], fl["qd"], fl["goal"], precision="f32", **kw)
+            r64 = O.step(desc, fl["q"], fl["qd"], fl["goal"], precision="f64", **kw)
+            ta = restatement_qdd(pool, fl)
+            near[f"{name}_qdd_pairs_f64"] = truth_of_the_restatement(fl)
+            for k in ("q", "qd", "goal"):
+                near[f"{name}_{k}"] = fl[k]
+            near[f"{name}_table"] = fl["table"]
+            if fl.get("csr_offset") is not None:
+                near[f"{name}_csr_offset"], near[f"{name}_csr_index"] = fl["csr_offset"], fl["csr_index"]
+            near[f"{name}_clearance"] = min_clearance(fl)
+            near[f"{name}_qdd_ref32"] = ta
+            near[f"{name}_qdd_c32"] = r32["qdd64"]
+            near[f"{name}_qdd_f64"] = r64["qdd64"]
+            near[f"{name}_M_f64"], near[f"{name}_f_f64"] = r64["M"], r64["f"]
+            e_ta = np.abs(ta - near[f"{name}_qdd_pairs_f64"]).max(axis=1)
+            e_c = np.abs(r32["qdd64"] - r64["qdd64"]).max(axis=1)
+            print(f"near-contact {name:18s} clearance {near[f'{name}_clearance'].min():.4f}..{near[f'{name}_clearance'].max():.4f}  "
+                  f"|qdd| up to {np.abs(r64['qdd64']).max():.1f}  err_ref32 median {np.median(e_ta):.2e} max {e_ta.max():.2e}  "
+                  f"err_c32 median {np.median(e_c):.2e} max {e_c.max():.2e}", flush=True)
+        np.savez_compressed(os.path.join(HERE, "near_contact.npz"), **near)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+D_STATUS_NONFINITE = 1   # include/rmp2.h RMP2_STATUS_NONFINITE
 
 ATOL = 1e-5
 
@@ -631,3 +632,63 @@ def test_explicit_pairs_streamed_by_lds_dma(torch_mod, R):
     c = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl1, p_obs=po))
     torch.cuda.synchronize()
     assert torch.equal(b, c) or torch.equal(torch.nan_to_num(b), torch.nan_to_num(c)), "the fall-back must be the register-load form"
+
+
+@pytest.mark.parametrize("R,solve", [(16411, "auto"), (40000, "pinv"), (65536, "pinv")])
+def test_explicit_pairs_streamed_pair_phase_before_the_pull_back(torch_mod, R, solve):
+    """Interface B in its streamed form (round 5; rmp2_quad.h kObsExplicitStream): the pair phase of all leaf frames runs BEFORE any
+    pull-back -- pair arrays by LDS-DMA through the frame records' LDS, sums per frame kept in registers, 128 registers and 9.6 KB of
+    LDS per wave (sixteen waves per CU) -- and the frame loop then pulls the stored sums back.  Same pairs, same formulae as the
+    single-loop form (RMP2_EXPLICIT_STREAM=0), summed in another order: equal to fp32 rounding of the sums, tail robots included;
+    right against the oracle (every robot through the gate); the default dispatch takes it from four waves per SIMD on (65 536
+    robots) and a layout the DMA cannot take falls back to the single-loop form by itself."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config3(solve)
+    rng = np.random.default_rng(R)
+    s = Cf.sample_panda_states(rng, R)
+    sph = Cf.sample_spheres(rng)
+    sph[:, 2] += np.float32(0.4)
+    q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
+    eng = Engine(desc, 0) if R == 65536 else _engine_env(desc, RMP2_EXPLICIT_STREAM="1")
+    old = _engine_env(desc, RMP2_EXPLICIT_STREAM="0")
+    pl, po = eng.closest_points(q, eng.obstacles(spheres=torch.from_numpy(sph)))
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    a = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl, p_obs=po), status=st)
+    assert "streamed" in eng.last_kernel(), eng.last_kernel()
+    b = old.step(q, qd, goal, obstacles=old.obstacles(p_link=pl, p_obs=po))
+    assert "streamed" not in old.last_kernel(), old.last_kernel()
+    torch.cuda.synchronize()
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+    calm = np.abs(bn).max(axis=1) <= 50.0
+    assert np.array_equal(np.isfinite(an).all(axis=1), np.isfinite(bn).all(axis=1))
+    assert (np.abs(an - bn).max(axis=1)[calm] <= 2e-6 * np.maximum(1.0, np.abs(bn).max(axis=1))[calm]).all()
+    sub = np.unique(np.concatenate([np.arange(64), np.arange(R - 64, R), rng.integers(0, R, 384)]))
+    kw = dict(p_link=pl[sub].cpu().numpy(), p_obs=po[sub].cpu().numpy())
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], **kw)
+    truth = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], precision="f64", **kw)["qdd64"]
+    verdict = O.accuracy_gate(an[sub], ref, truth=truth, envelope=O.fp32_envelope(desc, s["q"][sub], s["qd"][sub], s["goal"][sub], **kw))
+    assert verdict["ok"].all(), O.gate_summary(verdict)
+    assert not (st.cpu().numpy() & D_STATUS_NONFINITE).any()
+    # a view shifted by one float: addresses the 16-byte DMA cannot take -> the single-loop form, bit for bit
+    pl1 = torch.empty(pl.numel() + 4, dtype=torch.float32, device="cuda")[1:1 + pl.numel()].view_as(pl)
+    pl1.copy_(pl)
+    c = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl1, p_obs=po))
+    assert "streamed" not in eng.last_kernel()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(c))
+    # a NaN joint and a NaN pair: the robot answers NaN + status bit, its neighbours are untouched
+    q2 = q.clone()
+    q2[5, 2] = float("nan")
+    pl2 = pl.clone()
+    pl2[21, 40, 1] = float("nan")
+    d = eng.step(q2, qd, goal, obstacles=eng.obstacles(p_link=pl2, p_obs=po), status=st)
+    assert "streamed" in eng.last_kernel()
+    torch.cuda.synchronize()
+    dn, stn = d.cpu().numpy(), st.cpu().numpy()
+    assert np.isnan(dn[5]).all() and np.isnan(dn[21]).all() and (stn[[5, 21]] & D_STATUS_NONFINITE).all()
+    keep = np.ones(R, bool)
+    keep[[5, 21]] = False
+    assert np.array_equal(dn[keep], an[keep])

@@ -1,5 +1,19 @@
-"""Distribution of the accuracy verdicts (oracle.accuracy_gate) over the unrestricted perf fleets the full-size tests and
-bench.py check: how many robots pass the north-star bound (A), how many only the backward bound (B), how many neither."""
+"""Accuracy survey of the BASELINE perf fleets (round 5; profiles/r05_accuracy_survey.txt): for the first 2 048 robots of every
+perf fleet -- the fleets of tests/golden/make_perf_envelope.py: configs 2, 3, 3b (config 3 through explicit pairs), 3c, 5 (both robot
+types) -- the engine's error against the fp64 evaluation next to the errors of the two fp32 evaluations of the reference's graph
+that exist here:
+
+    err_engine   |engine - fp64|_inf          (fp64: the C oracle's double build on the interface the engine was fed)
+    err_c32      |C oracle, fp32 leaves - fp64|_inf on the same interface
+    err_ref32    |torch-autograd fp32 restatement - fp64 of the same explicit pairs|_inf   (tests/golden/perf_envelope.npz)
+
+and EVERY clause of oracle.accuracy_gate counted on its own (non-exclusively): A north star, B backward error (with the omega
+distribution, so that eta can be read off the data), C fp32 resolution of the inputs, D fp32 resolution of the system.  The ratio
+column is err_engine / max(err_ref32, err_c32) over the robots outside A: what separates error the KERNEL adds from error any fp32
+evaluation of the algorithm has.  Raw per-robot arrays go to <out>.npz for offline analysis.
+
+    python tools/accuracy_survey.py [n] [out_prefix]
+"""
 import json
 import os
 import sys
@@ -10,57 +24,149 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import oracle as O  # noqa: E402
+import make_perf_envelope as E  # noqa: E402
 from riemannian_motion_policies_amd import configs as Cf  # noqa: E402
 from riemannian_motion_policies_amd.engine import Engine  # noqa: E402
 from riemannian_motion_policies_amd.fleet import MixedFleetShard  # noqa: E402
 
 
-def report(name, got, ref, spread=None):
-    g = O.accuracy_gate(got, ref, spread=spread)
-    bad = ~g["ok"]
-    na = ~g["a"]
-    row = dict(name=name, robots=len(got), A=int(g["a"].sum()), B=int(g["b"].sum()), C=int(g["c"].sum()), nan=int(g["both_nan"].sum()), fail=int(bad.sum()),
-               omega_max_nonA=float(g["omega"][na].max()) if na.any() else 0.0,
-               omega_pcts_nonA=[float(x) for x in np.percentile(g["omega"][na], [50, 90, 99, 100])] if na.any() else [],
-               cond_pcts_nonA=[float(x) for x in np.percentile(g["cond"][na], [50, 90, 100])] if na.any() else [],
-               worst_fail=[dict(omega=float(g["omega"][i]), cond=float(g["cond"][i]), err=float(g["err_inf"][i]),
-                                ref=float(np.abs(ref["qdd64"][i]).max())) for i in np.where(bad)[0][:6]])
+def pct(a, qs=(50, 90, 99, 100)):
+    a = np.asarray(a)
+    a = a[np.isfinite(a)]
+    return [float(f"{x:.3g}") for x in np.percentile(a, qs)] if a.size else []
+
+
+def envelope_without_the_plain_draw(desc, q, qd, goal, kw, base, samples=16, seed=1):
+    """oracle.fp32_envelope's perturbed draws only (another seed): the envelope the PLAIN fp32 evaluation is held against in the
+    control column -- built without it, as the engine's envelope is built without the engine."""
+    rng = np.random.default_rng(seed)
+    eps = np.float64(2.0 ** -23)
+
+    def jiggle(a):
+        a = np.ascontiguousarray(a, dtype=np.float32).astype(np.float64)
+        return (a + rng.choice(np.array([-1.0, 1.0]), a.shape) * eps * np.maximum(np.abs(a), 1.0)).astype(np.float32)
+    env = np.zeros(len(q))
+    with np.errstate(invalid="ignore"):
+        for _ in range(samples):
+            kk = {k: (jiggle(v) if k in ("spheres", "p_link", "p_obs", "dist") else v) for k, v in kw.items()}
+            r = O.step(desc, jiggle(q), jiggle(qd), jiggle(goal), precision="f32", **kk)["qdd64"]
+            env = np.fmax(env, np.abs(r - base).max(axis=1))
+    return env
+
+
+def survey_row(name, got, kw, fleet, desc, err_ref32, raw):
+    """One line of the survey + the raw arrays.  kw: the oracle's obstacle arguments of the interface the engine was fed."""
+    q, qd, goal = fleet["q"], fleet["qd"], fleet["goal"]
+    n = len(q)
+    r64 = O.step(desc, q, qd, goal, precision="f64", **kw)
+    c32 = O.step(desc, q, qd, goal, precision="f32", **kw)
+    spread = O.ulp_spread(desc, q, qd, goal, **kw)
+    sysres = O.system_resolution(c32)
+    truth = r64["qdd64"]
+    scale = np.maximum(1.0, np.abs(truth).max(axis=1))
+    with np.errstate(invalid="ignore"):
+        e_eng = np.abs(got.astype(np.float64) - truth).max(axis=1)
+        e_c32 = np.abs(c32["qdd64"] - truth).max(axis=1)
+    e_ref = np.zeros(n) if err_ref32 is None else np.asarray(err_ref32)[:n]
+    env = np.maximum(e_ref, e_c32)
+    # the fp32 envelope the gate uses (clause E): 17 fp32 evaluations on inputs moved by an fp32 rounding, and the restatement's own
+    # error; `control`: the PLAIN fp32 evaluation against an envelope built from 16 OTHER draws -- what a faithful evaluation's ratio
+    # looks like, for the engine's to be read against
+    env17 = np.maximum(O.fp32_envelope(desc, q, qd, goal, **kw), e_ref)
+    env_ctl = np.maximum(envelope_without_the_plain_draw(desc, q, qd, goal, kw, r64["qdd64"]), e_ref)
+    # the gate as the tests and bench.py call it (reference = the reference-precision oracle), every clause on its own
+    g = O.accuracy_gate(got, c32, spread=np.fmax(spread, e_c32), system_spread=sysres)
+    A = g["a"]
+    # accuracy_gate returns b / c / d EXCLUSIVE of the earlier clauses; here each clause is counted on its own (the forward and
+    # minimum-norm riders of B only matter for rank-dropping systems, which these fleets do not hold)
+    omega, fin = g["omega"], np.isfinite(got).all(axis=1)
+    B_incl = fin & (omega <= 1e-4)
+    C_incl = fin & (g["err_inf"] <= 8.0 * np.fmax(spread, e_c32))
+    D_incl = fin & (g["err_inf"] <= 8.0 * sysres)
+    A64 = e_eng <= 1e-5 * scale
+    nonA = ~(A | A64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(env > 0, e_eng / env, np.inf)
+        ratio_c = np.where(e_c32 > 0, e_eng / e_c32, np.inf)
+        ratio17 = np.where(env17 > 0, e_eng / env17, np.inf)
+        ratio_ctl = np.where(env_ctl > 0, e_c32 / env_ctl, np.inf)
+    non_c = e_c32 > 1e-5 * scale
+    row = dict(fleet=name, robots=n, A_vs_c32=int(A.sum()), A_vs_f64=int(A64.sum()), B_omega_le_1e4=int(B_incl.sum()),
+               B_omega_le_2e5=int((fin & (omega <= 2e-5)).sum()), C_x8=int(C_incl.sum()), D_x8=int(D_incl.sum()),
+               passes_gate=int(g["ok"].sum()), outside_A=int(nonA.sum()),
+               omega_pcts_outside_A=pct(omega[nonA]), omega_max_all=float(np.nanmax(omega)),
+               rel_err_engine_pcts_outside_A=pct((e_eng / scale)[nonA]), rel_err_c32_pcts_outside_A=pct((e_c32 / scale)[nonA]),
+               rel_err_ref32_pcts_outside_A=pct((e_ref / scale)[nonA]),
+               ratio_engine_over_envelope_pcts=pct(ratio[nonA]), ratio_gt_2=int((ratio[nonA] > 2).sum()), ratio_gt_8=int((ratio[nonA] > 8).sum()),
+               ratio_engine_over_c32_pcts=pct(ratio_c[nonA]),
+               E_ratio_engine_over_envelope17_pcts=pct(ratio17[nonA]), E_ratio_gt_1=int((ratio17[nonA] > 1).sum()),
+               E_ratio_gt_2=int((ratio17[nonA] > 2).sum()),
+               control_ratio_c32_over_envelope16_pcts=pct(ratio_ctl[non_c]), control_gt_1=int((ratio_ctl[non_c] > 1).sum()),
+               control_gt_2=int((ratio_ctl[non_c] > 2).sum()),
+               rel_err_all_robots_pcts_engine=pct(e_eng / scale, (50, 90, 99, 99.9)), rel_err_all_robots_pcts_c32=pct(e_c32 / scale, (50, 90, 99, 99.9)),
+               c32_outside_A_of_f64=int((e_c32 > 1e-5 * scale).sum()), ref32_outside_A=int((e_ref > 1e-5 * scale).sum()))
     print(json.dumps(row), flush=True)
+    for k, v in dict(got=got, truth=truth, c32=c32["qdd64"], e_ref32=e_ref, spread=spread, sysres=sysres, omega=omega, cond=g["cond"], env17=env17).items():
+        raw[f"{name}__{k}"] = v
+    return row
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    for rank in (0, 7):
-        shard = MixedFleetShard.synthetic(262144, 8, rank, 0)
-        shard.step()
+    out_prefix = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r05", "accuracy_survey")
+    env = np.load(os.path.join(ROOT, "tests", "golden", "perf_envelope.npz"))
+    fleets = E.perf_fleets(n)
+    raw, rows = {}, []
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    for solve in ("pinv", "auto"):
+        # ---- config 2 (4 096 robots) ----
+        fl = fleets["config2"]
+        _, desc = Cf.config2(solve)
+        s = Cf.sample_panda_states(np.random.default_rng(1), 4096)
+        eng = Engine(desc, 0)
+        out = eng.step(t(s["q"]), t(s["qd"]), t(s["goal"]))
         torch.cuda.synchronize()
-        for key, part in shard.parts.items():
-            q, qd, goal, _ = part["keep"]
-            h = part["host"]
-            m = min(n, part["n"])
-            off = h["csr_offset"][: m + 1]
-            ref = O.step(part["desc"], q[:m].cpu().numpy(), qd[:m].cpu().numpy(), goal[:m].cpu().numpy(),
-                         spheres=h["spheres"], csr_offset=off, csr_index=h["csr_index"][: off[-1]])
-            report(f"config5 rank {rank} {key}", part["out"][:m].cpu().numpy(), ref)
-        del shard
-    for solve in ("auto", "pinv"):
+        rows.append(survey_row(f"config2 solve={solve}", out[:n].cpu().numpy(), {}, fl, desc, env["config2_err_ref32"], raw))
+        # ---- config 3 / 3c (65 536 robots, shared table) and 3b (explicit pairs of the first n robots' states over the fleet) ----
+        s = Cf.sample_panda_states(np.random.default_rng(1), 65536)
         _, desc = Cf.config3(solve)
         eng = Engine(desc, 0)
-        s = Cf.sample_panda_states(np.random.default_rng(1), 65536)
-        sph = Cf.sample_spheres(np.random.default_rng(7), Cf.N_SPHERES)
-        out = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
-                       obstacles=eng.obstacles(spheres=torch.from_numpy(sph)))
-        torch.cuda.synchronize()
-        ref = O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], spheres=sph)
-        report(f"config3 perf inputs solve={solve} ({eng.last_kernel()[:40]})", out[:n].cpu().numpy(), ref)
-        if solve == "auto":
-            caps = Cf.sample_capsules(np.random.default_rng(7), Cf.N_SPHERES)
-            out = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
-                           obstacles=eng.obstacles(spheres=torch.from_numpy(caps)))
+        q, qd, goal = t(s["q"]), t(s["qd"]), t(s["goal"])
+        for name in ("config3", "config3c"):
+            fl = fleets[name]
+            out = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=t(fl["table"])))
             torch.cuda.synchronize()
-            sp = O.fp32_resolution(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], spheres=caps)
-            report("config3c capsules", out[:n].cpu().numpy(), O.step(desc, s["q"][:n], s["qd"][:n], s["goal"][:n], spheres=caps), sp)
+            rows.append(survey_row(f"{name} solve={solve} [{eng.last_kernel()[:28]}]", out[:n].cpu().numpy(), dict(spheres=fl["table"]), fl, desc,
+                                   env[name + "_err_ref32"], raw))
+        # interface B: the explicit pairs the restatement read (fp64 kinematics rounded to fp32), tiled over a full-size fleet so that
+        # the kernel that runs is the perf fleet's
+        fl = fleets["config3"]
+        pl, po = E.pair_arrays(fl)
+        reps = 65536 // n
+        qb, qdb, gb = (t(np.tile(fl[k], (reps, 1))) for k in ("q", "qd", "goal"))
+        out = eng.step(qb, qdb, gb, obstacles=eng.obstacles(p_link=t(np.tile(pl, (reps, 1, 1))), p_obs=t(np.tile(po, (reps, 1, 1)))))
+        torch.cuda.synchronize()
+        rows.append(survey_row(f"config3b solve={solve} [{eng.last_kernel()[:28]}]", out[:n].cpu().numpy(), dict(p_link=pl, p_obs=po), fl, desc,
+                               env["config3_err_ref32"], raw))
+        del eng
+        # ---- config 5: rank 0 (TwoJoint) and rank 7 (Panda) of the 8-rank cut ----
+        for rank, key, name in ((0, "two_joint", "config5_two_joint"), (7, "panda", "config5_panda")):
+            shard = MixedFleetShard.synthetic(262144, 8, rank, 0, solve=solve)
+            shard.step()
+            torch.cuda.synchronize()
+            part = shard.parts[key]
+            fl = fleets[name]
+            m = len(fl["q"])
+            assert np.array_equal(part["keep"][0][:m].cpu().numpy(), fl["q"])
+            rows.append(survey_row(f"{name} solve={solve} [{part['engine'].last_kernel()[:28]}]", part["out"][:m].cpu().numpy(),
+                                   E.obstacle_kwargs(fl), fl, part["desc"], env[name + "_err_ref32"], raw))
+            del shard
+    np.savez_compressed(out_prefix + "_raw.npz", **raw)
+    json.dump(rows, open(out_prefix + ".json", "w"), indent=1)
 
 
 if __name__ == "__main__":
