@@ -167,6 +167,12 @@ typedef struct rmp2_desc {
 
 #define RMP2_PRIM_SPHERE 0
 #define RMP2_PRIM_CAPSULE 1
+#define RMP2_PRIM_CYLINDER 2 /* record = 8 floats (cx, cy, cz, radius, ux, uy, uz, half_height): a finite cylinder with FLAT caps, centre c, unit
+                              * axis u -- the reference's own obstacle primitive (simulation.py:245-261: pybullet.GEOM_CYLINDER).  Table modes:
+                              * x = signed distance of the control point to the cylinder's surface, direction = its outward normal there
+                              * (side, cap or rim).  rmp2_closest_points[_links]: the nearest points of the link (its capsule, or the frame
+                              * origin) and the cylinder's surface.  Not with link_capsules fused into the step (that closed form is an
+                              * iteration: run the stage and feed EXPLICIT_PAIRS). */
 
 typedef struct rmp2_obstacles {
   int32_t mode;
@@ -248,9 +254,11 @@ int rmp2_validate(const rmp2_desc *desc);
  *                                         compaction of the in-range pairs (built and parity-tested in round 4; measured no faster than
  *                                         the register loads -- the mode is bound by the bytes a CU can keep in flight beside the frame
  *                                         records in LDS --, so it is off by default)
- *   RMP2_EXPLICIT_STREAM = 0 | 1          (rmp2_create) EXPLICIT_PAIRS, plain control step: never / at every throughput grid take the
- *                                         streamed form (pair phase of all leaf frames before the pull-back, pair arrays by LDS-DMA
- *                                         through the frame records' LDS, four waves per SIMD); unset: from four waves per SIMD on
+ *   RMP2_EXPLICIT_STREAM = 1              (rmp2_create) EXPLICIT_PAIRS, plain control step: the streamed form (pair phase of all leaf
+ *                                         frames before the pull-back, pair arrays by LDS-DMA through the frame records' LDS, four
+ *                                         waves per SIMD) -- built, parity-tested and measured in round 5: not faster while the whole
+ *                                         fleet is one round of waves, so it is off by default
+ *   RMP2_STREAM_STAGGER = n               (rmp2_create) with it: start offset between the four waves of a SIMD (units of 3.4 us; A/B)
  *   RMP2_STRICT_CERTIFY = 0               (rmp2_create) solve = PINV: the Jacobi pseudo-inverse on EVERY robot (two kernels) instead of
  *                                         the certifying one-launch step -- the A/B the equality test of the two is built on
  * Further A/B knobs (RMP2_PRIO_TAIL, RMP2_HEX_WAVES, RMP2_QUAD_LATENCY_BLOCKS) exist only in builds compiled with

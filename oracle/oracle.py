@@ -47,7 +47,7 @@ def _ptr(a, ctype):
 
 
 def make_obstacles(desc: D.Desc, *, spheres=None, p_link=None, p_obs=None, pair_counts=None, csr_offset=None,
-                   csr_index=None, dist=None):
+                   csr_index=None, dist=None, primitive=None):
     """Host-pointer `rmp2_obstacles`; returns (struct, keepalive)."""
     o = D.Obstacles()
     keep = []
@@ -80,6 +80,9 @@ def make_obstacles(desc: D.Desc, *, spheres=None, p_link=None, p_obs=None, pair_
         spheres = np.ascontiguousarray(spheres, dtype=np.float32)
         assert spheres.ndim == 2 and spheres.shape[1] in (4, 8)
         o.primitive = D.PRIM_CAPSULE if spheres.shape[1] == 8 else D.PRIM_SPHERE
+        if primitive == "cylinder":   # (centre, radius, unit axis, half height): the reference's flat-capped cylinders
+            assert spheres.shape[1] == 8
+            o.primitive = D.PRIM_CYLINDER
         o.n_spheres = spheres.shape[0]
         o.spheres = spheres.ctypes.data
         keep.append(spheres)

@@ -519,6 +519,50 @@ static int pinv_solve(int n, const double *M, const double *f, double *x) {
 
 /* ------------------------------------------------------------------------------------ */
 /* One robot: RmpCore.evaluate   rmp.py:133-155                                            */
+/* Finite cylinder with flat caps, record (centre xyz, radius, unit axis xyz, half height): nearest point Y of its SURFACE to p, the
+ * outward unit normal n there and the signed distance sd (p = Y + sd n; negative inside).  Outside: the nearest point of the solid
+ * (axial coordinate clamped to [-h, h], radial to [0, r]: side, cap or rim); inside: the nearer of side and cap.  On the axis the
+ * radial direction is a fixed perpendicular of the axis (rmp2_device.h point_cylinder takes the same one). */
+static void point_cylinder(const float *rec, const real *p, real *Y, real *n, real *sd) {
+  const real c[3] = {(real)rec[0], (real)rec[1], (real)rec[2]}, r = (real)rec[3];
+  const real u[3] = {(real)rec[4], (real)rec[5], (real)rec[6]}, h = (real)rec[7];
+  real w[3], rv[3], e[3];
+  for (int k = 0; k < 3; ++k) w[k] = p[k] - c[k];
+  const real a = dot3(w, u);
+  for (int k = 0; k < 3; ++k) rv[k] = w[k] - a * u[k];
+  const real rho = R_SQRT(dot3(rv, rv));
+  if (rho > 0) {
+    for (int k = 0; k < 3; ++k) e[k] = rv[k] / rho;
+  } else {
+    const real ax = u[0] < 0 ? -u[0] : u[0], ay = u[1] < 0 ? -u[1] : u[1], az = u[2] < 0 ? -u[2] : u[2];
+    const int kx = ax <= ay && ax <= az, ky = !kx && ay <= az;
+    const real t[3] = {kx ? 1 : 0, ky ? 1 : 0, (!kx && !ky) ? 1 : 0};
+    real cr[3];
+    cross3(u, t, cr);
+    const real cn = R_SQRT(dot3(cr, cr));
+    for (int k = 0; k < 3; ++k) e[k] = cr[k] / cn;
+  }
+  const real sa = a < 0 ? -1 : 1;
+  const real da = (a < 0 ? -a : a) - h, dr = rho - r;
+  real ac, rc;
+  if (da <= 0 && dr <= 0) {
+    if (dr >= da) {
+      ac = a, rc = r, *sd = dr;
+      for (int k = 0; k < 3; ++k) n[k] = e[k];
+    } else {
+      ac = sa * h, rc = rho, *sd = da;
+      for (int k = 0; k < 3; ++k) n[k] = sa * u[k];
+    }
+  } else {
+    ac = a < -h ? -h : (a > h ? h : a);
+    rc = rho < r ? rho : r;
+    const real ga = a - ac, gr = rho - rc;
+    *sd = R_SQRT(ga * ga + gr * gr);
+    for (int k = 0; k < 3; ++k) n[k] = (ga * u[k] + gr * e[k]) / *sd;
+  }
+  for (int k = 0; k < 3; ++k) Y[k] = c[k] + ac * u[k] + rc * e[k];
+}
+
 static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32, const float *goal,
                      const rmp2_obstacles *obs, const float *p_link, const float *p_obs, const float *dist,
                      const int32_t *csr_idx, int csr_n, double *Mc, double *fc, unsigned char lz[FMAX][FMAX]) {
@@ -615,7 +659,13 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
            * (it divides by the SURFACE distance d) */
           const int s = (obs->mode == RMP2_OBS_RAGGED_SPHERES) ? csr_idx[b] : b;
           const int cap = obs->primitive == RMP2_PRIM_CAPSULE;
-          const float *sp = obs->spheres + (cap ? 8 : 4) * s;
+          const float *sp = obs->spheres + (obs->primitive == RMP2_PRIM_SPHERE ? 4 : 8) * s;
+          if (obs->primitive == RMP2_PRIM_CYLINDER) {
+            /* the reference's own obstacle primitive (simulation.py:245-261): nearest point of the cylinder's surface to the control
+             * point, signed distance along the outward normal there -- the same semantics as the sphere form */
+            real Ys[3];
+            point_cylinder(sp, pj, Ys, nh, &d);
+          } else {
           real ctr[3] = {(real)sp[0], (real)sp[1], (real)sp[2]};
           if (cap) { /* nearest point of the segment a-b to the control point (calculate_distances
                       * stage, simulation.py:462-484, for a point-vs-capsule pair) */
@@ -633,6 +683,7 @@ static void step_one(const rmp2_desc *desc, const float *q32, const float *qd32,
           const real dc = R_SQRT(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
           d = dc - (real)sp[3];
           for (int k = 0; k < 3; ++k) nh[k] = diff[k] / dc;
+          }
         }
         real Jd[1][NMAX];
         for (int j = 0; j < n; ++j) Jd[0][j] = nh[0] * Jp[0][j] + nh[1] * Jp[1][j] + nh[2] * Jp[2][j];

@@ -324,3 +324,116 @@ def pairs_from_link_capsules(T: np.ndarray, link_capsules: np.ndarray, table: np
     p_link = X - rl[None, :, None, None] * n
     p_obs = Y + ro[None, None, :, None] * n
     return p_link.reshape(R, Cn * K, 3).astype(np.float32), p_obs.reshape(R, Cn * K, 3).astype(np.float32)
+
+
+# ---- the reference's own obstacle primitive: finite cylinders with flat caps (simulation.py:245-261) ---------------------------
+
+def cylinder_record(position, rpy, radius, height) -> np.ndarray:
+    """(cx, cy, cz, radius, ux, uy, uz, half_height) of a `Cylinder(base_position, base_orientation, radius, height)` of the reference
+    (simulation.py:245-261; the orientation is an Euler triple handed to PyBullet's getQuaternionFromEuler: R = Rz(yaw) Ry(pitch)
+    Rx(roll), the cylinder's axis is its local z)."""
+    roll, pitch, yaw = (float(a) for a in rpy)
+    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    axis = np.array([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr])
+    return np.concatenate([np.asarray(position, np.float64), [radius], axis / np.linalg.norm(axis), [0.5 * height]]).astype(np.float32)
+
+
+# experiments/franka_panda/06_cluttered_environment.py:39-52: the seven cylinders of the cluttered scene
+EXP06_CYLINDERS = np.stack([
+    cylinder_record([0.35, -0.2, 0.55], [0.1, 0, 0], 0.025, 0.2),
+    cylinder_record([0.1, -0.4, 0.125], [0.1, 0, 0], 0.025, 0.3),
+    cylinder_record([0.33, -0.3, 0.7], [-1.7, 0.7, 0], 0.025, 0.3),
+    cylinder_record([0.55, 0.5 - 0.25, 0.5], [0.1, 0, 0], 0.025, 0.3),
+    cylinder_record([0.8, 0.5 - 0.25, 0.3], [0.1, 0, 0], 0.025, 0.3),
+    cylinder_record([0.5, 0.5 - 0.1, 0.31], [3.14 / 2, 0, 0], 0.025, 0.3),
+    cylinder_record([0.35 + 0.1, 0.5 - 0.4, 0.11], [3.14 / 2, 0, 0], 0.025, 0.3),
+])
+EXP06_GOAL = np.array([0.2, -0.2, 0.5], dtype=np.float32)   # 06_cluttered_environment.py:36
+
+
+def sample_cylinders(rng: np.random.Generator, K: int = N_SPHERES) -> np.ndarray:
+    """The reference's cylinder clutter as what it is (simulation.py:495-500, the draws of sample_capsules): [K, 8] cylinder records
+    of height 0.5."""
+    r, phi, z = rng.uniform(0.4, 0.9, K), rng.uniform(0, 2 * np.pi, K), rng.uniform(0, 1, K)
+    rpy = rng.uniform(0, np.pi, size=(K, 3))
+    rad = rng.uniform(0.05, 0.1, K)
+    return np.stack([cylinder_record([r[k] * np.cos(phi[k]), r[k] * np.sin(phi[k]), z[k]], rpy[k], rad[k], 0.5) for k in range(K)])
+
+
+def point_cylinder_np(p: np.ndarray, cyl: np.ndarray):
+    """fp64 numpy, independent of the engine and of the C oracle: p [..., 3] against cylinder records cyl [..., 8] (broadcast) ->
+    (Y nearest surface point, n outward unit normal there, sd signed distance: p = Y + sd n).  Outside: nearest point of the solid;
+    inside: the nearer of side and cap.  (tests/test_oracle_pins.py pins it by a brute-force scan of the surface.)"""
+    p = np.asarray(p, np.float64)
+    cyl = np.asarray(cyl, np.float64)
+    c, r, u, h = cyl[..., 0:3], cyl[..., 3], cyl[..., 4:7], cyl[..., 7]
+    w = p - c
+    a = (w * u).sum(-1)
+    rv = w - a[..., None] * u
+    rho = np.linalg.norm(rv, axis=-1)
+    # radial direction; on the axis: the fixed perpendicular the engine takes
+    ax = np.abs(u)
+    kx = (ax[..., 0] <= ax[..., 1]) & (ax[..., 0] <= ax[..., 2])
+    ky = ~kx & (ax[..., 1] <= ax[..., 2])
+    t = np.stack([kx, ky, ~kx & ~ky], axis=-1).astype(np.float64)
+    perp = np.cross(u, t)
+    perp /= np.linalg.norm(perp, axis=-1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e = np.where((rho > 0)[..., None], rv / np.where(rho > 0, rho, 1.0)[..., None], perp)
+    sa = np.where(a < 0, -1.0, 1.0)
+    da, dr = np.abs(a) - h, rho - r
+    inside = (da <= 0) & (dr <= 0)
+    side_in = inside & (dr >= da)
+    cap_in = inside & ~side_in
+    ac = np.where(side_in, a, np.where(cap_in, sa * h, np.clip(a, -h, h)))
+    rc = np.where(side_in, r, np.where(cap_in, rho, np.minimum(rho, r)))
+    Y = c + ac[..., None] * u + rc[..., None] * e
+    ga, gr = a - ac, rho - rc
+    gap = np.sqrt(ga * ga + gr * gr)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n_out = (ga[..., None] * u + gr[..., None] * e) / np.where(gap > 0, gap, 1.0)[..., None]
+    n = np.where(side_in[..., None], e, np.where(cap_in[..., None], sa[..., None] * u, n_out))
+    sd = np.where(side_in, dr, np.where(cap_in, da, gap))
+    return Y, n, sd
+
+
+def pairs_from_cylinders(origins: np.ndarray, cylinders: np.ndarray):
+    """Explicit closest-point pairs of frame-origin control points against a cylinder table, fp64 numpy: origins [R, C, 3],
+    cylinders [K, 8] -> p_link, p_obs [R, C*K, 3] (p_link = the origin, p_obs = the nearest point of the cylinder's surface)."""
+    R, Cn, _ = origins.shape
+    K = cylinders.shape[0]
+    o = np.broadcast_to(origins.astype(np.float64)[:, :, None, :], (R, Cn, K, 3))
+    Y, _, _ = point_cylinder_np(o, cylinders[None, None, :, :])
+    return o.reshape(R, Cn * K, 3).astype(np.float32).copy(), Y.reshape(R, Cn * K, 3).astype(np.float32).copy()
+
+
+def pairs_from_link_capsules_cylinders(T: np.ndarray, link_capsules: np.ndarray, cylinders: np.ndarray, iters: int = 60):
+    """Closest points of LINK capsules and cylinders in fp64 numpy: the signed distance of a point to a convex body is convex along
+    the link's axis, its derivative there n(s) . D monotone -- bisection on its sign (60 halvings).  T [R, C, 4, 4], link_capsules
+    [C, 8], cylinders [K, 8] -> p_link = X - r_link n, p_obs = Y, each [R, C*K, 3]."""
+    T = T.astype(np.float64)
+    R, Cn = T.shape[:2]
+    K = cylinders.shape[0]
+    lc = link_capsules.astype(np.float64)
+    A = (T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 0:3]))[:, :, None, :]
+    B = (T[:, :, :3, 3] + np.einsum("rcij,cj->rci", T[:, :, :3, :3], lc[:, 4:7]))[:, :, None, :]
+    Dv = np.broadcast_to(B - A, (R, Cn, K, 3))
+    cyl = cylinders[None, None, :, :]
+
+    def slope(s):
+        X = A + s[..., None] * Dv
+        Y, n, sd = point_cylinder_np(X, cyl)
+        return (n * Dv).sum(-1), X, Y, n
+
+    g0 = slope(np.zeros((R, Cn, K)))[0]
+    g1 = slope(np.ones((R, Cn, K)))[0]
+    lo, hi = np.zeros((R, Cn, K)), np.ones((R, Cn, K))
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        g = slope(mid)[0]
+        lo = np.where(g < 0, mid, lo)
+        hi = np.where(g < 0, hi, mid)
+    s = np.where(~(g0 < 0), 0.0, np.where(~(g1 > 0), 1.0, 0.5 * (lo + hi)))
+    _, X, Y, n = slope(s)
+    p_link = X - lc[None, :, None, 3:4] * n
+    return p_link.reshape(R, Cn * K, 3).astype(np.float32), Y.reshape(R, Cn * K, 3).astype(np.float32)

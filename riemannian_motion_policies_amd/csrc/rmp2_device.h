@@ -125,9 +125,81 @@ struct ObsArgs {
   const int32_t* __restrict__ pair_begin;  // device copy, [RMP2_MAX_LEAVES + 1]
   const float* __restrict__ dist;          // [R][P] distances of the attached-point leaves
   const float* __restrict__ link_caps;     // [n_distance_leaves][8] link capsules in frame coordinates (table modes), or null
+  int32_t cylinder;  // 1: the 8-float records are finite CYLINDERS (centre, radius, unit axis, half height: RMP2_PRIM_CYLINDER) -- `capsule`
+                     // is then 1 as well (the 8-float-record builds serve both; the closed form per pair is a wave-uniform branch)
   int32_t glds;  // EXPLICIT_PAIRS, plain two-wave quad build: the pair arrays are streamed half a leaf ahead by LDS-DMA (set by
                  // launch_quad when every leaf segment is 16-byte aligned; the launch then carries 6 KiB more LDS per wave)
 };
+
+// The reference's obstacle primitive: a finite CYLINDER with flat caps (simulation.py:245-261: pybullet.GEOM_CYLINDER of radius r and
+// height 2 h at a pose; seven of them in experiments/franka_panda/06_cluttered_environment.py:39-52).  Record (8 floats):
+// ra = (centre xyz, radius), rb = (unit axis xyz, half height).  Nearest point Y of the cylinder's SURFACE to the point p, the
+// outward unit normal n of the surface there and the signed distance sd (p = Y + sd n; negative inside) -- what PyBullet's closest
+// points give the reference for a point-like link shape (simulation.py:462-484): outside, the nearest point of the solid
+// (clamp the axial coordinate to [-h, h] and the radial one to [0, r]: side, cap or rim); inside, the nearer of the side and the
+// cap.  On the axis the radial direction is undefined: a fixed perpendicular of the axis is taken (only the rim and the inside-side
+// cases use it there; distance and position are unaffected).
+__device__ __forceinline__ void point_cylinder(const float4 ra, const float4 rb, const float p[3], float Y[3], float n[3], float& sd) {
+  const float u[3] = {rb.x, rb.y, rb.z};
+  const float r = ra.w, h = rb.w;
+  const float w[3] = {p[0] - ra.x, p[1] - ra.y, p[2] - ra.z};
+  const float a = w[0] * u[0] + w[1] * u[1] + w[2] * u[2];
+  float rv[3] = {w[0] - a * u[0], w[1] - a * u[1], w[2] - a * u[2]};
+  const float rho2 = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+  const float rho = sqrtf(rho2);
+  float e[3];  // unit radial direction
+  if (rho > 0.f) {
+    const float inv = 1.0f / rho;
+    e[0] = rv[0] * inv, e[1] = rv[1] * inv, e[2] = rv[2] * inv;
+  } else {  // on the axis: any unit vector perpendicular to u (cross with the coordinate axis u is least aligned with)
+    const float ax = fabsf(u[0]), ay = fabsf(u[1]), az = fabsf(u[2]);
+    const bool kx = ax <= ay && ax <= az, ky = !kx && ay <= az;
+    const float t[3] = {kx ? 1.f : 0.f, ky ? 1.f : 0.f, (!kx && !ky) ? 1.f : 0.f};
+    const float c[3] = {u[1] * t[2] - u[2] * t[1], u[2] * t[0] - u[0] * t[2], u[0] * t[1] - u[1] * t[0]};
+    const float inv = 1.0f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    e[0] = c[0] * inv, e[1] = c[1] * inv, e[2] = c[2] * inv;
+  }
+  const float sa = a < 0.f ? -1.f : 1.f;
+  const float da = fabsf(a) - h, dr = rho - r;  // signed distances to the cap plane and to the lateral surface
+  float ac, rc;                                  // axial and radial coordinate of Y
+  if (da <= 0.f && dr <= 0.f) {                  // inside (or on the surface): the nearer face
+    if (dr >= da) {                              // lateral surface
+      ac = a, rc = r, sd = dr;
+      n[0] = e[0], n[1] = e[1], n[2] = e[2];
+    } else {                                     // cap
+      ac = sa * h, rc = rho, sd = da;
+      n[0] = sa * u[0], n[1] = sa * u[1], n[2] = sa * u[2];
+    }
+  } else {
+    ac = fminf(fmaxf(a, -h), h), rc = fminf(rho, r);
+    const float ga = a - ac, gr = rho - rc;      // the gap's axial and radial component (one of them 0 off the rim)
+    sd = sqrtf(ga * ga + gr * gr);
+    const float inv = 1.0f / sd;
+    n[0] = (ga * u[0] + gr * e[0]) * inv, n[1] = (ga * u[1] + gr * e[1]) * inv, n[2] = (ga * u[2] + gr * e[2]) * inv;
+  }
+  Y[0] = ra.x + ac * u[0] + rc * e[0], Y[1] = ra.y + ac * u[1] + rc * e[1], Y[2] = ra.z + ac * u[2] + rc * e[2];
+}
+
+// Nearest points of a link segment A + s D (s in [0, 1]) and a cylinder: the signed distance of a point to a convex body is a convex
+// function of the point, so it is convex in s, and its derivative along the segment is n(s) . D with n the outward normal of the
+// nearest surface point -- monotone in s.  Bisection on its sign (24 halvings: the parameter to 6e-8) after the two end tests; every
+// step is one point_cylinder.  (No closed form: the rim case is a quartic.)
+__device__ __forceinline__ void segment_cylinder(const float4 ra, const float4 rb, const float A[3], const float D[3], float X[3],
+                                                 float Y[3], float n[3], float& sd) {
+  auto at = [&](float s) {
+    X[0] = fmaf(s, D[0], A[0]), X[1] = fmaf(s, D[1], A[1]), X[2] = fmaf(s, D[2], A[2]);
+    point_cylinder(ra, rb, X, Y, n, sd);
+    return n[0] * D[0] + n[1] * D[1] + n[2] * D[2];
+  };
+  if (!(at(0.f) < 0.f)) return;       // the distance grows from A on (or the segment is a point): A it is
+  if (!(at(1.f) > 0.f)) return;       // still falling at B
+  float lo = 0.f, hi = 1.f;
+  for (int it = 0; it < 24; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    if (at(mid) < 0.f) lo = mid; else hi = mid;
+  }
+  (void)at(0.5f * (lo + hi));
+}
 
 // Nearest point of the segment a-b (capsule axis) to the control point p: the point-vs-capsule case of the
 // reference's CPU closest-point stage (simulation.py:462-484).  rec = (a.xyz, radius, b.xyz, unused).

@@ -804,10 +804,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
                                           IP, S, h);
           else if (spheres_in_lds)
             pair_loop<kPairsSharedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, s,
-                                                  P3, V3, A3, lh.P, IP, S, h);
+                                                  P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
           else
             pair_loop<kPairsSharedGlobal, CAP, kHex>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres,
-                                                     s, P3, V3, A3, lh.P, IP, S, h);
+                                                     s, P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
         } else if (obs.mode == RMP2_OBS_EXPLICIT_PAIRS) {
           const int lidx = uni<true>(lf.index);
           const int pb = obs.pair_begin[lidx];
@@ -829,10 +829,10 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
                                          IP, S, h);
           else if (spheres_in_lds)
             pair_loop<kPairsRaggedLds, CAP, kHex>(sph_lds_base, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
-                                                  P3, V3, A3, lh.P, IP, S, h);
+                                                  P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
           else
             pair_loop<kPairsRaggedGlobal, CAP, kHex>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, s,
-                                                     P3, V3, A3, lh.P, IP, S, h);
+                                                     P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) S[c] = hex_sum(S[c]);

@@ -271,6 +271,11 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
               }
               float4 sp;
               float ctr[3];
+              if (EXT && obs.cylinder) {  // finite cylinder: nearest surface point, outward normal, signed distance
+                float Yc[3];
+                point_cylinder(reinterpret_cast<const float4*>(obs.spheres)[2 * sidx], reinterpret_cast<const float4*>(obs.spheres)[2 * sidx + 1],
+                               cur.p, Yc, nh, d);
+              } else {
               if (EXT && obs.capsule) {
                 sp = reinterpret_cast<const float4*>(obs.spheres)[2 * sidx];
                 capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * sidx + 1], cur.p, ctr);
@@ -285,6 +290,7 @@ rmp2_step_kernel(const DevProgram* __restrict__ prog, const float* __restrict__ 
               d = dc - sp.w;
 #pragma unroll
               for (int c = 0; c < 3; ++c) nh[c] = diff[c] / dc;
+              }
             }
             const float xdot = dot3(nh, cur.v);
             const float cd = (vv - xdot * xdot) / d + dot3(nh, cur.a);  // c2 + J2 c1 (taskmap.py:159)
@@ -702,6 +708,19 @@ rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict
         }
         const float r_link = lc[3];
         for (int b = 0; b < obs.n_spheres; ++b) {
+          if (obs.cylinder) {  // link capsule against a finite cylinder: nearest points by bisection on the convex distance
+            const float4 ca = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
+            const float4 cb = reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1];
+            const float Dl[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+            float X[3], Y[3], n[3], sd;
+            segment_cylinder(ca, cb, A, Dl, X, Y, n, sd);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              p_link[base + 3 * b + c] = X[c] - r_link * n[c];
+              p_obs[base + 3 * b + c] = Y[c];
+            }
+            continue;
+          }
           float C[3], D[3], r_obs;
           if (obs.capsule) {
             const float4 ca = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
@@ -733,6 +752,16 @@ rmp2_closest_kernel(const DevProgram* __restrict__ prog, const float* __restrict
       for (int b = 0; b < obs.n_spheres; ++b) {
         float4 sp;
         float ctr[3];
+        if (obs.cylinder) {  // frame origin against a finite cylinder: its nearest surface point
+          float Y[3], n[3], sd;
+          point_cylinder(reinterpret_cast<const float4*>(obs.spheres)[2 * b], reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1], cur.p, Y, n, sd);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            p_link[base + 3 * b + c] = cur.p[c];
+            p_obs[base + 3 * b + c] = Y[c];
+          }
+          continue;
+        }
         if (obs.capsule) {
           sp = reinterpret_cast<const float4*>(obs.spheres)[2 * b];
           capsule_centre(sp, reinterpret_cast<const float4*>(obs.spheres)[2 * b + 1], cur.p, ctr);
@@ -830,6 +859,22 @@ rmp2_closest_wave_kernel(const DevProgram* __restrict__ prog, const float* __res
     size_t off = ((size_t)r0 * P + p) * 3;
     for (int r = 0; r < n_live; ++r, off += (size_t)P * 3) {
       const float4 sa = seg[(r * n_dist + leaf) * 2];
+      if (CAPS && obs.cylinder) {  // (wave-uniform) finite cylinders: nearest SURFACE point and outward normal (rmp2_device.h)
+        float Xc[3] = {sa.x, sa.y, sa.z}, Yc[3], nc[3], sd;
+        if (LINK) {
+          const float4 sb = seg[(r * n_dist + leaf) * 2 + 1];
+          const float Al[3] = {sa.x, sa.y, sa.z}, Dl[3] = {sb.x - sa.x, sb.y - sa.y, sb.z - sa.z};
+          segment_cylinder(ca, cb, Al, Dl, Xc, Yc, nc, sd);
+        } else {
+          point_cylinder(ca, cb, Xc, Yc, nc, sd);
+        }
+        if (ok) {
+          const float wl = LINK ? sa.w : 0.f;
+          __builtin_nontemporal_store(f32x3{Xc[0] - wl * nc[0], Xc[1] - wl * nc[1], Xc[2] - wl * nc[2]}, reinterpret_cast<f32x3*>(p_link + off));
+          __builtin_nontemporal_store(f32x3{Yc[0], Yc[1], Yc[2]}, reinterpret_cast<f32x3*>(p_obs + off));
+        }
+        continue;
+      }
       float X[3] = {sa.x, sa.y, sa.z}, Y[3] = {ca.x, ca.y, ca.z};  // nearest points of the two axes
       if (LINK) {
         const float4 sb = seg[(r * n_dist + leaf) * 2 + 1];
@@ -1796,6 +1841,7 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
   if (const char* ce = std::getenv("RMP2_STRICT_CERTIFY")) h->strict_certify = std::atoi(ce) != 0;
   if (const char* ge = std::getenv("RMP2_EXPLICIT_GLDS")) h->explicit_glds = std::atoi(ge) != 0;
   if (const char* se = std::getenv("RMP2_EXPLICIT_STREAM")) h->explicit_stream = std::atoi(se) != 0 ? 1 : 0;
+  if (const char* sg = std::getenv("RMP2_STREAM_STAGGER")) h->stream_stagger = std::max(0, std::min(1023, std::atoi(sg)));  // (bits 8-9: A/B switches of the stream, rmp2_quad.h pair_loop_explicit_glds)
   if (const char* we = std::getenv("RMP2_QUAD_SYM")) h->symmetric = h->symmetric && std::atoi(we) != 0;  // 0 = general form (include/rmp2.h)
   h->n_leaf_ops = P.n_leaf_ops;
   h->hex_levels = P.hex.n_levels;
@@ -1950,8 +1996,11 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
     } else if (o.mode == RMP2_OBS_SHARED_SPHERES || o.mode == RMP2_OBS_RAGGED_SPHERES) {
       if (obs->n_spheres < 0 || (obs->n_spheres > 0 && !obs->spheres))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "sphere table missing");
-      if (obs->primitive != RMP2_PRIM_SPHERE && obs->primitive != RMP2_PRIM_CAPSULE)
+      if (obs->primitive != RMP2_PRIM_SPHERE && obs->primitive != RMP2_PRIM_CAPSULE && obs->primitive != RMP2_PRIM_CYLINDER)
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
+      if (obs->primitive == RMP2_PRIM_CYLINDER && (obs->link_capsules || h->has_point))
+        return fail(h, RMP2_ERR_UNSUPPORTED, "cylinder tables with link geometry / attached-point leaves: the nearest points of a segment and a "
+                                             "cylinder are an iteration -- rmp2_closest_points_links + EXPLICIT_PAIRS");
       if (o.mode == RMP2_OBS_RAGGED_SPHERES && (!obs->csr_offset || (!obs->csr_index && obs->n_spheres > 0)))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
     } else {
@@ -1959,7 +2008,8 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
     }
     o.n_spheres = obs->n_spheres;
     o.n_pairs = obs->n_pairs;
-    o.capsule = (o.mode != RMP2_OBS_EXPLICIT_PAIRS && obs->primitive == RMP2_PRIM_CAPSULE) ? 1 : 0;
+    o.capsule = (o.mode != RMP2_OBS_EXPLICIT_PAIRS && obs->primitive != RMP2_PRIM_SPHERE) ? 1 : 0;   // (8-float records)
+    o.cylinder = (o.mode != RMP2_OBS_EXPLICIT_PAIRS && obs->primitive == RMP2_PRIM_CYLINDER) ? 1 : 0;
     o.spheres = obs->spheres;
     o.p_link = obs->p_link;
     o.p_obs = obs->p_obs;
@@ -2323,7 +2373,7 @@ int rmp2_rollout(rmp2_handle* h, float* q, float* qd, const float* goal, int32_t
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: table_steps must be 0, 1 or n_control_steps");
     if (!obs || (obs->mode != RMP2_OBS_SHARED_SPHERES && obs->mode != RMP2_OBS_RAGGED_SPHERES))
       return fail(h, RMP2_ERR_INVALID_ARGUMENT, "rollout: per-step obstacle tables need a sphere / capsule table mode");
-    ro.table_stride = obs->n_spheres * (obs->primitive == RMP2_PRIM_CAPSULE ? 8 : 4);
+    ro.table_stride = obs->n_spheres * (obs->primitive != RMP2_PRIM_SPHERE ? 8 : 4);
   }
   return step_impl(h, q, qd, goal, goal_stride, obs, out, ro, R, stream);
 }
@@ -2355,7 +2405,7 @@ int rmp2_closest_points_links(rmp2_handle* h, const float* q, const rmp2_obstacl
   if (!q || !table || !p_link || !p_obs || R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "bad argument");
   if (table->mode != RMP2_OBS_SHARED_SPHERES || table->n_spheres < 0 || (table->n_spheres > 0 && !table->spheres))
     return fail(h, RMP2_ERR_INVALID_ARGUMENT, "closest_points needs a SHARED_SPHERES primitive table");
-  if (table->primitive != RMP2_PRIM_SPHERE && table->primitive != RMP2_PRIM_CAPSULE)
+  if (table->primitive != RMP2_PRIM_SPHERE && table->primitive != RMP2_PRIM_CAPSULE && table->primitive != RMP2_PRIM_CYLINDER)
     return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
   if (R == 0 || !h->has_distance || table->n_spheres == 0) return RMP2_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -2378,7 +2428,8 @@ int rmp2_closest_points_links(rmp2_handle* h, const float* q, const rmp2_obstacl
   o.mode = table->mode;
   o.n_spheres = table->n_spheres;
   o.n_pairs = acc;
-  o.capsule = table->primitive == RMP2_PRIM_CAPSULE ? 1 : 0;
+  o.capsule = table->primitive != RMP2_PRIM_SPHERE ? 1 : 0;   // (8-float records)
+  o.cylinder = table->primitive == RMP2_PRIM_CYLINDER ? 1 : 0;
   o.spheres = table->spheres;
   o.pair_begin = h->d_pair_begin;
   const int n_dist = acc / table->n_spheres;

@@ -34,6 +34,7 @@ struct rmp2_handle {
   bool strict_certify = true;  // RMP2_STRICT_CERTIFY=0: the Jacobi pseudo-inverse on every robot (A/B)
   bool link_rows_ok = false;   // <= 1 distance leaf per frame: link geometry may take the lean builds (segments formed in the walk)
   bool explicit_glds = false;  // RMP2_EXPLICIT_GLDS=1: explicit pairs streamed half a leaf ahead by LDS-DMA (measured: no gain)
+  int stream_stagger = 0;    // RMP2_STREAM_STAGGER=n: start offset between the four waves of a SIMD in the streamed explicit-pair step, units of 3.4 us
   int explicit_stream = -1;  // RMP2_EXPLICIT_STREAM=0|1: never / at any throughput grid take the streamed explicit-pair step (A/B; -1: by grid size)
   bool likely_singular = false;  // no positive-definite identity leaf in the set
   int kernel_choice = 0;  // 0 auto, 1 lane-per-robot, 2 quad-per-robot, 3 hex (env RMP2_KERNEL=lane|quad|hex, A/B only)
@@ -104,7 +105,8 @@ inline bool hex_certifies_strict(const rmp2_handle* h) { return h->strict && h->
 inline QuadHdr make_quad_hdr(const rmp2_handle* h) {
   return QuadHdr{h->n_ops_step, h->n_dof, h->n_id_leaves, h->n_leaves, h->goal_floats, h->n_leaf_ops, h->rev_mask,
                  h->hex_levels, h->n_fk_leaves, h->hex_is_chain, {h->dof_ops[0], h->dof_ops[1], h->dof_ops[2]}, h->cull_c0, h->strict ? 1 : 0,
-                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0, h->has_point ? 1 : 0, h->likely_singular ? 1 : 0};
+                 h->prio_tail >= 0 ? h->prio_tail : 0, h->quad_skip_resolve ? 1 : 0, h->has_point ? 1 : 0, h->likely_singular ? 1 : 0,
+                 h->stream_stagger};
 }
 // rmp2_hex_tu.hip (false: the working set does not fit the CU's LDS -- the caller falls back to the quad mapping)
 bool launch_hex_n2(const rmp2_handle* h, const float* q, const float* qd, const float* goal, int gs, const ObsArgs& o,

@@ -198,7 +198,8 @@ template <int MODE, bool CAP, int W = kQuad>
 __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, const float* po, const int32_t* ci,
                                           int count, int max_count, int sub, const float P3[3],
                                           const float V3[3], const float A3[3], const float* P, const float* IP,
-                                          float S[6], float h[3]) {
+                                          float S[6], float h[3], bool cyl = false) {
+  // cyl (CAP builds, wave-uniform): the 8-float records are finite cylinders (rmp2_device.h point_cylinder), not capsules
   const float vv = dot3(V3, V3);
   const int trips = (max_count + W - 1) / W;  // wave-uniform trip count
   // the obstacle record of the NEXT trip is fetched while the current one is evaluated
@@ -247,6 +248,9 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
       d = d2 * inv;
 #pragma unroll
       for (int c = 0; c < 3; ++c) nh[c] = diff[c] * inv;
+    } else if (CAP && cyl) {  // (wave-uniform) the reference's flat-capped cylinder: nearest surface point, outward normal, signed distance
+      float Yc[3];
+      point_cylinder(ca, cb, P3, Yc, nh, d);
     } else {
       float ctr[3] = {ca.x, ca.y, ca.z};
       if (CAP) {  // nearest point of the capsule axis a-b to the control point (rmp2_device.h capsule_centre)
@@ -347,7 +351,7 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
                                                  int sub, const float P3[3], const float V3[3], const float A3[3],
                                                  const float* P, const float* IP, float S[6], float h[3],
                                                  unsigned long long* dbg = nullptr, uint32_t member_lo = 0u,
-                                                 uint32_t member_hi = 0u, const float* caps = nullptr) {
+                                                 uint32_t member_hi = 0u, const float* caps = nullptr, bool cyl = false) {
   static_assert(!(CAPS && W != 4), "capsule culling exists in the quad mapping");
   static_assert(!(RAGGED && MEMBER), "a membership mask replaces the list");
   static_assert(W == 4 || W == 16, "quad or hex");
@@ -429,10 +433,15 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       if (dbg) dbg[0] += 1ull;  // trips of the wave
 #endif
       float diff[3], r;
+      float d_cyl = 0.f, n_cyl[3] = {0.f, 0.f, 0.f};
       if (CAPS) {
         take(on_n, sidx_n);
         ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
         cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+        if (cyl) {  // (wave-uniform) finite cylinder: nearest surface point, outward normal, signed distance
+          float Yc[3];
+          point_cylinder(ca, cb, P3, Yc, n_cyl, d_cyl);
+        }
         // nearest point of the capsule axis a-b to the control point (rmp2_device.h capsule_centre; same arithmetic as the
         // un-culled loop above)
         const float u[3] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z};
@@ -451,8 +460,9 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
       float dn, inv;
       norm_and_inverse(d2, dn, inv);
-      const float d = dn - r;
-      const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+      const bool use_cyl = CAPS && cyl;
+      const float d = use_cyl ? d_cyl : dn - r;
+      const float nh[3] = {use_cyl ? n_cyl[0] : diff[0] * inv, use_cyl ? n_cyl[1] : diff[1] * inv, use_cyl ? n_cyl[2] : diff[2] * inv};
       const float xdot = dot3(nh, V3);
       const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
       float acc, met;
@@ -868,10 +878,13 @@ constexpr int kGldsList = kRobotsPerWave * kGldsListCap * 4;  // floats: [16 qua
 __device__ __forceinline__ void pair_loop_explicit_glds(const float* PL, const float* PO, int n_pairs, int r0, int R, int pb,
                                                         int pb_next, int& pf_pb, float* buf, int lane, int g, int sub,
                                                         const float P3[3], const float V3[3], const float A3[3], const float* P,
-                                                        const float* IP, float thr2, float S[6], float h[3]) {
+                                                        const float* IP, float thr2, float S[6], float h[3], int dbg = 0) {
+  // dbg (tuning builds' A/B only, 0 in the shipped paths): bit 0 = no pair is in range (the stream without the pair arithmetic),
+  // bit 1 = no DMA is issued (the arithmetic on whatever the buffer holds, without the stream)
   const float vv = dot3(V3, V3);
   float* const list = buf + kGldsBuf + g * (kGldsListCap * 4);  // this quad's list
   auto issue = [&](int pbx, int half) __attribute__((always_inline)) {
+    if (dbg & 2) return;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int c = 64 * i + lane;
@@ -931,6 +944,7 @@ __device__ __forceinline__ void pair_loop_explicit_glds(const float* PL, const f
       d2s[i] = df[i][0] * df[i][0] + df[i][1] * df[i][1] + df[i][2] * df[i][2];
       mine |= !(d2s[i] > thr2) ? (1u << i) : 0u;  // (NaN compares "in range")
     }
+    if (dbg & 1) mine = 0u;
     uint32_t m = mine << (kQuad * sub);  // the quad's 16-bit mask: nibble `sub` = lane sub's four slots
     m |= dppu<kXor1>(m);
     m |= dppu<kXor2>(m);
@@ -1027,6 +1041,8 @@ struct QuadHdr {
   int32_t has_point;    // the set carries attached-point leaves (full 16-float rotation records even when link geometry is given)
   int32_t rank1;        // the set has no positive-definite identity leaf: a leaf metric that is rank one is pulled back in its
                         // rank-one form (rmp2_device.h rank_one_of)
+  int32_t stagger;      // streamed explicit pairs (kObsExplicitStream): the wave in slot s of its SIMD starts (s & 3) * stagger * 3.4 us
+                        // late (s_sleep), so that the four waves of a SIMD are not all in their streaming phase at once
 };
 
 __device__ __forceinline__ int gi_loc(int g, int n_ops) { return g * kSlot * quad_slots(n_ops); }
@@ -1143,6 +1159,14 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   // 65 536 robots with two rounds of two waves, 51.5 -> 49.1 at 49 152 with one round of three, 73.0 -> 68.5 for the
   // 128-register build; thirds instead of halves of the frame loop: another 52.5 -> 51.5).
   __builtin_amdgcn_s_setprio(3);
+  if constexpr (OBS == kObsExplicitStream) {
+    // All 4 096 waves of a 65 536-robot fleet are resident at once and would walk, stream and pull back IN STEP: the memory system
+    // idle through everybody's walk, saturated through everybody's pair phase (measured: 53 % of a wave's life in s_waitcnt with
+    // 25 MB in flight across the chip, 116 us per step), idle again through the pull-backs.  The four waves of a SIMD start a
+    // quarter of a streaming phase apart instead: while one streams, its neighbours walk or pull back.
+    const int slot = __builtin_amdgcn_s_getreg(0x1804) & 3;  // HW_ID[3:0]: the wave's slot in its SIMD
+    for (int i = 0; i < slot * (hdr.stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int lane = threadIdx.x;
   const int sub = lane & 3;
   const int g = lane >> 2;
@@ -1180,6 +1204,11 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       for (int i = lane; i < n_sph_lds; i += kWave) {
         const float4 ca = reinterpret_cast<const float4*>(table)[2 * i];
         const float4 cb = reinterpret_cast<const float4*>(table)[2 * i + 1];
+        if (obs.cylinder) {  // (wave-uniform) finite cylinder (centre, radius, axis, half height): centre, sqrt(r^2 + h^2)
+          const float br = sqrtf(ca.w * ca.w + cb.w * cb.w) * 1.000001f;
+          reinterpret_cast<float4*>(sph_lds_base)[i] = sphere_aux(make_float4(ca.x, ca.y, ca.z, br), hdr.cull_c0);
+          continue;
+        }
         const float hx = 0.5f * (cb.x - ca.x), hy = 0.5f * (cb.y - ca.y), hz = 0.5f * (cb.z - ca.z);
         const float hl = sqrtf(hx * hx + hy * hy + hz * hz) * 1.000001f;  // (rounded up: the test must never under-cover)
         reinterpret_cast<float4*>(sph_lds_base)[i] =
@@ -1750,7 +1779,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
             const int pb_next = nxt >= 0 ? obs.pair_begin[nxt] : -1;
             const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
             pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, dma, lane, g, sub, P3, V3, A3, lh.P,
-                                    IP, thr * thr * kCullSlack, S, h);
+                                    IP, thr * thr * kCullSlack, S, h, hdr.stagger >> 8);
 #pragma unroll
             for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
 #pragma unroll
@@ -2024,14 +2053,14 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               if (spheres_in_lds)
   #ifdef RMP2_STAMPS
                 pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                       V3, A3, lh.P, IP, S, h, &seg_[5], 0u, 0u, step_table);
+                                                                       V3, A3, lh.P, IP, S, h, &seg_[5], 0u, 0u, step_table, obs.cylinder != 0);
   #else
                 pair_loop_culled<false, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                       V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
+                                                                       V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table, obs.cylinder != 0);
   #endif
               else
                 pair_loop<kPairsSharedGlobal, CAP>(step_table, nullptr, nullptr, nullptr, obs.n_spheres, obs.n_spheres, sub,
-                                              P3, V3, A3, lh.P, IP, S, h);
+                                              P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
             } else if (obs_mode == RMP2_OBS_EXPLICIT_PAIRS) {
               const int lidx = uni<STAGE>(lf.index);
               const int pb = obs.pair_begin[lidx];
@@ -2053,7 +2082,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
                                                                               lh.P, IP, thr * thr * kCullSlack, S, h);
             } else if (use_member) {  // (wave-uniform) ragged list as a membership mask: the dense loop, masked
               pair_loop_culled<false, kQuad, (MINW >= 2), true, CAP>(sph_lds, n_sph_lds, nullptr, obs.n_spheres, obs.n_spheres, sub, P3,
-                                                                    V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table);
+                                                                    V3, A3, lh.P, IP, S, h, nullptr, member_lo, member_hi, step_table, obs.cylinder != 0);
             } else {
               int rr_ = live ? robot : 0;  // (opaque copy: the two 64-bit addresses are formed here, not in the prologue)
               if (MINW >= 3) asm volatile("" : "+v"(rr_));
@@ -2064,10 +2093,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               for (int o = 32; o >= kQuad; o >>= 1) max_count = max(max_count, __shfl_xor(max_count, o));
               if (spheres_in_lds)
                 pair_loop_culled<true, kQuad, (MINW >= 2), false, CAP>(sph_lds, n_sph_lds, obs.csr_index + b0, count, max_count, sub, P3,
-                                                                      V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table);
+                                                                      V3, A3, lh.P, IP, S, h, nullptr, 0u, 0u, step_table, obs.cylinder != 0);
               else
                 pair_loop<kPairsRaggedGlobal, CAP>(step_table, nullptr, nullptr, obs.csr_index + b0, count, max_count, sub,
-                                              P3, V3, A3, lh.P, IP, S, h);
+                                              P3, V3, A3, lh.P, IP, S, h, obs.cylinder != 0);
             }
             RMP2_SEG(2);  // distance leaf: cull + pair trips
   #pragma unroll

@@ -47,6 +47,7 @@ OBS_RAGGED_SPHERES = 3
 
 PRIM_SPHERE = 0
 PRIM_CAPSULE = 1
+PRIM_CYLINDER = 2   # (cx, cy, cz, radius, ux, uy, uz, half_height): finite cylinder, flat caps (simulation.py:245-261)
 
 STATUS_NONFINITE = 1
 STATUS_RANK_DROP = 2

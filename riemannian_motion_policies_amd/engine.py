@@ -67,7 +67,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------
     def obstacles(self, *, spheres=None, p_link=None, p_obs=None, pair_counts: Optional[Sequence[int]] = None,
-                  csr_offset=None, csr_index=None, dist=None, link_capsules=None):
+                  csr_offset=None, csr_index=None, dist=None, link_capsules=None, primitive: Optional[str] = None):
         """Build the per-step `rmp2_obstacles` struct from device tensors (kept alive by the result).
         link_capsules [n_distance_leaves, 8] = (a, radius, b, -) per distance leaf, in its frame's coordinates
         (urdf.link_capsules), with a shared table `spheres`: the control point of a pair is the nearest point of the link's
@@ -118,7 +118,18 @@ class Engine:
             if spheres.dim() != 2 or spheres.shape[1] not in (4, 8):
                 raise ValueError("spheres must be [K, 4] = (cx, cy, cz, radius) or, for capsules, "
                                  "[K, 8] = (ax, ay, az, radius, bx, by, bz, unused)")
-            o.primitive = D.PRIM_CAPSULE if spheres.shape[1] == 8 else D.PRIM_SPHERE
+            # 8-float records are capsules (a, radius, b, -) unless primitive="cylinder": (centre, radius, unit axis, half height),
+            # the reference's flat-capped cylinder obstacles (simulation.py:245-261)
+            if primitive not in (None, "sphere", "capsule", "cylinder"):
+                raise ValueError("primitive must be 'sphere', 'capsule' or 'cylinder'")
+            if primitive == "cylinder":
+                if spheres.shape[1] != 8:
+                    raise ValueError("cylinder records are [K, 8] = (cx, cy, cz, radius, ux, uy, uz, half_height)")
+                o.primitive = D.PRIM_CYLINDER
+            else:
+                if primitive is not None and (primitive == "capsule") != (spheres.shape[1] == 8):
+                    raise ValueError(f"primitive={primitive!r} does not go with records of {spheres.shape[1]} floats")
+                o.primitive = D.PRIM_CAPSULE if spheres.shape[1] == 8 else D.PRIM_SPHERE
             o.n_spheres, o.spheres = spheres.shape[0], spheres.data_ptr()
             keep.append(spheres)
             if csr_offset is not None:
@@ -235,13 +246,13 @@ class Engine:
         self._lib.rmp2_set_step_fence(self._h, fence._h if fence is not None else None)
         self._fence_attached = fence is not None
 
-    def obstacle_trajectory(self, tables: torch.Tensor, csr_offset=None, csr_index=None):
+    def obstacle_trajectory(self, tables: torch.Tensor, csr_offset=None, csr_index=None, primitive: Optional[str] = None):
         """Obstacle tables of a rollout with MOVING obstacles: `tables` [n_control_steps, K, 4] (spheres) or
         [n_control_steps, K, 8] (capsules); control step k of rollout(..., obstacles=this) reads tables[k]."""
         tables = _f32(tables, self.device)
         if tables.dim() != 3 or tables.shape[2] not in (4, 8):
             raise ValueError("tables must be [n_control_steps, K, 4] or [n_control_steps, K, 8]")
-        o = self.obstacles(spheres=tables[0], csr_offset=csr_offset, csr_index=csr_index)
+        o = self.obstacles(spheres=tables[0], csr_offset=csr_offset, csr_index=csr_index, primitive=primitive)
         o.spheres = tables.data_ptr()
         o._keep.append(tables)
         o._table_steps = int(tables.shape[0])

@@ -65,7 +65,7 @@ def _judge(name, got, desc, fleet, kw, err_ref32, max_beyond_b):
     # the fleet as a whole: no worse than an fp32 evaluation with correctly rounded square roots and divisions
     e_c32 = np.abs(c32["qdd64"] - truth).max(axis=1)
     # (measured: the 90th percentiles agree to 5 %, the engine's 99th is 1.5 x the oracle's on the sphere fleets)
-    for pq, factor in ((90, 1.25), (99, 2.0)):
+    for pq, factor in ((90, 1.25), (99, 2.0)) if len(got) >= 1000 else ():   # (quantiles of 64 robots are single robots: the per-robot bounds above)
         pe, pc = np.percentile(err / scale, pq), np.percentile(e_c32 / scale, pq)
         assert pe <= factor * pc + 2e-7, f"{name}: {pq}th percentile of the relative error {pe:.2e} against the fp32-leaf oracle's {pc:.2e}"
     return counts

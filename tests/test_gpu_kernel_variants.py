@@ -639,9 +639,9 @@ def test_explicit_pairs_streamed_pair_phase_before_the_pull_back(torch_mod, R, s
     """Interface B in its streamed form (round 5; rmp2_quad.h kObsExplicitStream): the pair phase of all leaf frames runs BEFORE any
     pull-back -- pair arrays by LDS-DMA through the frame records' LDS, sums per frame kept in registers, 128 registers and 9.6 KB of
     LDS per wave (sixteen waves per CU) -- and the frame loop then pulls the stored sums back.  Same pairs, same formulae as the
-    single-loop form (RMP2_EXPLICIT_STREAM=0), summed in another order: equal to fp32 rounding of the sums, tail robots included;
-    right against the oracle (every robot through the gate); the default dispatch takes it from four waves per SIMD on (65 536
-    robots) and a layout the DMA cannot take falls back to the single-loop form by itself."""
+    single-loop form (the default), summed in another order: equal to fp32 rounding of the sums, tail robots included; right against
+    the oracle (every robot through the gate); opt-in (RMP2_EXPLICIT_STREAM=1: measured no faster at one round of waves, DESIGN.md
+    section 8); a layout the DMA cannot take falls back to the single-loop form by itself."""
     torch = torch_mod
     import oracle as O
     from riemannian_motion_policies_amd import configs as Cf
@@ -652,8 +652,8 @@ def test_explicit_pairs_streamed_pair_phase_before_the_pull_back(torch_mod, R, s
     sph = Cf.sample_spheres(rng)
     sph[:, 2] += np.float32(0.4)
     q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
-    eng = Engine(desc, 0) if R == 65536 else _engine_env(desc, RMP2_EXPLICIT_STREAM="1")
-    old = _engine_env(desc, RMP2_EXPLICIT_STREAM="0")
+    eng = _engine_env(desc, RMP2_EXPLICIT_STREAM="1")
+    old = Engine(desc, 0)
     pl, po = eng.closest_points(q, eng.obstacles(spheres=torch.from_numpy(sph)))
     st = torch.zeros(R, dtype=torch.int32, device="cuda")
     a = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl, p_obs=po), status=st)

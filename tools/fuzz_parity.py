@@ -275,6 +275,17 @@ def draw_case(seed):
         qd *= 5.0                                     # faster robots: the velocity cap's band
     goal = rng.uniform(-0.8, 0.8, (R, desc.goal_floats)).astype(np.float32) if desc.goal_floats else None
     kw, obs_label = draw_obstacles(rng, O, desc, q, obstacle_kind)
+    side = np.random.default_rng([seed, 5])       # round-5 extras draw from a generator of their own: a seed's base case is unchanged
+    if "_engine" not in kw and "spheres" in kw and kw["spheres"].shape[1] == 8 and side.random() < 0.5:
+        # the capsule table read as the reference's flat-capped CYLINDERS (simulation.py:245-261): centre = the axis' midpoint, unit axis,
+        # half height = half the axis length (RMP2_PRIM_CYLINDER; shared and ragged tables, every mapping)
+        tab = kw["spheres"].astype(np.float64)
+        axis = tab[:, 4:7] - tab[:, 0:3]
+        ln = np.linalg.norm(axis, axis=1)
+        axis = np.where(ln[:, None] > 0, axis / np.where(ln > 0, ln, 1.0)[:, None], np.array([0.0, 0.0, 1.0]))
+        cyl = np.concatenate([0.5 * (tab[:, 0:3] + tab[:, 4:7]), tab[:, 3:4], axis, np.maximum(0.5 * ln, 0.01)[:, None]], axis=1).astype(np.float32)
+        kw = dict(kw, spheres=cyl, primitive="cylinder")
+        obs_label = obs_label.replace("capsules", "cylinders")
     pairs_fp32 = kw.pop("_pairs_fp32", None)
     eng_kw = kw.pop("_engine", None) or kw       # (link geometry: the engine gets table + link capsules, the oracle the pairs)
     dead = np.zeros(R, bool)
@@ -288,7 +299,155 @@ def draw_case(seed):
         q[bad_rows[2], :] = np.nan
         obs_label += " +3 non-finite robots"
     return dict(c, desc=desc, q=q, qd=qd, goal=goal, kw=kw, eng_kw=eng_kw, dead=dead, dead_velocity=dead_velocity, obs_label=obs_label,
-                pairs_fp32=pairs_fp32)
+                pairs_fp32=pairs_fp32, side=side, obstacle_kind=obstacle_kind)
+
+
+def core_from_specs(c, fk, by_function):
+    """The RMP set of a case through the reference's class surface (rmp.RmpCore + the leaf classes of rmp2.py / rmp.py): sets of
+    identity-map leaves and FK -> position leaves; the FK map as TaskmapByForwardKinematic, or -- by_function -- as the reference's
+    TaskmapByFunction over closures of the kinematics (taskmap.py:33-42, tests/test_taskmaps.py:33-36).  None: a leaf kind this helper
+    does not build."""
+    from riemannian_motion_policies_amd import descriptor as D, rmp, rmp2, taskmap as T
+    core = rmp.RmpCore(rmps={}, solve=c["solve"])
+    goal, off = c["goal"], 0
+    for i, sp in enumerate(c["specs"]):
+        P = list(sp.params)      # (the very doubles the hand-built descriptor was given)
+        name = f"leaf{i}"
+        if sp.taskmap == D.TASKMAP_FK_POSITION:
+            frame = c["table"].frame_names[sp.frame]
+            first = (T.TaskmapByFunction(lambda q, f=frame: fk.forward(q, frame=f), lambda q, qd, f=frame: fk.differentiate(q, qd, frame=f))
+                     if by_function else T.TaskmapByForwardKinematic(fk, frame))
+            tm = T.chain_taskmaps([first, T.TaskmapFrom4x4ToPosition()])
+            g = goal[:, off:off + 3]
+            off += 3
+            if sp.kind == D.LEAF_TARGET_ATTRACTOR:
+                core.add_rmp(rmp2.TargetAttractor(g, *P[:9], taskmap=tm, name=name))
+            elif sp.kind == D.LEAF_TARGET_POLICY:
+                core.add_rmp(rmp.TargetPolicy(P[0], P[1], P[2], g, tm, name=name))
+            else:
+                return None
+        elif sp.taskmap == D.TASKMAP_IDENTITY:
+            if sp.kind == D.LEAF_TARGET_POLICY:
+                n = c["n"]
+                core.add_rmp(rmp.TargetPolicy(P[0], P[1], P[2], goal[:, off:off + n], T.IdentityTaskmap(), name=name))
+                off += n
+            elif sp.kind == D.LEAF_JOINT_VELOCITY_CAP:
+                core.add_rmp(rmp2.JointVelocityCap(*P[:4], name=name))
+            elif sp.kind == D.LEAF_JOINT_DAMPING:
+                core.add_rmp(rmp2.JointDamping(*P[:3], name=name))
+            elif sp.kind == D.LEAF_CSPACE_BIASING:
+                core.add_rmp(rmp2.CSpaceBiasing(np.asarray(sp.vec_a, np.float32), *P[:5], name=name))
+            elif sp.kind == D.LEAF_JOINT_LIMIT_AVOIDANCE:
+                core.add_rmp(rmp.JointLimitAvoidance(np.asarray(sp.vec_a, np.float32), np.asarray(sp.vec_b, np.float32), P[0], P[1], name=name))
+            elif sp.kind == D.LEAF_CONFIG_SPACE_BIASING:
+                core.add_rmp(rmp.ConfigurationSpaceBiasing(P[0], P[1], np.asarray(sp.vec_a, np.float32), name, w=P[2]))
+            else:
+                return None
+        else:
+            return None
+    return core
+
+
+def round5_extras(c, eng, obstacles, got, torch, O, what):
+    """What the round-4 campaign did not draw (its own list), on the case the seed fixes, from the side generator:
+    the Euler task map's entry point, Engine.bind + HIP-graph capture and replay, the native obstacle exchange (real RCCL, one rank),
+    the class surface with TaskmapByFunction maps.  Returns a problem string or None."""
+    side, desc, q, qd, goal, R, n, t = c["side"], c["desc"], c["q"], c["qd"], c["goal"], c["R"], c["n"], c["table"]
+    dead = c["dead"]
+    eq = lambda a, b: bool(torch.equal(torch.nan_to_num(a, nan=12345.0, posinf=2e30, neginf=-2e30), torch.nan_to_num(b, nan=12345.0, posinf=2e30, neginf=-2e30)))
+    tq, tqd = torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()
+    tg = None if goal is None else torch.from_numpy(goal).cuda()
+    done = []
+    if side.random() < 0.08 and not dead.any() and t.n_frames > 0:
+        # rmp2_differentiate_euler: (x, xd, J, c) of [FK(frame), 4x4 -> Euler xyz] (taskmap.py:57-67) of a random frame against the oracle
+        m = min(R, 64)
+        fr = int(side.integers(0, t.n_frames))
+        ge = [x.cpu().numpy() for x in eng.differentiate_euler(tq[:m], tqd[:m], fr)]
+        we = O.differentiate_euler(desc, q[:m], qd[:m], fr)
+        calm = np.abs(np.cos(we[0][:, 1])) > 0.2                       # (away from the gimbal pole, where 1 / cos(theta_y) amplifies fp32)
+        scale = 1.0 + float(np.abs(qd[:m]).max()) ** 2
+        dd = [float(np.abs(a - b)[calm].max()) if calm.any() else 0.0 for a, b in zip(ge, we)]
+        done.append(f"euler frame {fr}")
+        # (the reference's own tolerance for this Jacobian is 1e-3, tests/test_taskmaps.py:75; measured here: <= 3.3e-4)
+        if dd[0] > 2e-5 or dd[1] > 5e-4 * scale or dd[2] > 1e-3 or dd[3] > 5e-3 * scale:
+            return f"rmp2_differentiate_euler frame {fr}: x {dd[0]:.2e} xd {dd[1]:.2e} J {dd[2]:.2e} c {dd[3]:.2e}"
+    if side.random() < 0.1:
+        # Engine.bind (the pre-marshalled launch on fixed buffers), eagerly and captured into a HIP graph and replayed: bit for bit the
+        # step's result -- a strict / rank-deficient handle needs rmp2_reserve before the capture (include/rmp2.h)
+        out_b = torch.empty_like(tq)
+        try:
+            eng.reserve(R)
+            launch, _ = eng.bind(tq, tqd, tg, obstacles=obstacles, out=out_b)
+            launch()
+            torch.cuda.synchronize()
+            first = out_b.clone()
+            g = torch.cuda.CUDAGraph()
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                launch_s, _ = eng.bind(tq, tqd, tg, obstacles=obstacles, out=out_b, stream=stream.cuda_stream)
+                launch_s()
+                stream.synchronize()
+                with torch.cuda.graph(g, stream=stream):
+                    launch_s()
+            out_b.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            done.append("bind + graph")
+            if not (eq(first, torch.from_numpy(got).cuda()) and eq(out_b, first)):
+                return "Engine.bind / graph replay differs from Engine.step"
+        except Exception as e:   # noqa: BLE001
+            from riemannian_motion_policies_amd import _native
+            if not (isinstance(e, _native.Rmp2Error) and e.code == _native.ERR_UNSUPPORTED):
+                return f"bind / graph capture: {type(e).__name__}: {e}"
+    ek = c["eng_kw"]
+    if side.random() < 0.25 and set(ek) == {"spheres"} and ek["spheres"].shape[1] == 4 and not dead.any():
+        # the native obstacle exchange (rmp2_exchange_*: RCCL all-gather of the table + step, one call per control step) with the real
+        # RCCL at one rank, depth 1 or 2, the table MOVING every step: step k must read table k -- bit for bit the plain step on it
+        from riemannian_motion_policies_amd.fleet import NativeObstacleExchange
+        depth = int(side.integers(1, 3))
+        K = ek["spheres"].shape[0]
+        tabs = [ek["spheres"] + np.float32(0.01 * k) * np.array([1, 0, 0, 0], np.float32) for k in range(3 + depth)]
+        dev_tabs = [torch.from_numpy(x).cuda() for x in tabs]
+        exch = NativeObstacleExchange(K, torch.device("cuda", 0), depth=depth)
+        try:
+            for k in range(depth):
+                exch.start(dev_tabs[k])
+            out_x = torch.empty_like(tq)
+            for k in range(3):
+                exch.step(eng, tq, tqd, tg, out_x, next_local=dev_tabs[k + depth])
+                want = eng.step(tq, tqd, tg, obstacles=eng.obstacles(spheres=dev_tabs[k]))
+                torch.cuda.synchronize()
+                if not eq(out_x, want):
+                    return f"native exchange (depth {depth}): step {k} did not read table {k}"
+            done.append(f"exchange depth {depth}")
+        finally:
+            exch.close()
+    if side.random() < 0.5 and c["robot_kind"] in ("two_joint", "panda") and c["obstacle_kind"] == "none" and R <= 2049 and not dead.any():
+        # the reference's class surface on the same set: RmpCore + leaf classes, FK maps as TaskmapByForwardKinematic and as
+        # TaskmapByFunction over closures of the kinematics -- the very accelerations of the descriptor the harness built by hand
+        from riemannian_motion_policies_amd import urdf as U
+        from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
+        fk = UrdfForwardKinematic(*((U.PANDA_URDF, U.PANDA_ORDER) if c["robot_kind"] == "panda" else (U.TWO_JOINT_URDF, U.TWO_JOINT_ORDER)))
+        old_k = os.environ.get("RMP2_KERNEL")
+        if c["kernel"]:
+            os.environ["RMP2_KERNEL"] = c["kernel"]
+        try:
+            for by_function in (False, True):
+                core = core_from_specs(c, fk, by_function)
+                if core is None:
+                    break
+                res = np.asarray(core.evaluate(q, qd))
+                done.append("class surface" + (" (TaskmapByFunction)" if by_function else ""))
+                if not np.array_equal(np.nan_to_num(res, nan=12345.0), np.nan_to_num(got, nan=12345.0)):
+                    return f"class surface (by_function={by_function}) differs from the descriptor: max {np.nanmax(np.abs(res - got)):.3e}"
+        finally:
+            if old_k is None:
+                os.environ.pop("RMP2_KERNEL", None)
+            else:
+                os.environ["RMP2_KERNEL"] = old_k
+    if done:
+        what["round5_extras"] = done
+    return None
 
 
 def run_case(seed, torch, verbose=False):
@@ -315,9 +474,10 @@ def run_case(seed, torch, verbose=False):
                 os.environ.pop("RMP2_KERNEL", None)
             else:
                 os.environ["RMP2_KERNEL"] = old
-        dev = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in eng_kw.items() if k != "pair_counts"}
-        if "pair_counts" in eng_kw:
-            dev["pair_counts"] = eng_kw["pair_counts"]
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in eng_kw.items() if k not in ("pair_counts", "primitive")}
+        for k in ("pair_counts", "primitive"):
+            if k in eng_kw:
+                dev[k] = eng_kw[k]
         obstacles = eng.obstacles(**dev) if eng_kw else None
         st = torch.zeros(R, dtype=torch.int32, device="cuda")
         want_system = (rng.random() < 0.3) or verbose
@@ -351,6 +511,7 @@ def run_case(seed, torch, verbose=False):
         what["entry_points"] = dict(frame=fr, T=dT, x=dd[0], xd=dd[1], J=dd[2], c=dd[3])
         if dT > 5e-6 or dd[0] > 5e-6 or dd[1] > 5e-6 * scale or dd[2] > 5e-6 or dd[3] > 2e-5 * scale or zeros_differ:
             entry_problem = f"kinematics entry points: {what['entry_points']}, zero columns differ: {zeros_differ}"
+    extras_problem = round5_extras(c, eng, obstacles, got, torch, O, what)
     rollout_problem, rollout_first = None, None
     if ("p_link" not in eng_kw) and rng.random() < 0.25:
         # the fused rollout (rmp2_rollout): K control steps in one launch must equal K launches of one control step each BIT FOR BIT
@@ -371,6 +532,8 @@ def run_case(seed, torch, verbose=False):
                 drift[:, 3] = 0.0
                 tables = np.stack([base + k * drift for k in range(K)]).astype(np.float32)
                 lists = {k: torch.from_numpy(eng_kw[k]) for k in ("csr_offset", "csr_index") if k in eng_kw}
+                if "primitive" in eng_kw:
+                    lists["primitive"] = eng_kw["primitive"]
                 traj = eng.obstacle_trajectory(torch.from_numpy(tables), **lists)
                 per_step = [eng.obstacles(spheres=torch.from_numpy(tables[k]), **lists) for k in range(K)]
             qa, qda = tq.clone(), tqd.clone()
@@ -460,6 +623,8 @@ def run_case(seed, torch, verbose=False):
     flagged = (stc & D.STATUS_NONFINITE) != 0 if hasattr(D, "STATUS_NONFINITE") else (stc & 1) != 0
     if rollout_problem:
         problems.append(rollout_problem)
+    if extras_problem:
+        problems.append(extras_problem)
     if entry_problem:
         problems.append(entry_problem)
     if (nonfinite_ref & ~nonfinite_got & ~finite_where_oracle_nan).any():       # (the gate's both_nan branch covers the converse)

@@ -2,7 +2,7 @@
 # round 5, third call: streamed explicit pairs (interface B) -- parity, then timing against the single-loop form; FK error diagnostic
 O=gpurun_out/r05; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_kernel_variants.py tests/test_gpu_accuracy_envelope.py tests/test_gpu_dropin.py -q -m gpu -x > $O/gpu_suite_c.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/gpu_suite_c.log; tail -12 $O/gpu_suite_c.log
-python tools/diag_fk_error.py > $O/diag_fk_error.txt 2>&1; cat $O/diag_fk_error.txt
+python tools/diag_fk_error.py 2>/dev/null | cut -c1-400 > $O/diag_fk_error.txt; cat $O/diag_fk_error.txt
 [ $rc -eq 0 ] || exit $rc
 {
   echo "# interface B (config3b): us per step / fraction of 8 TB/s; s0 = RMP2_EXPLICIT_STREAM=0 (single-loop two-wave form), s1 = streamed"
