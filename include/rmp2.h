@@ -187,12 +187,17 @@ typedef struct rmp2_obstacles {
   const int32_t *csr_index;                /* device [csr_offset[R]]; non-null even when every list is empty */
   const float *dist;                       /* device [R][P], FK_POINT leaves only (else NULL) */
   const float *link_capsules;              /* device [n_distance_leaves][8] = (a, radius, b, -) in each distance leaf's FRAME
-                                              coordinates (leaf order), or NULL.  SHARED_SPHERES only, at most 256 primitives:
-                                              the control point of a pair is the nearest point of the LINK's capsule to the
-                                              obstacle, formed inside the step -- the fused form of rmp2_closest_points_links +
-                                              EXPLICIT_PAIRS (same value d = |p_link - p_obs| and unit normal; as there, the
-                                              derivative moves the point with the frame origin, taskmap.py:124-129).  Robots
-                                              with at most 9 dofs, AUTO resolve. */
+                                              coordinates (leaf order), or NULL.  Table modes: the control point of a pair is
+                                              the nearest point of the LINK's capsule to the obstacle -- the values of
+                                              rmp2_closest_points_links + EXPLICIT_PAIRS (d = |p_link - p_obs| and unit normal; as
+                                              there, the derivative moves the point with the frame origin, taskmap.py:124-129).
+                                              FUSED into the step for tables of at most 256 spheres / capsules, robots with at
+                                              most 9 dofs and an inertia leaf, solve = AUTO or a certifying PINV (shared tables,
+                                              ragged lists, rollouts); a plain step over a SHARED table beyond those limits --
+                                              more dofs, the all-Jacobi PINV, bigger tables, CYLINDER tables -- runs as the stage
+                                              into a buffer of the handle followed by the explicit-pair step (two launches, same
+                                              numbers as calling the two entry points).  Rollouts and ragged lists beyond the
+                                              fused limits: RMP2_ERR_UNSUPPORTED. */
 } rmp2_obstacles;
 
 /* ---- outputs ----------------------------------------------------------------------- */

@@ -239,6 +239,32 @@ def fp32_envelope(desc: D.Desc, q, qd, goal=None, samples: int = 16, seed: int =
     return env
 
 
+def rank_flips(desc: D.Desc, q, qd, goal=None, trials: int = 6, seed: int = 0, **obstacle_kwargs):
+    """Per robot: does the NUMBER of non-zero singular values of the reference-precision M change when every fp32 input moves by one
+    unit-scale fp32 rounding?  It does when a pair sits within a rounding of a leaf's cutoff radius (rmp2.py:170-174: the gate has a
+    double root there -- metric exactly 0 on one side, 1e-12 on the other): a dof whose only metric that is has q-double-dot = f / M =
+    O(1..100) in one faithful evaluation and 0 (dropped by the pseudo-inverse) in the next.  tools/fuzz_parity.py counts such robots as
+    undetermined at fp32 (seed 510845: one of 1.3 M robots; the engine had the pair in range, both oracle builds out of range)."""
+    rng = np.random.default_rng(seed)
+    eps = np.float64(2.0 ** -23)
+
+    def jiggle(a):
+        a = np.ascontiguousarray(a, dtype=np.float32).astype(np.float64)
+        return (a + rng.choice(np.array([-1.0, 1.0]), a.shape) * eps * np.maximum(np.abs(a), 1.0)).astype(np.float32)
+
+    def rank(M):
+        with np.errstate(invalid="ignore"):
+            sv = np.linalg.svd(np.where(np.isfinite(M), M, 0.0), compute_uv=False)
+        return (sv > 1e-18 * np.maximum(sv[:, :1], 1e-300)).sum(axis=1)
+
+    base = rank(step(desc, q, qd, goal, precision="f32", **obstacle_kwargs)["M"])
+    flips = np.zeros(len(base), bool)
+    for _ in range(trials):
+        kw = {k: (jiggle(v) if k in ("spheres", "p_link", "p_obs", "dist") and v is not None else v) for k, v in obstacle_kwargs.items()}
+        flips |= rank(step(desc, jiggle(q), jiggle(qd), None if goal is None else jiggle(goal), precision="f32", **kw)["M"]) != base
+    return flips
+
+
 def system_resolution(ref, trials: int = 4, eps: float = 2.0 ** -22, seed: int = 0):
     """Per robot: how far the resolve `pinv(M) f` (TensorFlow's cutoff, rmp.py:153-154) of the oracle's combined system moves when
     every ENTRY of M and f moves by a relative `eps` (two fp32 roundings by default) with a random sign, the maximum over `trials`

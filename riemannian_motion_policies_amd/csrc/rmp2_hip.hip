@@ -1944,6 +1944,7 @@ int rmp2_destroy(rmp2_handle* h) {
   if (h->d_pair_begin) (void)hipFree(h->d_pair_begin);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->d_system) (void)hipFree(h->d_system);
+  if (h->d_pairs) (void)hipFree(h->d_pairs);
   if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
   delete h;
   return RMP2_OK;
@@ -1998,9 +1999,9 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "sphere table missing");
       if (obs->primitive != RMP2_PRIM_SPHERE && obs->primitive != RMP2_PRIM_CAPSULE && obs->primitive != RMP2_PRIM_CYLINDER)
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "unknown obstacle primitive");
-      if (obs->primitive == RMP2_PRIM_CYLINDER && (obs->link_capsules || h->has_point))
-        return fail(h, RMP2_ERR_UNSUPPORTED, "cylinder tables with link geometry / attached-point leaves: the nearest points of a segment and a "
-                                             "cylinder are an iteration -- rmp2_closest_points_links + EXPLICIT_PAIRS");
+      if (obs->primitive == RMP2_PRIM_CYLINDER && (obs->link_capsules || h->has_point))   // (plain steps over a shared table never get here: step_impl)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "cylinder tables with link geometry in a rollout / over ragged lists / for attached-point leaves: the "
+                                             "nearest points of a segment and a cylinder are an iteration -- rmp2_closest_points_links + EXPLICIT_PAIRS");
       if (o.mode == RMP2_OBS_RAGGED_SPHERES && (!obs->csr_offset || (!obs->csr_index && obs->n_spheres > 0)))
         return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
     } else {
@@ -2063,6 +2064,43 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   if (!h) return RMP2_ERR_INVALID_ARGUMENT;
   if (R < 0) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "R < 0");
   if (R == 0) return RMP2_OK;  // empty fleet: nothing to do (pointers may be null)
+  // Link geometry of the distance leaves beyond what the fused forms take (include/rmp2.h rmp2_obstacles.link_capsules: robots with
+  // more than nine dofs, solve = pinv where the quad mapping does not certify it, sets without an inertia leaf, tables beyond 256
+  // primitives, CYLINDER tables -- whose segment-cylinder closed form is an iteration): the step runs as the reference's own data
+  // flow instead (simulation.py:462-484 -> data_management.py:22-37 -> taskmap.py:115-138) -- the closest-point stage into a buffer
+  // of the handle, then the explicit-pair step on it.  Same pairs, same semantics; two launches.  (Plain control steps over a shared
+  // table; rollouts and ragged lists keep the fused forms' limits.)
+  rmp2_obstacles staged;
+  if (obs && obs->link_capsules && obs->mode == RMP2_OBS_SHARED_SPHERES && !h->has_point && ro.n_iters == 1 && ro.substeps == 0 &&
+      obs->n_spheres > 0 && !h->distance_leaves.empty() &&
+      (obs->n_spheres > kLdsSpheres || obs->primitive == RMP2_PRIM_CYLINDER || (h->strict && !quad_certifies_strict(h)) ||
+       (h->likely_singular && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)) {
+    const size_t P = h->distance_leaves.size() * (size_t)obs->n_spheres;
+    const size_t need = (size_t)R * P * 3;
+    hipStream_t s0 = (hipStream_t)stream;
+    if (need > h->pairs_floats) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (s0 && hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link geometry as stage + explicit-pair step: the handle's pair buffer must grow -- step once "
+                                             "outside the capture first");
+      if (int rc = use_device(h)) return rc;
+      if (h->d_pairs) HIP_TRY(h, hipFree(h->d_pairs));   // (synchronises the device: no launch still reads the old buffer)
+      h->d_pairs = nullptr, h->pairs_floats = 0;
+      HIP_TRY(h, hipMalloc(&h->d_pairs, sizeof(float) * 2 * need));
+      h->pairs_floats = need;
+    }
+    float* const pl = h->d_pairs;
+    float* const po = h->d_pairs + h->pairs_floats;
+    rmp2_obstacles table = *obs;
+    table.link_capsules = nullptr;
+    if (int rc = rmp2_closest_points_links(h, q, &table, obs->link_capsules, pl, po, R, stream)) return rc;
+    std::memset(&staged, 0, sizeof(staged));
+    staged.mode = RMP2_OBS_EXPLICIT_PAIRS;
+    staged.n_pairs = (int32_t)P;
+    staged.p_link = pl, staged.p_obs = po;
+    for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) staged.pair_begin[l] = h->h_pair_begin[l];   // (as the stage laid the pairs out)
+    obs = &staged;
+  }
   ObsArgs o;
   OutArgs oa;
   if (int rc = prepare_step(h, q, qd, goal, goal_stride, obs, out, ro, R, stream, o, oa)) return rc;

@@ -59,6 +59,8 @@ struct rmp2_handle {
   bool pair_begin_valid = false;
   float* d_scratch = nullptr;  // rmp2_differentiate scratch
   size_t scratch_robots = 0;
+  float* d_pairs = nullptr;    // p_link | p_obs of the closest-point stage when a step with link geometry runs as stage + explicit-pair step
+  size_t pairs_floats = 0;     // (floats per array)
   double* d_system = nullptr;  // [robots][n_dof * (n_dof + 1)] combined metric and force between the quad step and rmp2_pinv_kernel
   size_t system_robots = 0;
   mutable bool quad_skip_resolve = false;  // set around that quad launch (dispatch_solve)

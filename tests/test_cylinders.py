@@ -207,12 +207,16 @@ def test_cylinder_closest_point_stage(hip_lib, links):
     truth = O.step(desc, s["q"], s["qd"], s["goal"], precision="f64", **kw)["qdd64"]
     v = O.accuracy_gate(qdd.cpu().numpy(), ref, truth=truth, envelope=O.fp32_envelope(desc, s["q"], s["qd"], s["goal"], **kw))
     assert v["ok"].all(), O.gate_summary(v)
-    # fused link geometry + cylinders: declined with the way out in the message (the segment-cylinder form is an iteration)
+    # link geometry + a cylinder table handed to the STEP: the library runs exactly this (stage into its own buffer, explicit-pair step)
     if links:
+        both = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
+                        obstacles=eng.obstacles(spheres=torch.from_numpy(cyl), primitive="cylinder", link_capsules=lct))
+        torch.cuda.synchronize()
+        assert torch.equal(both, qdd)
         from riemannian_motion_policies_amd import _native
-        with pytest.raises(_native.Rmp2Error, match="rmp2_closest_points_links"):
-            eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
-                     obstacles=eng.obstacles(spheres=torch.from_numpy(cyl), primitive="cylinder", link_capsules=lct))
+        with pytest.raises(_native.Rmp2Error, match="rmp2_closest_points_links"):      # (a rollout cannot: the pairs are one step's)
+            eng.rollout(torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda(), torch.from_numpy(s["goal"]).cuda(),
+                        obstacles=eng.obstacles(spheres=torch.from_numpy(cyl), primitive="cylinder", link_capsules=lct), n_control_steps=2)
 
 
 @pytest.mark.gpu

@@ -353,8 +353,15 @@ def test_link_geometry_argument_errors(torch_mod):
     with pytest.raises(ValueError):
         eng.obstacles(p_link=torch.zeros(8, 8, 3), p_obs=torch.zeros(8, 8, 3), link_capsules=lc)
     big = torch.from_numpy(Cf.sample_spheres(rng, 300)).cuda()                      # beyond the LDS-resident table
+    # (round 5: beyond the fused form's limits a plain step over a shared table runs as the stage + the explicit-pair step, inside
+    #  the library; a ROLLOUT there is still refused)
+    staged = eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=big, link_capsules=lc))
+    pl_, po_ = eng.closest_points(q, eng.obstacles(spheres=big), link_capsules=lc)
+    two = eng.step(q, qd, goal, obstacles=eng.obstacles(p_link=pl_, p_obs=po_))
+    torch.cuda.synchronize()
+    assert torch.equal(staged, two)
     with pytest.raises(_native.Rmp2Error, match="link_capsules"):
-        eng.step(q, qd, goal, obstacles=eng.obstacles(spheres=big, link_capsules=lc))
+        eng.rollout(q.clone(), qd.clone(), goal, obstacles=eng.obstacles(spheres=big, link_capsules=lc), n_control_steps=2)
     # solve = pinv: served since round 4 where the quad mapping certifies full rank per robot (the same numbers as AUTO on these
     # well-conditioned robots); still refused where the strict step is two kernels (here forced: RMP2_STRICT_CERTIFY=0)
     _, dpinv = Cf.config3("pinv")
@@ -368,8 +375,9 @@ def test_link_geometry_argument_errors(torch_mod):
         e2 = Engine(dpinv, 0)
     finally:
         del os.environ["RMP2_STRICT_CERTIFY"]
-    with pytest.raises(_native.Rmp2Error, match="link_capsules"):
-        e2.step(q, qd, goal, obstacles=e2.obstacles(spheres=big[:8], link_capsules=lc))
+    c = e2.step(q, qd, goal, obstacles=e2.obstacles(spheres=big[:8], link_capsules=lc))     # (all-Jacobi PINV: stage + explicit pairs)
+    torch.cuda.synchronize()
+    assert "pinv_kernel" in e2.last_kernel() and (c - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
 
 
 @pytest.mark.parametrize("prim,K", [("spheres", 32), ("spheres", 48), ("capsules", 12), ("spheres", 80)])

@@ -225,6 +225,9 @@ def known_classes(O, desc, specs, n, q, qd, goal, kw, ref):
     # a pair within an fp32 rounding of a leaf's cutoff radius: metric exactly 0 in one evaluation, +-1e-12 in another -- when it is
     # the ONLY metric of the system, the oracle's M is all zero while its fp64 evaluation is not (or the other way round)
     und |= (sv[:, 0] == 0) != (sv64[:, 0] == 0)
+    # ... or when it is the only metric of ONE dof: the rank of M then flips under a one-ulp jiggle of the inputs (oracle.rank_flips;
+    # seed 510845: the engine had such a pair in range -- metric 1e-12, q-double-dot -23.8 on that dof -- both oracle builds out of range)
+    und |= O.rank_flips(desc, q, qd, goal, **kw)
     Mz = np.where(np.isfinite(ref["M"]), ref["M"], 0.0)
     diag = np.einsum("rii->ri", Mz)
     scale_m = max([float(sp.params[8]) / max(float(sp.params[10]), 1e-30) for sp in specs if sp.kind == D.LEAF_OBSTACLE_AVOIDANCE] + [0.0])
