@@ -122,15 +122,16 @@ class Datamanager:
             T = T_all[self.fkine.table.frame_index(frame)]
             st["relative_position"].assign((p_link - T[:3, 3][None, :]) @ T[:3, :3])
 
-    def update_device(self, core, q, primitives, link_capsules=None):
+    def update_device(self, core, q, primitives, link_capsules=None, primitive=None):
         """The same five fields, filled on the device for a whole fleet without PyBullet and without a host hop: `core` is the
         RmpCore whose distance leaves read this manager's holders; its closest-point stage (rmp2_closest_points_links) writes
         pos_on_link / pos_on_obstacle for every (robot, leaf, primitive) pair, and distance, normal_vec and relative_position
         follow from them (simulation.py:462-484 reports the same tuple; data_management.py:33-53 the relative position).
-        q: [R, n] tensor on the core's device; primitives: [K,4] spheres or [K,8] capsules; link_capsules: urdf.link_capsules(...)
-        rows in the order of the core's distance leaves, or None for the frame origins as control points."""
+        q: [R, n] tensor on the core's device; primitives: [K,4] spheres, [K,8] capsules or -- primitive="cylinder" -- [K,8] finite
+        cylinders (centre, radius, unit axis, half height: the reference's own obstacles, simulation.py:245-261); link_capsules:
+        urdf.link_capsules(...) rows in the order of the core's distance leaves, or None for the frame origins as control points."""
         import torch
-        pairs = core.update_distances(q, primitives, link_capsules=link_capsules)   # (lazy: nothing has run yet)
+        pairs = core.update_distances(q, primitives, link_capsules=link_capsules, primitive=primitive)   # (lazy: nothing has run yet)
         src = pairs.source
         eng, single = src.eng, src.single
         frames = pairs.frames

@@ -55,8 +55,9 @@ class _StageSource:
     """One call of RmpCore.update_distances: the inputs of the closest-point stage (snapshots: the caller may advance q or move
     the obstacles in place afterwards) and, once somebody asks for them, its output arrays."""
 
-    def __init__(self, core, eng, q, single, prim, lc, n_leaves):
+    def __init__(self, core, eng, q, single, prim, lc, n_leaves, primitive=None):
         self.core, self.eng, self.single, self.n_leaves = core, eng, single, n_leaves
+        self.primitive = primitive    # None (by record size) | "cylinder"
         # "the q the stage was given, unmodified": the tensor OBJECT (holding it pins its storage: the allocator cannot hand the
         # address to a fresh tensor that would then pass for it) and its version counter (inference-mode tensors have none:
         # the fused route is then not taken)
@@ -90,7 +91,7 @@ class _StageSource:
 
     def arrays(self):
         if self._arrays is None:
-            table = self.eng.obstacles(spheres=self.prim)
+            table = self.eng.obstacles(spheres=self.prim, primitive=self.primitive)
             pl, po = self.eng.closest_points(self.q, table, link_capsules=self.lc)
             self._arrays = (pl, po)
             self.core._pairs_cache = (pl, po, [self.K] * self.n_leaves)
@@ -212,7 +213,7 @@ class RmpCore:
         _compile: every entry point compiles first)."""
         return self._pairs
 
-    def update_distances(self, q, primitives, link_capsules=None):
+    def update_distances(self, q, primitives, link_capsules=None, primitive=None):
         """The closest-point preprocessing stage on the device (simulation.py:462-484 calculate_distances followed by
         data_management.py:16-31 update): for every TaskmapJointFrame4x4ToDistance leaf and every obstacle primitive
         ([K,4] spheres or [K,8] capsules) the nearest points of the link (its capsule from `link_capsules`, rows in leaf order;
@@ -238,7 +239,7 @@ class RmpCore:
             raise NotImplementedError("update_distances: attached-point leaves (TaskmapRelative4x4) carry their own pair data")
         prim = as_tensor(primitives, eng.device)
         lc = None if link_capsules is None else as_tensor(link_capsules, eng.device)
-        src = _StageSource(self, eng, qt, single, prim, lc, len(leaves))
+        src = _StageSource(self, eng, qt, single, prim, lc, len(leaves), primitive=primitive)
         self._stage = src
         names = self._table.frame_names
         frames = []
@@ -265,7 +266,7 @@ class RmpCore:
                 h = getattr(last, attr, None)
                 if not (isinstance(h, ArrayVar) and h.owner is src):
                     return None
-        return eng.obstacles(spheres=src.prim, link_capsules=src.link_capsules_or_origins())
+        return eng.obstacles(spheres=src.prim, link_capsules=src.link_capsules_or_origins(), primitive=src.primitive)
 
     def _evaluate_device(self, q, qd, spheres, link_capsules=None):
         """evaluate() for tensors that already live on the engine's device: nothing goes through the host, the result is a

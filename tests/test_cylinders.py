@@ -266,3 +266,55 @@ def test_experiment06_scene_with_its_cylinders(hip_lib, kernel):
     assert vb["ok"].all() and vb["a"].mean() > 0.8, O.gate_summary(vb)
     # the link geometry matters: control points on the links' surfaces give another answer than the frame origins
     assert (out_b - out).abs().max().item() > 1e-3
+
+
+@pytest.mark.gpu
+def test_experiment06_loop_body_with_cylinders_through_the_class_surface(hip_lib):
+    """The experiment-06 loop body as the script writes it (06_cluttered_environment.py:96-131): an ObstacleAvoidance leaf per collision
+    frame on [FK(frame), TaskmapJointFrame4x4ToDistance(data_manager[frame][...])], `data_manager.update_device(core, q, cylinders,
+    link_capsules, primitive="cylinder")` standing where the script calls calculate_distances + data_manager.update, then
+    core.evaluate(q, qd) -- against the oracle on the fp64 closest points of the links' capsules and the script's seven cylinders."""
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D, rmp, rmp2, taskmap as T, urdf as U
+    from riemannian_motion_policies_amd.data_management import Datamanager
+    from riemannian_motion_policies_amd.kinematics import UrdfForwardKinematic
+    fk = UrdfForwardKinematic(U.PANDA_URDF, U.PANDA_ORDER)
+    data_manager = Datamanager(fk)
+    core = rmp.RmpCore(rmps={}, solve="pinv")
+    ee = T.chain_taskmaps([T.TaskmapByForwardKinematic(fk, "panda_grasptarget_hand"), T.TaskmapFrom4x4ToPosition()])
+    R = 128
+    s = Cf.sample_panda_states(np.random.default_rng(16), R)
+    s["goal"][:] = Cf.EXP06_GOAL
+    core.add_rmp(rmp2.TargetAttractor(s["goal"], *Cf.TARGET_ATTRACTOR_PARAMS, taskmap=ee, name="attractor"))
+    core.add_rmp(rmp2.JointVelocityCap(*Cf.JOINT_VELOCITY_CAP_PARAMS))
+    core.add_rmp(rmp2.JointDamping(*Cf.JOINT_DAMPING_PARAMS))
+    core.add_rmp(rmp2.CSpaceBiasing(Cf.CSPACE_BIASING_GOAL, *Cf.CSPACE_BIASING_PARAMS))
+    for frame in Cf.CONTROL_POINT_FRAMES:
+        tm = T.chain_taskmaps([T.TaskmapByForwardKinematic(fk, frame),
+                               T.TaskmapJointFrame4x4ToDistance(data_manager[frame]['pos_on_link_in_base_frame'],
+                                                                data_manager[frame]['pos_on_obstacle_in_base_frame'])])
+        core.add_rmp(rmp2.ObstacleAvoidance(*Cf.OBSTACLE_AVOIDANCE_PARAMS, taskmap=tm, name=f"collision_avoidance_for_{frame}"))
+    dev = torch.device("cuda", 0)
+    q, qd = torch.from_numpy(s["q"]).to(dev), torch.from_numpy(s["qd"]).to(dev)
+    table = fk.table
+    lc = U.link_capsules(U.PANDA_URDF, table, Cf.CONTROL_POINT_FRAMES)
+    cyl = torch.from_numpy(Cf.EXP06_CYLINDERS).to(dev)
+    data_manager.update_device(core, q, cyl, link_capsules=torch.from_numpy(lc).to(dev), primitive="cylinder")
+    qdd = core.evaluate(q, qd)
+    torch.cuda.synchronize()
+    _, desc = Cf.config3("pinv")
+    frames = [desc.leaves[i].frame for i in D.distance_leaf_indices(desc)]
+    Tw = O.forward_kinematics(desc, s["q"], precision="f64")[:, frames]
+    pl, po = Cf.pairs_from_link_capsules_cylinders(Tw, lc, Cf.EXP06_CYLINDERS)
+    kw = dict(p_link=pl, p_obs=po)
+    ref = O.step(desc, s["q"], s["qd"], s["goal"], **kw)
+    truth = O.step(desc, s["q"], s["qd"], s["goal"], precision="f64", **kw)["qdd64"]
+    v = O.accuracy_gate(qdd.cpu().numpy(), ref, truth=truth, envelope=O.fp32_envelope(desc, s["q"], s["qd"], s["goal"], **kw), envelope_factor=4.0)
+    assert v["ok"].all() and v["a"].mean() > 0.8, O.gate_summary(v)
+    # the holders the leaves read are the stage's arrays (views, nothing copied), the distances the closed form's
+    first = data_manager[Cf.CONTROL_POINT_FRAMES[0]]['pos_on_link_in_base_frame'].value
+    assert first.is_cuda and tuple(first.shape) == (R, 7, 3)
+    d0 = (first - data_manager[Cf.CONTROL_POINT_FRAMES[0]]['pos_on_obstacle_in_base_frame'].value).norm(dim=-1).cpu().numpy()
+    d_ref = np.linalg.norm(pl[:, :7].astype(np.float64) - po[:, :7], axis=-1)
+    assert np.abs(d0 - d_ref).max() < 3e-6

@@ -167,6 +167,20 @@ def main():
             del shard
     np.savez_compressed(out_prefix + "_raw.npz", **raw)
     json.dump(rows, open(out_prefix + ".json", "w"), indent=1)
+    # ---- the table (profiles/r05_accuracy_survey.txt keeps the JSON rows above AND this) ----
+    f3 = lambda v: "/".join(f"{x:.3g}" for x in v) if v else "-"
+    print("\n# 2 048 robots per fleet; errors against the fp64 evaluation of the reference's formulae (C oracle, double build).")
+    print("# A: |err| <= 1e-5 max(1, |qdd|)   B: backward error omega <= 2e-5 (oracle.ETA)   E: |err| <= 2 x fp32 envelope (17 fp32 oracle")
+    print("# draws + the autograd fp32 restatement's own error); every clause counted ON ITS OWN.  ratio = err_engine / envelope over the robots")
+    print("# outside A (percentiles 50/90/99/100); control = the plain fp32 oracle evaluation against an envelope of 16 OTHER draws.")
+    print(f"{'fleet':44s} {'A':>5s} {'B':>5s} {'E':>5s} {'gate':>5s} {'out-A':>5s} | {'ratio engine/envelope':>24s} {'>1':>4s} {'>2':>4s} | "
+          f"{'control':>22s} {'>1':>4s} {'>2':>4s} | {'rel err p90/p99 engine':>24s} {'fp32 oracle':>20s} {'restatement out-A':>18s} {'omega max':>10s}")
+    for r in rows:
+        n_e = r["robots"] - r["outside_A"] + (r["outside_A"] - r["E_ratio_gt_2"])
+        print(f"{r['fleet'][:44]:44s} {r['A_vs_f64']:5d} {r['B_omega_le_2e5']:5d} {n_e:5d} {r['passes_gate']:5d} {r['outside_A']:5d} | "
+              f"{f3(r['E_ratio_engine_over_envelope17_pcts']):>24s} {r['E_ratio_gt_1']:4d} {r['E_ratio_gt_2']:4d} | "
+              f"{f3(r['control_ratio_c32_over_envelope16_pcts']):>22s} {r['control_gt_1']:4d} {r['control_gt_2']:4d} | "
+              f"{f3(r['rel_err_all_robots_pcts_engine'][1:3]):>24s} {f3(r['rel_err_all_robots_pcts_c32'][1:3]):>20s} {r['ref32_outside_A']:18d} {r['omega_max_all']:10.2e}")
 
 
 if __name__ == "__main__":

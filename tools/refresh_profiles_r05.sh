@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-5 evidence, part 1 (one GPU call): the whole GPU suite, the accuracy survey, the bench lines, the two-rank rehearsal.
+# Part 2: tools/refresh_profiles_r05_b.sh (rocprofv3 kernel stats, PMC traffic, SQ counters + stamps, the fuzz campaign).
+# Both write under gpurun_out/r05/final/; tools/copy_profiles_r05.sh copies the judged files into profiles/.
+O=gpurun_out/r05/final; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -q -m gpu > $O/gpu_suite.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/gpu_suite.log; tail -6 $O/gpu_suite.log | cut -c1-300
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python tools/accuracy_survey.py 2048 $O/accuracy_survey > $O/accuracy_survey.txt 2> $O/accuracy_survey.err || { tail -5 $O/accuracy_survey.err; exit 1; }
+tail -16 $O/accuracy_survey.txt | cut -c1-330
+python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_style_steps20.json 2> /dev/null || exit 1
+for wl in config3b config3c config3l config2 config4 config5; do
+  python bench.py --workload $wl --no-cpu-baseline --no-secondary > $O/bench_$wl.json 2> $O/bench_$wl.err || { tail -5 $O/bench_$wl.err; exit 1; }
+done
+python bench.py --workload config3 --solve auto --no-cpu-baseline --no-secondary > $O/bench_config3_auto.json 2> /dev/null || exit 1
+python bench.py --gpus 2 --rehearse-one-gpu --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $O/rehearsal_2ranks_config4.json 2> $O/rehearsal_2ranks_config4.err || { tail -5 $O/rehearsal_2ranks_config4.err; exit 1; }
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r05/final/bench_*.json")) + ["gpurun_out/r05/final/rehearsal_2ranks_config4.json"]:
+    j = json.loads(open(f).read().strip().splitlines()[-1]); r = j["roofline"]
+    print(f.split("/")[-1][:-5].ljust(34), f"{j['ms_per_step']*1e3:8.2f} us  {j['value']/1e6:8.1f} M/s  {j['config']['solve']:5s} {r['bound']:4s} frac {r['frac']:.3f}",
+          "exec", None if r.get("executed_frac") is None else round(r["executed_frac"], 3),
+          {k: round(v["ms_per_step"]*1e3, 2) for k, v in j.items() if k.startswith("solve_")}, j.get("world1_same_workload_ms"))
+PY
