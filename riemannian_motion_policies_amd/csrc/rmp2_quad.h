@@ -982,6 +982,81 @@ __device__ __forceinline__ void pair_loop_explicit_glds(const float* PL, const f
   pf_pb = pb_next;
 }
 
+// ---- explicit pairs streamed a QUARTER leaf at a time (the four-wave form, kObsExplicitStream) -----------------------------------
+// One chunk = 8 pairs per robot of both arrays = 2 x 16 robots x 96 B = 3 KiB = exactly three wave-instructions of 64 x 16 B: piece
+// c = 64 i + lane is array c / 96, robot (c % 96) / 6, bytes 16 ((c % 96) % 6) .. +16 of that robot's 96-byte segment.  Image: p_link
+// [16 robots][8 pairs][3 floats] at buf, p_obs the same at buf + 384 floats.  One buffer: a chunk is read into registers (two pairs per
+// lane: pair sub and sub + 4 of the eight), the NEXT chunk is issued into the same buffer at once, and the two slots are evaluated
+// masked while it flies -- through the quad sums, the Jacobian columns and the pull-back of the frame too when it was the leaf's last
+// chunk.  No per-quad compaction: the mode is bound by the stream, its arithmetic hides under it (measured, round 5).
+constexpr int kQdmaBuf = 768;  // floats: one chunk, both arrays
+// pf_pb: pair_begin of the leaf whose FIRST chunk is already in the buffer / in flight (-1: none); updated for the next leaf.
+__device__ __forceinline__ void pair_loop_explicit_qdma(const float* PL, const float* PO, int n_pairs, int r0, int R, int pb, int pb_next,
+                                                        int& pf_pb, float* buf, int lane, int g, int sub, const float P3[3],
+                                                        const float V3[3], const float A3[3], const float* P, const float* IP,
+                                                        float thr2, float S[6], float h[3], int dbg = 0) {
+  const float vv = dot3(V3, V3);
+  auto issue = [&](int pbx, int quarter) __attribute__((always_inline)) {
+    if (dbg & 2) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = 64 * i + lane;
+      const int arr = c >= 96 ? 1 : 0;
+      const int cc = c - 96 * arr;
+      const int rr = (cc * 10923) >> 16;  // cc / 6 for cc < 96
+      const int piece = cc - 6 * rr;
+      const int robot = min(r0 + rr, R - 1);  // (quads beyond the fleet's tail re-read the last robot: in bounds, discarded)
+      const size_t off = ((size_t)robot * n_pairs + pbx + 8 * quarter) * 3 + 4 * piece;
+      glds16((arr ? PO : PL) + off, buf + 256 * i);
+    }
+  };
+  if (pf_pb != pb) issue(pb, 0);  // (wave-uniform) first distance leaf of the pass: nothing was prefetched for it
+#pragma unroll
+  for (int quarter = 0; quarter < 4; ++quarter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk has landed (LDS-DMA counts on vmcnt)
+    F3 a[2], o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* src = buf + g * 24 + 3 * (sub + kQuad * i);
+      a[i] = *reinterpret_cast<const F3*>(src);
+      o[i] = *reinterpret_cast<const F3*>(src + 384);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and is in registers: the buffer is free for the next chunk
+    if (quarter < 3)
+      issue(pb, quarter + 1);
+    else if (pb_next >= 0)
+      issue(pb_next, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // taskmap.py:124-129: rel = stop_gradient(p_link - p_joint); crit = p_joint + rel
+      const float diff[3] = {(P3[0] + (a[i].x - P3[0])) - o[i].x, (P3[1] + (a[i].y - P3[1])) - o[i].y, (P3[2] + (a[i].z - P3[2])) - o[i].z};
+      const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+      const bool on = !(d2 > thr2) && !(dbg & 1);  // (NaN compares "in range")
+      if (!__any(on)) continue;
+      const float inv = rsq0(d2);
+      const float d = d2 * inv;
+      const float nh[3] = {diff[0] * inv, diff[1] * inv, diff[2] * inv};
+      const float xdot = dot3(nh, V3);
+      const float cd = fmaf(-xdot, xdot, vv) * rcp0(d) + dot3(nh, A3);  // c2 + J2 c1 (taskmap.py:159)
+      float acc, met;
+      obstacle_pair(P, IP, d, xdot, acc, met);
+      if (!on) met = 0.f;
+      const float wgt = met * (acc - cd);
+      const float mn[3] = {met * nh[0], met * nh[1], met * nh[2]};
+      S[0] = fmaf(mn[0], nh[0], S[0]);
+      S[1] = fmaf(mn[0], nh[1], S[1]);
+      S[2] = fmaf(mn[0], nh[2], S[2]);
+      S[3] = fmaf(mn[1], nh[1], S[3]);
+      S[4] = fmaf(mn[1], nh[2], S[4]);
+      S[5] = fmaf(mn[2], nh[2], S[5]);
+      h[0] = fmaf(wgt, nh[0], h[0]);
+      h[1] = fmaf(wgt, nh[1], h[1]);
+      h[2] = fmaf(wgt, nh[2], h[2]);
+    }
+  }
+  pf_pb = pb_next;
+}
+
 // v[4 m + sub] of a wave-uniform per-dof vector of the program (leaf va / vb): four scalar-cache words and three
 // selects instead of a lane-indexed vector load from global memory (a full memory latency in the middle of a leaf)
 __device__ __forceinline__ float pick4(const float* v, int m, int sub) {
@@ -1082,20 +1157,19 @@ constexpr int kObsAny = -1;
 constexpr int kObsSharedLink = 4;
 constexpr int kLinkSeg = 8;  // floats per (robot, leaf frame): A.xyz, -, B.xyz, -
 // OBS = kObsExplicitStream (plain builds, four waves per SIMD): interface B -- explicit closest-point pairs, 6 264 B per robot-step,
-// the one HBM-bound form of the step -- with the PAIR PHASE SEPARATED FROM THE PULL-BACK.  The single-loop form (per leaf frame:
-// pairs, quad sums, Jacobian columns, pull-back into the fp64 system) keeps the whole system and the frame records live through the
-// pair loop: 256 registers and 18 KB of LDS per wave, i.e. two waves per SIMD, and at two waves the step is bound by the latencies
-// two waves cannot cover (round 4: 104.5 us at 65 536 robots = 49 % of the HBM roof; six loader variants, none faster).  Here:
-//   walk            as before; then every lane takes what the later phases need of the frame records into REGISTERS -- the
-//                   (z, o) records of the joints that own its rows (18), and three floats per leaf-bearing frame of [p v a] (27) --
-//   pair phase      and the frame records' LDS becomes the LDS-DMA buffer: the pair arrays stream half a leaf ahead
-//                   (pair_loop_explicit_glds, as the opt-in two-wave form did) while NO fp64 system exists yet; per frame the
-//                   quad's sums S = sum m n n^T, h = sum m (xdd - c) n replace [v a] in the same registers;
-//   pull-back       the sums go back to LDS (the DMA is done), and the frame loop runs as in the table modes minus the pair loops.
-// 128 registers and 9.6 KB of LDS per wave: sixteen waves per CU, every one of them with half a leaf (6 KB) in flight through its
-// pair phase -- the latency-hiding the two-wave form could not buy with any loader.
+// the one HBM-bound form of the step -- with the pair arrays STREAMED through LDS beside a four-wave working set.  The two-wave form keeps
+// the frame records (8.4 KB of a wave's LDS) and 256 registers through the frame loop; at two waves per SIMD the step is bound by the
+// latencies two waves cannot cover (round 4: 104.5 us at 65 536 robots = 49 % of the HBM roof; six loader variants, none faster).  Here,
+// after the walk, what the frame loop needs of the records leaves their LDS: the (z, o) records of the joints that own a lane's rows go
+// to registers (18), [p v a] of the leaf-bearing frames to a compact image (nine floats per robot and frame: 5.2 KB), and the rest of the
+// region becomes a 3 KiB LDS-DMA buffer through which every leaf's pairs arrive a quarter leaf at a time (pair_loop_explicit_qdma):
+// the next chunk is in flight while the current one is evaluated, summed, and -- at a leaf's end -- pulled back.  128 registers and 9.6 KB
+// of LDS per wave: sixteen waves per CU in ONE round at 65 536 robots, each with a chunk in flight from its first leaf to its last.
+// (Round 5 first built the two-phase form -- all pair phases, then all pull-backs: tools/experiments/r05_explicit_two_phase.patch --,
+// whose stream ran at 6 TB/s but in series with 56 us of walk and pull-back: every wave of a one-round fleet is in the same phase.)
 constexpr int kObsExplicitStream = 5;
-constexpr int kStreamMaxFrames = 9;  // leaf-bearing frames the streamed form holds in registers (the Panda's cluttered set: 8 + 1)
+constexpr int kStreamMaxFrames = 9;  // leaf-bearing frames of the compact [p v a] image (the Panda's cluttered set: 8 + 1)
+constexpr int kStreamPva = kRobotsPerWave * kStreamMaxFrames * 9;  // floats of that image; the chunk buffer (kQdmaBuf) sits behind it
 // FLAVOR: kGeneral = everything at run time (debug outputs M / f, rollout loop, any obstacle mode); kPlainStep = one control
 // step, no debug outputs, OBS fixed; kPlainRollout = the fused rollout loop, no debug outputs, OBS fixed (sphere-table modes).
 constexpr int kGeneral = 0, kPlainStep = 1, kPlainRollout = 2;
@@ -1278,7 +1352,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   bool flagged = false;
   // explicit pairs by LDS-DMA (pair_loop_explicit_glds): the plain two-wave build of the explicit-pair mode only -- its launch
   // carries the 6 KiB chunk buffer behind the other regions (stage_base: no staged program, no sphere table in this build)
-  constexpr bool kGlds = STREAM || (OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2 && !STAGE && !PT);
+  constexpr bool kGlds = OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2 && !STAGE && !PT;
   int pf_pb = -1;  // (wave-uniform) pair_begin of the leaf whose first half is in the chunk buffer / in flight
 
   // ---- ragged lists over a small table: the robot's list as a membership mask (built once, by its quad) -----------------
@@ -1714,10 +1788,10 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
   }
   RMP2_STAMP();  // 2: walk done
 
-  // ---- explicit pairs, streamed (OBS = kObsExplicitStream): the pair phase of ALL leaf frames, before any pull-back ----------
-  // (see kObsExplicitStream above).  sh_[t] = this lane's floats {sub, 4 + sub, 8 + sub} of the twelve [p v a -] of leaf frame t
-  // before its pairs ran, of [p S h] after; rj*_s = the (z, o) records of the joints that own my rows.
-  float sh_[STREAM ? kStreamMaxFrames : 1][3];
+  // ---- explicit pairs, streamed (OBS = kObsExplicitStream): what the frame loop needs of the frame records leaves their LDS ---------
+  // (see kObsExplicitStream above).  The (z, o) records of the joints that own my rows go to registers; [p v a] of every leaf-bearing
+  // frame goes to a compact image at the START of the records' region -- nine floats per robot and frame, kStreamMaxFrames frames per
+  // robot: 5 184 B --, and the rest of the region (from kStreamPva floats on) becomes the LDS-DMA chunk buffer of the pair loops.
   float rjz_s[STREAM ? ROWS : 1][3], rjo_s[STREAM ? ROWS : 1][3];
   if constexpr (STREAM) {
 #pragma unroll
@@ -1731,77 +1805,23 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       rjz_s[m][0] = j2.y, rjz_s[m][1] = j2.z, rjz_s[m][2] = j2.w;
       rjo_s[m][0] = j0.x, rjo_s[m][1] = j0.y, rjo_s[m][2] = j0.z;
     }
+    float pva_[kStreamMaxFrames][3];  // my floats {sub, 4 + sub, 8 + sub} of the twelve [p v a -] of leaf frame t
 #pragma unroll
     for (int t = 0; t < kStreamMaxFrames; ++t) {
-      sh_[t][0] = sh_[t][1] = sh_[t][2] = 0.f;
+      pva_[t][0] = pva_[t][1] = pva_[t][2] = 0.f;
       if (t < hdr.n_leaf_ops) {  // (wave-uniform)
         const float* fr = loc + kSlot * prog->leaf_frames[t].op;
-        sh_[t][0] = fr[sub], sh_[t][1] = fr[4 + sub], sh_[t][2] = fr[8 + sub];
+        pva_[t][0] = fr[sub], pva_[t][1] = fr[4 + sub], pva_[t][2] = fr[8 + sub];
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records are in registers: the DMA may overwrite their LDS
-    float* const dma = lds + QuadLds<N>::kLoc;           // [chunk image kGldsBuf | the quads' lists kGldsList] (checked on the host)
-#pragma unroll
-    for (int t = 0; t < kStreamMaxFrames; ++t) {
-      if (t < hdr.n_leaf_ops) {  // (wave-uniform)
-        if (3 * t >= hdr.n_leaf_ops && 3 * (t - 1) < hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(2);      // (thirds, as the frame loop)
-        if (3 * t >= 2 * hdr.n_leaf_ops && 3 * (t - 1) < 2 * hdr.n_leaf_ops) __builtin_amdgcn_s_setprio(1);
-        const int4 lfr = *reinterpret_cast<const int4*>(&prog->leaf_frames[t]);
-        const float r0v = sh_[t][0], r1v = sh_[t][1], r2v = sh_[t][2];
-        const float P3[3] = {bcast<0>(r0v), bcast<1>(r0v), bcast<2>(r0v)};
-        const float V3[3] = {bcast<3>(r0v), bcast<0>(r1v), bcast<1>(r1v)};
-        const float A3[3] = {bcast<2>(r1v), bcast<3>(r1v), bcast<0>(r2v)};
-        // the frame's leaves share its Jacobian, and the pull-back is linear in (S, h): their sums are pulled back ONCE
-        float Ss[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hs[3] = {0.f, 0.f, 0.f};
-        for (int li = 0; li < lfr.w; ++li) {
-          const DevLeaf& lf = prog->exec_leaves[lfr.z + li];
-          const LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
-          float S[6], h[3];
-          if (lh.taskmap == RMP2_TASKMAP_FK_POSITION) {
-            float gl[3], xdd[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gl[c] = my_goal[lh.goal_offset + c];
-            if (lh.kind == RMP2_LEAF_TARGET_ATTRACTOR)
-              target_attractor_fast(lh.P, P3, V3, gl, xdd, S);
-            else
-              leaf_target_policy3(lh.P, P3, V3, gl, xdd, S);
-            const float e[3] = {xdd[0] - A3[0], xdd[1] - A3[1], xdd[2] - A3[2]};
-            h[0] = S[0] * e[0] + S[1] * e[1] + S[2] * e[2];
-            h[1] = S[1] * e[0] + S[3] * e[1] + S[4] * e[2];
-            h[2] = S[2] * e[0] + S[4] * e[1] + S[5] * e[2];
-          } else {  // distance leaf on explicit pairs: 32 pairs per robot (checked on the host), streamed
-#pragma unroll
-            for (int c = 0; c < 6; ++c) S[c] = 0.f;
-            h[0] = h[1] = h[2] = 0.f;
-            const float IP[6] = {lf.vb[0], lf.vb[1], lf.vb[2], lf.vb[3], lf.vb[4], lf.vb[5]};
-            const int pb = obs.pair_begin[lf.index];
-            const int nxt = lf.next_pair_leaf;
-            const int pb_next = nxt >= 0 ? obs.pair_begin[nxt] : -1;
-            const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
-            pair_loop_explicit_glds(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, pb_next, pf_pb, dma, lane, g, sub, P3, V3, A3, lh.P,
-                                    IP, thr * thr * kCullSlack, S, h, hdr.stagger >> 8);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) S[c] = quad_sum(S[c]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) h[c] = quad_sum(h[c]);
-          }
-#pragma unroll
-          for (int c = 0; c < 6; ++c) Ss[c] += S[c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) hs[c] += h[c];
-        }
-        // [p S h]: float `sub`, 4 + sub, 8 + sub of the twelve (every lane of the quad holds all of them)
-        sh_[t][0] = sub == 0 ? P3[0] : (sub == 1 ? P3[1] : (sub == 2 ? P3[2] : Ss[0]));
-        sh_[t][1] = sub == 0 ? Ss[1] : (sub == 1 ? Ss[2] : (sub == 2 ? Ss[3] : Ss[4]));
-        sh_[t][2] = sub == 0 ? Ss[5] : (sub == 1 ? hs[0] : (sub == 2 ? hs[1] : hs[2]));
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no chunk in flight any more: slots 1 .. n_leaf_ops take the sums
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane of the wave has its copies: the records may be overwritten
+    float* const pva = lds + QuadLds<N>::kLoc + g * (kStreamMaxFrames * 9);
 #pragma unroll
     for (int t = 0; t < kStreamMaxFrames; ++t) {
       if (t < hdr.n_leaf_ops) {
-        float* dst = loc + kSlot * (1 + t);   // (slot 0 stays the robot's qdd tile)
-        dst[sub] = sh_[t][0], dst[4 + sub] = sh_[t][1], dst[8 + sub] = sh_[t][2];
+        pva[9 * t + sub] = pva_[t][0];                    // floats 0 .. 3
+        pva[9 * t + 4 + sub] = pva_[t][1];                // floats 4 .. 7
+        if (sub == 0) pva[9 * t + 8] = pva_[t][2];        // float 8 (9 .. 11 of the record: the joint axis, not needed here)
       }
     }
   }
@@ -1872,9 +1892,16 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       }
       RMP2_SEG_BEGIN();
       // full 3-vectors of the frame in every lane (written by the walk; broadcast reads)
-      const float4* fr4 = reinterpret_cast<const float4*>(floc + kSlot * (STREAM ? 1 + t : k));
-      const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
-      const float P3[3] = {f0.x, f0.y, f0.z}, V3[3] = {f0.w, f1.x, f1.y}, A3[3] = {f1.z, f1.w, f2.x};
+      float P3[3], V3[3], A3[3];
+      if constexpr (STREAM) {  // the compact [p v a] image (nine floats per robot and leaf frame)
+        const float* pv = lds + QuadLds<N>::kLoc + g * (kStreamMaxFrames * 9) + 9 * t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P3[c] = pv[c], V3[c] = pv[3 + c], A3[c] = pv[6 + c];
+      } else {
+        const float4* fr4 = reinterpret_cast<const float4*>(floc + kSlot * k);
+        const float4 f0 = fr4[0], f1 = fr4[1], f2 = fr4[2];
+        P3[0] = f0.x, P3[1] = f0.y, P3[2] = f0.z, V3[0] = f0.w, V3[1] = f1.x, V3[2] = f1.y, A3[0] = f1.z, A3[1] = f1.w, A3[2] = f2.x;
+      }
       // Jacobian columns of the frame: formed AFTER the first leaf's (S, h) -- the pair loop is where the time goes and
       // it runs with 36 fewer live registers this way (the kernel must fit 128 for four waves per SIMD)
       float mycol[ROWS][3];
@@ -1882,17 +1909,12 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
 #pragma unroll       //  nine registers live through the pair loop; the 256-register build has them to spare)
         for (int m = 0; m < ROWS; ++m) mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;
       }
-      for (int li = 0; li < (STREAM ? 1 : op.leaf_count); ++li) {
+      for (int li = 0; li < op.leaf_count; ++li) {
         float S[6], h[3];
         // attached-point leaf: the sums over its pairs that the pull-back below needs (see there)
         bool pt_leaf = false;
         float ptW = 0.f, ptRho[3] = {0.f, 0.f, 0.f}, ptQ[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ptTau[3] = {0.f, 0.f, 0.f};
-        if constexpr (STREAM) {
-          // streamed explicit pairs: the pair phase ran before this pass and left [p S h] of the frame -- the sums over ALL its
-          // leaves -- in slot 1 + t (read above as f0, f1, f2)
-          S[0] = f0.w, S[1] = f1.x, S[2] = f1.y, S[3] = f1.z, S[4] = f1.w, S[5] = f2.x;
-          h[0] = f2.y, h[1] = f2.z, h[2] = f2.w;
-        } else {
+        {
           const DevLeaf& lf = STAGE ? leaves[uni<STAGE>(fk_list[op.leaf_begin + li])] : prog->exec_leaves[op.leaf_begin + li];
           LeafHead lh = *reinterpret_cast<const LeafHead*>(&lf);  // one 64-byte load
           lh.kind = uni<STAGE>(lh.kind);
@@ -2068,7 +2090,15 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
               const size_t base = ((size_t)(live ? robot : 0) * obs.n_pairs + pb) * 3;
               // (cull threshold of THIS leaf: x = max(d - margin, 0) > metric_modulation_radius  <=>  d > margin + radius)
               const float thr = fmaxf(lh.P[0] + lh.P[7], 0.f);
-              if (kGlds && obs.glds && count == 32) {  // (wave-uniform) streamed half a leaf ahead by LDS-DMA
+              if constexpr (STREAM) {  // a quarter leaf at a time through the chunk buffer behind the compact [p v a] image (32 pairs per leaf: host)
+              const int nxt = lf.next_pair_leaf;
+              // (the buffer's offset is a compile-time constant: laundered, because the compiler folds the generic-to-LDS cast of a
+              //  CONSTANT address inside global_load_lds into an instruction the assembler rejects -- V_CMP with src_shared_base)
+              int dma_off = QuadLds<N>::kLoc + kStreamPva;
+              asm volatile("" : "+s"(dma_off));
+              pair_loop_explicit_qdma(obs.p_link, obs.p_obs, obs.n_pairs, r0, R, pb, nxt >= 0 ? obs.pair_begin[nxt] : -1, pf_pb,
+                                      lds + dma_off, lane, g, sub, P3, V3, A3, lh.P, IP, thr * thr * kCullSlack, S, h, hdr.stagger >> 8);
+            } else if (kGlds && obs.glds && count == 32) {  // (wave-uniform) streamed half a leaf ahead by LDS-DMA
                 const int nxt = lf.next_pair_leaf;
                 int pb_next = -1;
                 if (nxt >= 0) {
@@ -2511,7 +2541,8 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
       // slot 0 doubles as the qdd tile: a flagged robot keeps its slots for the careful pass below
       if (sub == 0 && !flagged) {
         static_assert(N <= kSlot, "the qdd tile of a robot is its first frame slot");
-        int mo_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);  // (formed here: hoisted to the prologue it is spilled and reloaded per dof)
+        // (streamed explicit pairs: the frame slots hold the [p v a] image and the chunk buffer -- the robot's own q row takes its qdd)
+        int mo_off = STREAM ? QuadLds<N>::kQ + g * N : QuadLds<N>::kLoc + gi_loc(g, n_ops);  // (formed here: hoisted to the prologue it is spilled and reloaded per dof)
         if (MINW >= 3) asm volatile("" : "+v"(mo_off));
         float* mo = lds + mo_off;
 #pragma unroll
@@ -2545,7 +2576,7 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         if (dropped) status |= RMP2_STATUS_RANK_DROP;
       }
       bool finite = true;
-      int co_off = QuadLds<N>::kLoc + gi_loc(g, n_ops);
+      int co_off = STREAM ? QuadLds<N>::kQ + g * N : QuadLds<N>::kLoc + gi_loc(g, n_ops);
       if (MINW >= 3) asm volatile("" : "+v"(co_off));
       float* co = lds + co_off;
       for (int i = 0; i < n_dof; ++i) {
@@ -2595,12 +2626,13 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     }
   }
   {
-    const float* tile = &lds[QuadLds<N>::kLoc];
+    const float* tile = &lds[STREAM ? QuadLds<N>::kQ : QuadLds<N>::kLoc];
+    const int tile_stride = STREAM ? N : out_stride;
     const int count = min(kRobotsPerWave, R - r0) * n_dof;
     float* go = out.qdd + (size_t)r0 * n_dof;
     for (int i = lane_o; i < count; i += kWave) {
       const int rr = i / n_dof, jj = i - rr * n_dof;
-      go[i] = tile[rr * out_stride + jj];
+      go[i] = tile[rr * tile_stride + jj];
     }
   }
   if (out.status && live && sub == 0) out.status[robot] = status;

@@ -153,20 +153,15 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
     }
   }
   if constexpr (N == 9) {
-    // interface B (explicit closest-point pairs), plain control step: the STREAMED form (rmp2_quad.h kObsExplicitStream) -- pair
-    // phase before the pull-back, pair arrays by LDS-DMA through the frame records' LDS, 128 registers / 9.6 KB per wave: sixteen
-    // waves per CU.  OPT-IN (RMP2_EXPLICIT_STREAM=1): built, parity-tested and measured in round 5 -- NOT faster (65 536 robots:
-    // 111-124 us against 105-108 for the single-loop two-wave form; profiles/r05_interface_b.txt): its stream runs at 6 TB/s and
-    // its arithmetic hides under it entirely, but with every wave of the fleet resident in ONE round a wave's walk, stream and
-    // pull-back are serial and the launch lasts as long as one wave does: 56 us + 68 us.  Needs: 32 pairs per distance leaf and
-    // 16-byte aligned leaf segments (the DMA moves 16-byte pieces), at most kStreamMaxFrames leaf-bearing frames with a frame slot
-    // each behind slot 0, frame slots that hold the chunk image and the quads' lists, an inertia leaf (the rank-one pull-back lives
-    // in the general builds).
+    // interface B (explicit closest-point pairs), plain control step: the STREAMED form (rmp2_quad.h kObsExplicitStream) -- the pair
+    // arrays by LDS-DMA a quarter leaf at a time beside a four-wave working set (128 registers / 9.6 KB per wave: sixteen waves per
+    // CU).  Needs: 32 pairs per distance leaf and 16-byte aligned leaf segments (the DMA moves 16-byte pieces), at most
+    // kStreamMaxFrames leaf-bearing frames, frame slots that hold the compact [p v a] image and the chunk buffer, an inertia leaf (the
+    // rank-one pull-back lives in the general builds).  RMP2_EXPLICIT_STREAM=0 | 1 forces the single-loop two-wave form / this one.
     const int stream_env = h->explicit_stream;
     bool stream = o.mode == RMP2_OBS_EXPLICIT_PAIRS && !latency && !with_records && plain && !o.capsule && !o.dist &&
                   !h->likely_singular && stream_env == 1 &&
-                  h->n_leaf_ops <= kStreamMaxFrames && h->n_ops_step >= h->n_leaf_ops + 1 &&
-                  kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) >= kGldsBuf + kGldsList &&
+                  h->n_leaf_ops <= kStreamMaxFrames && kSlot * kRobotsPerWave * quad_slots(h->n_ops_step) >= kStreamPva + kQdmaBuf &&
                   (o.n_pairs % 4) == 0 && (reinterpret_cast<uintptr_t>(o.p_link) % 16) == 0 && (reinterpret_cast<uintptr_t>(o.p_obs) % 16) == 0;
     for (int l : h->distance_leaves)
       stream = stream && (h->h_pair_begin[l] % 4) == 0 && h->h_pair_begin[l + 1] - h->h_pair_begin[l] == 32;

@@ -13,10 +13,10 @@ s = Cf.sample_panda_states(np.random.default_rng(1), R)
 sph = Cf.sample_spheres(np.random.default_rng(7), Cf.N_SPHERES)
 q, qd, goal = (torch.from_numpy(s[k]).cuda() for k in ("q", "qd", "goal"))
 print("# config3b, 65 536 robots, solve = pinv: us per step of the streamed explicit-pair step and of its two halves")
-for label, env in (("single-loop two-wave form", dict(RMP2_EXPLICIT_STREAM="0")), ("streamed", dict(RMP2_STREAM_STAGGER="0")),
-                   ("streamed, no pair in range (stream + everything but the pair arithmetic)", dict(RMP2_STREAM_STAGGER="256")),
-                   ("streamed, no DMA issued (everything but the stream)", dict(RMP2_STREAM_STAGGER="512")),
-                   ("streamed, neither", dict(RMP2_STREAM_STAGGER="768"))):
+for label, env in (("single-loop two-wave form", dict(RMP2_EXPLICIT_STREAM="0")), ("streamed", dict(RMP2_EXPLICIT_STREAM="1", RMP2_STREAM_STAGGER="0")),
+                   ("streamed, no pair in range (stream + everything but the pair arithmetic)", dict(RMP2_EXPLICIT_STREAM="1", RMP2_STREAM_STAGGER="256")),
+                   ("streamed, no DMA issued (everything but the stream)", dict(RMP2_EXPLICIT_STREAM="1", RMP2_STREAM_STAGGER="512")),
+                   ("streamed, neither", dict(RMP2_EXPLICIT_STREAM="1", RMP2_STREAM_STAGGER="768"))):
     os.environ.update(env)
     _, desc = Cf.config3("pinv")
     eng = Engine(desc, 0)
