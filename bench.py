@@ -20,9 +20,15 @@ Workloads (BASELINE.json configs[1..4]; weak scaling: the per-GPU fleet is fixed
 anything in this process touches a GPU) and fails loudly when the node has fewer devices; under
 `torch.distributed.run` the ranks are taken from the environment.
 
+`--solve pinv` (the default: the reference's only resolve, rmp.py:148-152, as one certifying launch) gives the line's `value`;
+the same workload under `--solve auto` (elimination without the certificate) rides along as the nested `solve_auto` object.
+
 Rank 0 prints ONE JSON line (contract in the task description): whole-job steps/s, the roofline fractions of the
-control-step kernel from the ALGORITHMIC bytes / flops of BASELINE.md section 3, and (N = 1) a CPU baseline
-timed on this box's host cores on a bounded sample.
+control-step kernel from the ALGORITHMIC bytes / flops of BASELINE.md section 3 (and, beside them, from the flops this run
+EXECUTED: `roofline.executed_frac`), and (N = 1) a CPU baseline timed on this box's host cores on a bounded sample.  N > 1
+lines carry `world1_same_workload_ms`: the same workload on every rank's own shard with a one-rank communicator, MAX over ranks
+-- the like-for-like base of a weak-scaling efficiency.  No child process is started once HIP has been touched (host facts come
+from /proc, the libraries are built in `preflight()` before the first device call).
 """
 from __future__ import annotations
 

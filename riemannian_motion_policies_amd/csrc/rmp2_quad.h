@@ -1241,6 +1241,13 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
     const int slot = __builtin_amdgcn_s_getreg(0x1804) & 3;  // HW_ID[3:0]: the wave's slot in its SIMD
     for (int i = 0; i < slot * (hdr.stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
   }
+  if constexpr (OBS == RMP2_OBS_EXPLICIT_PAIRS && FLAVOR == kPlainStep && MINW == 2) {
+    // The same question for the two-wave form (two ROUNDS at 65 536 robots): the odd slot of every SIMD starts its first wave late,
+    // so that one wave of a SIMD streams while the other walks or pulls back, and the offset carries into the second round by itself
+    // (a slot's next wave starts when its first ends).  Only the first round sleeps.  RMP2_STREAM_STAGGER=n, opt-in.
+    if ((hdr.stagger & 255) != 0 && block_idx < MINW * 1024 && (__builtin_amdgcn_s_getreg(0x1804) & 1))
+      for (int i = 0; i < (hdr.stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int lane = threadIdx.x;
   const int sub = lane & 3;
   const int g = lane >> 2;
