@@ -571,6 +571,13 @@ def world1_leg(args, dev, local_rank, rank, world, R, timer):
             from riemannian_motion_policies_amd import configs as Cf
             exch1 = NativeObstacleExchange(Cf.N_SPHERES, dev, depth=args.exchange_depth, rank=0, world=1,
                                            uid=NativeObstacleExchange.unique_id())
+        else:
+            # (the torch-driven exchange would gather over the job's DEFAULT group: N ranks, not one -- a one-rank exchange is its
+            #  local-copy form; no collective of the job is issued inside this leg)
+            from riemannian_motion_policies_amd.fleet import ObstacleExchange
+            from riemannian_motion_policies_amd import configs as Cf
+            exch1 = ObstacleExchange(Cf.N_SPHERES, dev, collective=False)
+            info["what"] = "config 4 at world 1 on every rank's own shard (torch-driven exchange of one rank: a local copy), MAX over ranks"
         import copy
         a1 = copy.copy(args)
         one_step, eng1, *_rest = build_config34("config4", a1, dev, local_rank, 0, 1, R, seed_rank=rank, exch=exch1)
@@ -736,7 +743,7 @@ def emulate_world(args, workload, dev, local_rank, use_dist):
                 "max_us": max(x["us_per_step"] for x in v),
                 "imbalance_max_over_mean": max(x["us_per_step"] for x in v) / (sum(x["us_per_step"] for x in v) / len(v))}
             for k, v in extra["plans"].items()}
-    print(json.dumps(line), flush=True)
+    emit(line)
     return 0
 
 
@@ -974,11 +981,26 @@ def worker(args) -> int:
                          "full rank certified per robot inside the elimination (pinv = inv there), Jacobi pseudo-inverse for the rest")}
         if not args.no_cpu_baseline and world == 1 and desc is not None:
             line["cpu_baseline"] = cpu_baseline(workload, desc, table, s, spheres_np)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return rc
+
+
+REAL_STDOUT = None   # fd of the process's real stdout once main() has pointed fd 1 at stderr
+
+
+def emit(line) -> None:
+    """The ONE JSON line, on the real stdout.  main() points fd 1 at stderr for the rest of the process: RCCL prints a version banner
+    on fd 1 when a process creates its first communicator (torch's, or the library's own in a rehearsal), rocprofv3 and hipcc talk
+    there too, and under torch.distributed.run every rank shares the launcher's stdout -- none of it may reach the line's reader."""
+    text = json.dumps(line) + "\n"
+    if REAL_STDOUT is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        os.write(REAL_STDOUT, text.encode())
 
 
 def preflight():
@@ -1036,6 +1058,10 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     preflight()
     sys.exit(worker(args))
 

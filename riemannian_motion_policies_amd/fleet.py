@@ -90,9 +90,11 @@ class ObstacleExchange:
     stream shares a queue with the compute stream the gather serialises behind the kernel it should overlap (+20 us per
     step measured).  Export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises (bench.py does)."""
 
-    def __init__(self, spheres_per_rank: int, device, group=None):
+    def __init__(self, spheres_per_rank: int, device, group=None, collective=None):
+        # collective=False: a one-rank exchange (the slice is the table, a local copy) inside a job whose default group is larger --
+        # what bench.py's world-1 leg of an N-rank run needs; no rank of the job is involved.
         self.group = group
-        self.collective = dist.is_available() and dist.is_initialized()
+        self.collective = (dist.is_available() and dist.is_initialized()) if collective is None else bool(collective)
         self.world = dist.get_world_size(group) if self.collective else 1
         self.rank = dist.get_rank(group) if self.collective else 0
         self.device = torch.device(device)

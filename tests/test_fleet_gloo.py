@@ -38,6 +38,14 @@ def _worker(rank, world, port, tmp):
     for shift in (1.0, 2.0):
         assert np.array_equal(ex.finish().numpy(), spheres + np.float32(shift))
         ex.consumed()
+    # a one-rank exchange INSIDE the two-rank job (bench.py's world-1 leg): the slice is the table, no collective of the job is
+    # issued -- rank 1 makes an extra exchange step that rank 0 does not, which a gather over the default group would hang on
+    solo = ObstacleExchange(K, "cpu", collective=False)
+    assert solo.world == 1 and solo.rank == 0 and solo.tables[0].shape == (K, 4)
+    for _ in range(1 + rank):
+        solo.start(torch.from_numpy(spheres + np.float32(rank)))
+        assert np.array_equal(solo.finish().numpy(), spheres + np.float32(rank))
+        solo.consumed()
     sl = slice(start, start + count)
     r = O.step(desc, s["q"][sl], s["qd"][sl], s["goal"][sl], spheres=table)
     np.save(os.path.join(tmp, f"qdd_{rank}.npy"), r["qdd"])

@@ -13,3 +13,19 @@ import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('131072 robots, stagger $s'.ljust(28), '%8.2f us' % (j['ms_per_step']*1e3))"
 done; } > $O/interface_b_stagger_two_wave.txt 2>&1
 cat $O/interface_b_stagger_two_wave.txt | cut -c1-200
+# the two-rank rehearsal in the driver's launcher shape (hung in the round's first evidence run: the world-1 leg of a job that had
+# fallen back to the torch-driven exchange gathered over the job's default group)
+F=$O/final; mkdir -p $F
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse-one-gpu --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $F/rehearsal_2ranks_config4_torchrun.json 2> $F/rehearsal_2ranks_config4_torchrun.err; echo "torchrun rehearsal rc=$?"
+timeout -k 10 300 python bench.py --gpus 2 --rehearse-one-gpu --steps 200 --warmup 20 --rank-timeout 250 --no-cpu-baseline --no-secondary > $F/rehearsal_2ranks_config4.json 2> $F/rehearsal_2ranks_config4.err; echo "launcher rehearsal rc=$?"
+wc -l $F/rehearsal_2ranks_config4_torchrun.json $F/rehearsal_2ranks_config4.json
+python - <<'PY'
+import json
+for n in ("config4_torchrun", "config4"):
+    try:
+        j = json.loads(open(f"gpurun_out/r05/final/rehearsal_2ranks_{n}.json").read())
+        print(n, {k: j.get(k) for k in ("value", "ms_per_step", "exchange", "rccl_nranks", "world1_same_workload_ms")}, j["world1_same_workload"]["what"][:90])
+    except Exception as e:
+        print(n, "no line", repr(e)[:200])
+PY
+tail -3 $F/rehearsal_2ranks_config4_torchrun.err | cut -c1-300
