@@ -5,7 +5,7 @@ O=gpurun_out/r05; mkdir -p $O
 for s in 0 2 4 6 8 10 12 16; do
   RMP2_STREAM_STAGGER=$s python bench.py --workload config3b --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import sys, json
-j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stagger $s'.ljust(14), '%8.2f us' % (j['ms_per_step']*1e3), ' rejected', j['result_check']['rejected'], ' [' + j['kernel'][:70] + ']')"
+j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stagger $s'.ljust(14), '%8.2f us' % (j['ms_per_step']*1e3), ' rejected', j['result_check']['rejected'], ' [' + str(j['config'].get('kernel', ''))[:70] + ']')"
 done
 for s in 0 6; do
   RMP2_STREAM_STAGGER=$s python bench.py --workload config3b --robots 131072 --steps 50 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
