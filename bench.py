@@ -311,8 +311,9 @@ class Timed:
         for _ in range(warmup):
             one_step()
         grp = 8 if steps >= 16 else 1
-        n_groups = min(8, steps // grp)
-        starts = {int(round(k * (steps - grp) / max(n_groups - 1, 1))) for k in range(n_groups)}
+        # (K = 20, the driver's run: ONE group of eight, the region's last eight steps -- an event pair costs GPU time inside the region)
+        n_groups = min(8, steps) if grp == 1 else min(8, max(1, steps // (4 * grp)))
+        starts = {int(round(k * (steps - grp) / max(n_groups - 1, 1))) for k in range(n_groups)} if n_groups > 1 else {steps - grp}
         ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sorted(starts)}
         ends = {i + grp - 1: i for i in ev}
         stream = torch.cuda.current_stream(self.dev)

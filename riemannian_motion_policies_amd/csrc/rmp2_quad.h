@@ -303,6 +303,10 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
 //           bit) and only those pairs run the transcendental chain.
 // Table image in LDS for K spheres: K x float4 {-2cx, -2cy, -2cz, w} followed by K radii.
 constexpr float kCullSlack = 1.0002f;
+#ifndef RMP2_TRIP_AHEAD
+#define RMP2_TRIP_AHEAD 1
+#endif
+constexpr bool kTripAhead = RMP2_TRIP_AHEAD != 0;
 __host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
 // quad mapping: capsule tables keep only the four-float range-test records in LDS (bounding sphere of the capsule); the
 // capsule itself (8 floats) is fetched from global memory by the lanes that evaluate an in-range pair -- 512 B for 32
@@ -411,6 +415,8 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       sidx_ = on_ ? pos : 0;
       if (RAGGED) sidx_ = on_ ? ci[pos] : 0;
     };
+    // (sphere tables, kTripAhead: the staged record {-2c, w} and the radius of the NEXT trip are read from LDS before this trip's
+    //  chain starts -- the read's latency, and for ragged lists the list entry's before it, hide behind ~80 instructions)
     bool on_n = false;
     int sidx_n = 0;
     float4 ca_n = make_float4(0.f, 0.f, 0.f, 0.f), cb_n = ca_n;
@@ -418,12 +424,16 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       take(on_n, sidx_n);
       ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
       cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+    } else if (kTripAhead) {
+      take(on_n, sidx_n);
+      ca_n = aux[sidx_n];
+      cb_n.x = rad[sidx_n];
     }
     while (true) {
       bool on;
       int sidx;
       float4 ca, cb;
-      if (CAPS) {
+      if (CAPS || kTripAhead) {
         on = on_n, sidx = sidx_n, ca = ca_n, cb = cb_n;
       } else {
         take(on, sidx);
@@ -434,6 +444,11 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
 #endif
       float diff[3], r;
       float d_cyl = 0.f, n_cyl[3] = {0.f, 0.f, 0.f};
+      if (!CAPS && kTripAhead) {
+        take(on_n, sidx_n);
+        ca_n = aux[sidx_n];
+        cb_n.x = rad[sidx_n];
+      }
       if (CAPS) {
         take(on_n, sidx_n);
         ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
@@ -453,8 +468,8 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
         diff[0] = P3[0] - ctr[0], diff[1] = P3[1] - ctr[1], diff[2] = P3[2] - ctr[2];
         r = ca.w;
       } else {
-        const float4 a = aux[sidx];
-        r = rad[sidx];
+        const float4 a = kTripAhead ? ca : aux[sidx];
+        r = kTripAhead ? cb.x : rad[sidx];
         diff[0] = fmaf(0.5f, a.x, P3[0]), diff[1] = fmaf(0.5f, a.y, P3[1]), diff[2] = fmaf(0.5f, a.z, P3[2]);  // p - c, exactly
       }
       const float d2 = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];

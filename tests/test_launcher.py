@@ -100,11 +100,11 @@ def test_stub_collective_library_exports_what_the_exchange_binds():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The line `python bench.py` printed on the GPU box this round (profiles/r04_bench_default.json): every field the driver's
-    contract names, the roofline and cpu_baseline objects, and the round-4 additions (tolerance rule + robots admitted per branch
-    in result_check)."""
+    """The line `python bench.py` printed on the GPU box this round (profiles/r05_bench_default.json): every field the driver's
+    contract names, the roofline and cpu_baseline objects, the tolerance rule + robots admitted per clause in result_check, and the
+    round-5 additions: `value` on solve = "pinv" with the auto leg nested, the executed-flop fraction beside the algorithmic one."""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -121,6 +121,11 @@ def test_committed_bench_line_keeps_the_contract():
     assert cpu["kind"] in ("port", "reference")
     chk = line["result_check"]
     assert chk["rejected"] == 0 and sum(chk["admitted_by"].values()) == chk["robots_checked"] and "north star" in chk["tolerance"]
+    assert set(chk["passing_each_clause_on_its_own"]) == {"A", "B", "E"}
+    assert line["config"]["solve"] == "pinv" and "solve_auto" in line and line["solve_auto"]["ms_per_step"] > 0
+    assert line["value"] >= 1.43e9                                            # (the round-4 review's bar for the pinv headline)
+    assert 0 < roof["executed_frac"] < roof["frac"] and roof["executed_flops_per_robot_step"] < 66.0e3
+    assert len(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().strip().splitlines()) == 1   # ONE line on stdout
 
 
 def test_spawned_ranks_share_device_0_in_a_rehearsal(monkeypatch):
@@ -150,13 +155,13 @@ def test_spawned_ranks_share_device_0_in_a_rehearsal(monkeypatch):
 
 
 def test_committed_two_rank_rehearsal_lines():
-    """profiles/r04_rehearsal_2ranks_*.json: what `tools/gpu_calls_r04_rehearsal.sh` printed on the one-GPU box -- two rank
+    """profiles/r05_rehearsal_2ranks_*.json: what `tools/refresh_profiles_r05.sh` printed on the one-GPU box -- two rank
     PROCESSES through bench.py's own launcher and through torch.distributed.run (the driver's command shape).  Config 4: the
     native exchange's communicator failed on both ranks (RCCL refuses two ranks on one device), the ranks agreed and every rank
     took the torch-driven exchange; both configs: every checked robot passed the gate; each line says it is a rehearsal."""
     import json
     for name in ("config4", "config4_torchrun", "config5"):
-        line = json.loads(open(os.path.join(ROOT, "profiles", f"r04_rehearsal_2ranks_{name}.json")).read().strip().splitlines()[-1])
+        line = json.loads(open(os.path.join(ROOT, "profiles", f"r05_rehearsal_2ranks_{name}.json")).read().strip().splitlines()[-1])
         assert line["rehearsal"]["ranks"] == 2 and line["rehearsal"]["gpus"] == 1 and line["n_gpus"] == 1
         assert "NOT a scaling measurement" in line["rehearsal"]["note"]
         total = line["config"]["robots_per_gpu"] * 2
@@ -168,3 +173,5 @@ def test_committed_two_rank_rehearsal_lines():
             assert chk["rejected"] == 0
             assert line["exchange"] == "torch" and "every rank took --exchange torch" in line["exchange_fell_back"]
             assert line["rccl_nranks"] is None
+            # the world-1 leg of the same workload: every rank's own shard, no collective of the job inside it
+            assert 0 < line["world1_same_workload_ms"] < line["ms_per_step"] and "MAX over ranks" in line["world1_same_workload"]["what"]

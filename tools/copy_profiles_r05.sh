@@ -17,6 +17,8 @@ if [ -f $B/interface_b_stream.txt ]; then
     echo; echo "# (2) its SQ counters against the default form's (rocprofv3 --pmc, own passes)"; cat $B/interface_b_stream_counters.txt
     echo; echo "# (3) the waves of a SIMD staggered by their slot (RMP2_STREAM_STAGGER, shader-clock units of 64)"; cat $B/interface_b_stagger.txt
     echo; echo "# (4) the single-loop streamed form in the tree (RMP2_EXPLICIT_STREAM=1) and its floors: pair arithmetic off / DMA off / both off"
-    cat $B/interface_b_floor.txt; } | cut -c1-400 > profiles/r05_interface_b.txt
+    cat $B/interface_b_floor.txt
+    echo; echo "# (5) the default two-wave form with the odd wave slot of every SIMD started late (first round only; RMP2_STREAM_STAGGER=n)"
+    cat $B/interface_b_stagger_two_wave.txt; } | cut -c1-400 > profiles/r05_interface_b.txt
 fi
 ls profiles | grep r05_ | wc -l

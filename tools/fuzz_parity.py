@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Parity fuzz campaign: random robots x random RMP sets x obstacle interfaces x kernel mappings x resolves, the HIP engine
-against the CPU oracle through oracle.accuracy_gate.  Every robot gets a bound; three classes get a WEAKER one than the gate's,
+against the CPU oracle through oracle.accuracy_gate (clauses A-D; a case with a robot outside them is judged with clause E too: within
+twice the fp32 envelope of the fp64 evaluation).  Every robot gets a bound; three classes get a WEAKER one than the gate's,
 each counted in the summary and capped by tests/test_gpu_fuzz.py: robots whose system is undetermined at fp32 (backward error
 only), single dofs whose only metric is a tiny projection (that dof excused, the robot's other dofs gated), robots this harness
 fed a non-finite state (NaN + status bit accepted where the reference's graph never reaches the value).
@@ -569,6 +570,13 @@ def run_case(seed, torch, verbose=False):
             res = np.fmax(res, np.abs(r32 - ref["qdd64"]).max(axis=1))
     sys_res = O.system_resolution(ref)
     verdict = O.accuracy_gate(got, ref, spread=res, system_spread=sys_res)
+    envelope_kw = {}
+    if not verdict["ok"].all():
+        # clause E, as tests/test_gpu_accuracy_envelope.py and bench.py judge the perf fleets (oracle.ETA came down from 1e-4 to 2e-5 with
+        # it): a robot outside A-D may be no further from the fp64 evaluation than twice what 17 fp32 evaluations of the reference's
+        # formulae are seen to land.  Computed only for cases that need it (17 oracle passes over the case).
+        envelope_kw = dict(truth=O.step(desc, q, qd, goal, precision="f64", **kw)["qdd64"], envelope=O.fp32_envelope(desc, q, qd, goal, **kw))
+        verdict = O.accuracy_gate(got, ref, spread=res, system_spread=sys_res, **envelope_kw)
     summary = O.gate_summary(verdict)
     # Robots whose system is UNDETERMINED at fp32: a singular value of the oracle's M inside (1e-18, 1e-6] x sigma_max.  M is built
     # from fp32 leaves (rmp.py:133-151: relative noise ~1e-7) and resolved in fp64 with TensorFlow's cutoff 10 n eps64 sigma_max
@@ -606,6 +614,10 @@ def run_case(seed, torch, verbose=False):
         # the first q-double-dot of the rollout (often ANOTHER mapping than the plain step's: rollouts of strict / singular sets run
         # on the hex mapping at any fleet size) goes through the same gate against the oracle, every robot
         vr = O.accuracy_gate(rollout_first, ref, spread=res, system_spread=sys_res)
+        if not vr["ok"].all():
+            if not envelope_kw:
+                envelope_kw = dict(truth=O.step(desc, q, qd, goal, precision="f64", **kw)["qdd64"], envelope=O.fp32_envelope(desc, q, qd, goal, **kw))
+            vr = O.accuracy_gate(rollout_first, ref, spread=res, system_spread=sys_res, **envelope_kw)
         fin_r = np.isfinite(rollout_first).all(axis=1)
         ok_r = vr["ok"] | (undetermined & fin_r & (vr["omega"] <= O.ETA)) | (dead & ~fin_r)
         ok_r |= excused_by_tiny_dofs(O, rollout_first, ref, tiny_alone, ~ok_r, res, sys_res)   # (the known limitation above, per dof)
