@@ -474,10 +474,13 @@ __device__ __forceinline__ void leaf_obstacle_avoidance(const float* __restrict_
   const float base = mscal / (x / estd + eeps);
   const float gate = x * x / (radius * radius) - 2.0f * x / radius + 1.0f;
   const float repel = rgain * expf(-(x / rstd));
-  const float sig = 1.0f / (1.0f + expf(-(xd / gate_len)));
-  const float damp = -(1.0f - sig) * dgain * xd / (x / dstd + deps);
+  // 1 - sigmoid(z) without the cancellation of `1. - tf.sigmoid(z)` for z > 0 (rmp2_quad.h obstacle_pair)
+  const float zg = xd / gate_len;
+  const float ez = expf(-fabsf(zg));
+  const float oms = (zg > 0.0f ? (zg > 17.328680f ? 0.0f : ez) : 1.0f) / (1.0f + ez);   // (25 ln 2: an fp32 sigmoid is 1 beyond, the gate an exact 0)
+  const float damp = -oms * dgain * xd / (x / dstd + deps);
   accel = repel + damp;
-  metric = (x > radius) ? 0.0f : (1.0f - sig) * (base * gate);
+  metric = (x > radius) ? 0.0f : oms * (base * gate);
 }
 
 // ---- pull-back of a position-type leaf into the fp64 accumulators ------------------------
@@ -566,7 +569,10 @@ __device__ __forceinline__ RankOne rank_one_of(const float S[6]) {
   RankOne r;
   const float tr = S[0] + S[3] + S[5];
   const float f2 = S[0] * S[0] + S[3] * S[3] + S[5] * S[5] + 2.f * (S[1] * S[1] + S[2] * S[2] + S[4] * S[4]);
-  r.on = tr > 0.f && (tr * tr - f2) <= 4e-7f * (tr * tr);  // 2 lambda_1 lambda_2 <= 4e-7 tr^2 (NaN compares false)
+  // 2 lambda_1 lambda_2 <= 4e-7 tr^2 (NaN compares false).  tr > 1e-15: below that tr^2 and dk tr leave fp32's normal range -- the
+  // test would read 0 <= 0, the normalisation rsqrt(0) (fuzz seeds 33 / 200016 / 300032 once the velocity gate 1 - sigmoid stopped
+  // rounding to an exact 0: a pair's weight of 1e-24 turned its robot into NaN) -- and a metric that small takes the general form
+  r.on = tr > 1e-15f && (tr * tr - f2) <= 4e-7f * (tr * tr);
   const bool k0 = S[0] >= S[3] && S[0] >= S[5], k1 = !k0 && S[3] >= S[5];
   const float dk = k0 ? S[0] : (k1 ? S[3] : S[5]);
   const float inv = r.on ? rsqrtf(dk * tr) : 0.f;

@@ -152,7 +152,17 @@ __device__ __forceinline__ void obstacle_pair(const float* P, const float* IP, f
   const float base = P[8] * rcp0(fmaf(x, IP[0], P[10]));
   const float gate = fmaf(x * x, IP[4], fmaf(-x, IP[5], 1.0f));
   const float repel = P[5] * __builtin_amdgcn_exp2f(-(x * IP[1]));
-  const float oms = 1.0f - rcp0(1.0f + __builtin_amdgcn_exp2f(-(xd * IP[3])));  // 1 - sigmoid
+  // 1 - sigmoid(z), z = xd / gate_len, as e^-|z| / (1 + e^-|z|) for z > 0 and 1 / (1 + e^-|z|) otherwise: the reference's
+  // `1. - tf.sigmoid(z)` (rmp2.py:189-194) cancels for a control point that moves AWAY from the obstacle -- at z = 7.5 the 1e-7 of a
+  // rounded sigmoid are 2e-4 of the gate, which scales the pair's metric and damping (fuzz seed 2000473: a point inside a capsule, its
+  // leaf's weight in M and f off by 1.1e-4 while an fp32 evaluation is only off by what its roundings happen to be); this form is
+  // good to a few ulp of the gate itself, i.e. closer to the exact value of the reference's formula than its own fp32 arithmetic
+  // Beyond z = 25 ln 2 = 17.33 an fp32 sigmoid IS 1 and the reference's gate an exact 0 (a robot whose only metric is such a pair
+  // rests: pinv(0) 0 = 0 -- fuzz seed 300057): kept, so that a weight of 1e-30 never turns into an acceleration.
+  const float z2 = xd * IP[3];                              // z log2(e)
+  const float ez = __builtin_amdgcn_exp2f(-fabsf(z2));
+  const float rz = rcp0(1.0f + ez);
+  const float oms = (z2 > 0.0f ? (z2 > 25.0f ? 0.0f : ez) : 1.0f) * rz;
   const float damp = -oms * P[1] * xd * rcp0(fmaf(x, IP[2], P[3]));
   accel = repel + damp;
   metric = (x > P[7]) ? 0.0f : oms * (base * gate);
@@ -304,9 +314,13 @@ __device__ __forceinline__ void pair_loop(const float* sph, const float* pl, con
 // Table image in LDS for K spheres: K x float4 {-2cx, -2cy, -2cz, w} followed by K radii.
 constexpr float kCullSlack = 1.0002f;
 #ifndef RMP2_TRIP_AHEAD
-#define RMP2_TRIP_AHEAD 1
+#define RMP2_TRIP_AHEAD 0   // measured (profiles/r05_pair_loop_ab.txt): 44.1 us against 43.8 for config 3 -- four waves per SIMD cover the read already
 #endif
 constexpr bool kTripAhead = RMP2_TRIP_AHEAD != 0;
+#ifndef RMP2_BATCHED_TESTS
+#define RMP2_BATCHED_TESTS 1
+#endif
+constexpr bool kBatchedTests = RMP2_BATCHED_TESTS != 0;
 __host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
 // quad mapping: capsule tables keep only the four-float range-test records in LDS (bounding sphere of the capsule); the
 // capsule itself (8 floats) is fetched from global memory by the lanes that evaluate an in-range pair -- 512 B for 32
@@ -367,17 +381,30 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
   for (int base = 0; base < max_count; base += 32) {  // wave-uniform
     // ---- pass 1: in-range mask of this robot's chunk ----
     uint32_t m = 0u;
+    if (kBatchedTests && !RAGGED && base + 32 <= count) {
+      // a full chunk of a table (count is the table's size here: wave-uniform): all records read, THEN all tests -- one LDS round
+      // trip per chunk instead of one per slot (the slot-wise form below puts every read in its own basic block behind a branch)
+      float4 a[kTests];
 #pragma unroll
-    for (int i = 0; i < kTests; ++i) {
-      if (SKIP && base + W * i >= max_count) continue;  // wave-uniform: no robot of the wave has a sphere in this slot
-      const int pos = base + sub + W * i;
-      const bool valid = pos < count;
-      int sidx = valid ? pos : 0;
-      if (RAGGED) sidx = valid ? ci[pos] : 0;
-      const float4 a = aux[sidx];
-      const float t = fmaf(P3[0], a.x, fmaf(P3[1], a.y, fmaf(P3[2], a.z, a.w)));
-      const bool keep = valid && !(t > npp);
-      m |= keep ? (1u << (W * i)) : 0u;
+      for (int i = 0; i < kTests; ++i) a[i] = aux[base + sub + W * i];
+#pragma unroll
+      for (int i = 0; i < kTests; ++i) {
+        const float t = fmaf(P3[0], a[i].x, fmaf(P3[1], a[i].y, fmaf(P3[2], a[i].z, a[i].w)));
+        m |= !(t > npp) ? (1u << (W * i)) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kTests; ++i) {
+        if (SKIP && base + W * i >= max_count) continue;  // wave-uniform: no robot of the wave has a sphere in this slot
+        const int pos = base + sub + W * i;
+        const bool valid = pos < count;
+        int sidx = valid ? pos : 0;
+        if (RAGGED) sidx = valid ? ci[pos] : 0;
+        const float4 a = aux[sidx];
+        const float t = fmaf(P3[0], a.x, fmaf(P3[1], a.y, fmaf(P3[2], a.z, a.w)));
+        const bool keep = valid && !(t > npp);
+        m |= keep ? (1u << (W * i)) : 0u;
+      }
     }
     m <<= sub;
     m |= dppu<kXor1>(m);
@@ -415,8 +442,8 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
       sidx_ = on_ ? pos : 0;
       if (RAGGED) sidx_ = on_ ? ci[pos] : 0;
     };
-    // (sphere tables, kTripAhead: the staged record {-2c, w} and the radius of the NEXT trip are read from LDS before this trip's
-    //  chain starts -- the read's latency, and for ragged lists the list entry's before it, hide behind ~80 instructions)
+    // (sphere tables, kTripAhead -- off, measured no gain --: the staged record {-2c, w} and the radius of the NEXT trip are read from
+    //  LDS before this trip's chain starts; capsule records, which come from global memory, are always fetched a trip ahead)
     bool on_n = false;
     int sidx_n = 0;
     float4 ca_n = make_float4(0.f, 0.f, 0.f, 0.f), cb_n = ca_n;

@@ -692,3 +692,54 @@ def test_explicit_pairs_streamed_pair_phase_before_the_pull_back(torch_mod, R, s
     keep = np.ones(R, bool)
     keep[[5, 21]] = False
     assert np.array_equal(dn[keep], an[keep])
+
+
+@pytest.mark.parametrize("kernel", ["hex", "quad", "lane"])
+def test_vanishing_pair_weights_stay_finite(torch_mod, kernel):
+    """Control points that move AWAY from their obstacles.  The reference's velocity gate `1. - tf.sigmoid(z)`, z = xdot / gate_length
+    (rmp2.py:189-194), cancels in fp32; the kernels form it as e^-z / (1 + e^-z), exact to a few ulp, and keep the reference's exact 0
+    beyond z = 17.33 where an fp32 sigmoid is 1.  Three kinds of second pair per leaf: the same receding obstacle again (all weights
+    exactly 0), an ordinary one beside the point, and one at the edge of the modulation radius with z ~ 16.5 -- gate (1 - x / r)^2 ~ 1e-14
+    times 1e-7: weights of ~1e-23, whose SQUARE leaves fp32's range; the rank-one pull-back once normalised such a metric by rsqrt(0)
+    (fuzz seeds 33 / 200016 / 300032).  Every robot finite, unflagged, and on the exact evaluation's value."""
+    torch = torch_mod
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf, descriptor as D
+    R = 96
+    s = Cf.sample_panda_states(np.random.default_rng(41), R)
+    s["qd"] = (s["qd"] * np.float32(10.0)).astype(np.float32)       # control points at 0.1 .. 1 m/s: z = 10 .. 100
+    _, desc = Cf.config3()
+    gate_len, radius = Cf.OBSTACLE_AVOIDANCE_PARAMS[4], Cf.OBSTACLE_AVOIDANCE_PARAMS[7]
+    rng = np.random.default_rng(42)
+    pl, po = [], []
+    kind = np.arange(R)[:, None] % 3
+    for i in D.distance_leaf_indices(desc):
+        x, xd, _, _ = O.differentiate(desc, s["q"], s["qd"], desc.leaves[i].frame, "f64")
+        p, v = x[:, [3, 7, 11]], xd[:, [3, 7, 11]]
+        vn = np.linalg.norm(v, axis=1, keepdims=True)
+        rnd = rng.normal(size=(R, 3))
+        vh = np.where(vn > 1e-6, v / np.maximum(vn, 1e-30), rnd / np.linalg.norm(rnd, axis=1, keepdims=True))   # (the base links do not move)
+        side = np.cross(vh, rng.normal(size=(R, 3)))
+        side /= np.linalg.norm(side, axis=1, keepdims=True)
+        behind = p - rng.uniform(0.1, 0.4, (R, 1)) * vh          # the point leaves this obstacle along its own velocity
+        beside = p + 0.3 * side                                   # an ordinary pair: xdot = 0
+        cos = np.minimum(1.0, 16.5 * gate_len / np.maximum(vn, 1e-30))
+        nh = cos * vh + np.sqrt(1.0 - cos * cos) * side           # n . v = 16.5 gate_length where the point is fast enough
+        edge = p - radius * (1.0 - 2e-7) * nh                     # x = r (1 - 2e-7): inside the modulation radius by a few fp32 roundings
+        pl.append(np.repeat(p[:, None, :], 2, axis=1))
+        po.append(np.stack([behind, np.where(kind == 0, behind, np.where(kind == 1, beside, edge))], axis=1))
+    pl, po = (np.concatenate(a, axis=1).astype(np.float32) for a in (pl, po))
+    eng = _engine(desc, kernel)
+    st = torch.zeros(R, dtype=torch.int32, device="cuda")
+    qdd = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]),
+                   obstacles=eng.obstacles(p_link=torch.from_numpy(pl), p_obs=torch.from_numpy(po)), status=st)
+    torch.cuda.synchronize()
+    got = qdd.cpu().numpy()
+    assert np.isfinite(got).all() and not (st.cpu().numpy() & D.STATUS_NONFINITE).any()
+    exact = O.step(desc, s["q"], s["qd"], s["goal"], precision="f64", p_link=pl, p_obs=po)["qdd64"]
+    # (joint velocities of 5 rad/s make a few robots ill-conditioned whatever the obstacles do: robots an fp32 evaluation of the
+    #  reference's formulae itself resolves to 2e-6 are the ones held to the north star here)
+    c32 = O.step(desc, s["q"], s["qd"], s["goal"], precision="f32", p_link=pl, p_obs=po)["qdd64"]
+    well = np.abs(c32 - exact).max(axis=1) <= 2e-6 * np.maximum(1.0, np.abs(exact).max(axis=1))
+    assert well.sum() >= 0.9 * R and all(well[np.arange(R) % 3 == k].sum() >= 0.8 * R / 3 for k in range(3))
+    _check(got, exact, f"vanishing pair weights {kernel}", mask=well)

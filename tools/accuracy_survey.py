@@ -82,6 +82,11 @@ def survey_row(name, got, kw, fleet, desc, err_ref32, raw):
     # accuracy_gate returns b / c / d EXCLUSIVE of the earlier clauses; here each clause is counted on its own (the forward and
     # minimum-norm riders of B only matter for rank-dropping systems, which these fleets do not hold)
     omega, fin = g["omega"], np.isfinite(got).all(axis=1)
+    # the backward error against the EXACT system (fp64 evaluation): what clause B is judged on since the kernels form 1 - sigmoid
+    # without the cancellation of the reference's fp32 `1. - tf.sigmoid(z)` -- the fp32 oracle's own system carries that noise (its
+    # answer's backward error against the exact system is printed beside the engine's)
+    omega_x = O.accuracy_gate(got, r64)["omega"]
+    omega_c32_x = O.accuracy_gate(c32["qdd64"], r64)["omega"]
     B_incl = fin & (omega <= 1e-4)
     C_incl = fin & (g["err_inf"] <= 8.0 * np.fmax(spread, e_c32))
     D_incl = fin & (g["err_inf"] <= 8.0 * sysres)
@@ -94,7 +99,8 @@ def survey_row(name, got, kw, fleet, desc, err_ref32, raw):
         ratio_ctl = np.where(env_ctl > 0, e_c32 / env_ctl, np.inf)
     non_c = e_c32 > 1e-5 * scale
     row = dict(fleet=name, robots=n, A_vs_c32=int(A.sum()), A_vs_f64=int(A64.sum()), B_omega_le_1e4=int(B_incl.sum()),
-               B_omega_le_2e5=int((fin & (omega <= 2e-5)).sum()), C_x8=int(C_incl.sum()), D_x8=int(D_incl.sum()),
+               B_omega_le_2e5=int((fin & (omega_x <= O.ETA)).sum()), B_vs_fp32_oracle_system=int((fin & (omega <= O.ETA)).sum()),
+               omega_exact_max=float(np.nanmax(omega_x)), omega_exact_max_of_the_fp32_oracle=float(np.nanmax(omega_c32_x)), C_x8=int(C_incl.sum()), D_x8=int(D_incl.sum()),
                passes_gate=int(g["ok"].sum()), outside_A=int(nonA.sum()),
                omega_pcts_outside_A=pct(omega[nonA]), omega_max_all=float(np.nanmax(omega)),
                rel_err_engine_pcts_outside_A=pct((e_eng / scale)[nonA]), rel_err_c32_pcts_outside_A=pct((e_c32 / scale)[nonA]),
@@ -108,7 +114,7 @@ def survey_row(name, got, kw, fleet, desc, err_ref32, raw):
                rel_err_all_robots_pcts_engine=pct(e_eng / scale, (50, 90, 99, 99.9)), rel_err_all_robots_pcts_c32=pct(e_c32 / scale, (50, 90, 99, 99.9)),
                c32_outside_A_of_f64=int((e_c32 > 1e-5 * scale).sum()), ref32_outside_A=int((e_ref > 1e-5 * scale).sum()))
     print(json.dumps(row), flush=True)
-    for k, v in dict(got=got, truth=truth, c32=c32["qdd64"], e_ref32=e_ref, spread=spread, sysres=sysres, omega=omega, cond=g["cond"], env17=env17).items():
+    for k, v in dict(got=got, truth=truth, c32=c32["qdd64"], e_ref32=e_ref, spread=spread, sysres=sysres, omega=omega, omega_exact=omega_x, cond=g["cond"], env17=env17).items():
         raw[f"{name}__{k}"] = v
     return row
 
@@ -173,14 +179,17 @@ def main():
     print("# A: |err| <= 1e-5 max(1, |qdd|)   B: backward error omega <= 2e-5 (oracle.ETA)   E: |err| <= 2 x fp32 envelope (17 fp32 oracle")
     print("# draws + the autograd fp32 restatement's own error); every clause counted ON ITS OWN.  ratio = err_engine / envelope over the robots")
     print("# outside A (percentiles 50/90/99/100); control = the plain fp32 oracle evaluation against an envelope of 16 OTHER draws.")
+    print("# omega (B, omega max): against the EXACT system (M, f) of the fp64 evaluation; `fp32 oracle`: the fp32-leaf oracle's answer against the")
+    print("# same system; `vs fp32 sys`: the engine against the fp32-leaf oracle's OWN system (which holds the 1e-7 / (1 - sigmoid) noise of the")
+    print("# reference's `1. - tf.sigmoid(z)`; the kernels form that gate without the cancellation).")
     print(f"{'fleet':44s} {'A':>5s} {'B':>5s} {'E':>5s} {'gate':>5s} {'out-A':>5s} | {'ratio engine/envelope':>24s} {'>1':>4s} {'>2':>4s} | "
-          f"{'control':>22s} {'>1':>4s} {'>2':>4s} | {'rel err p90/p99 engine':>24s} {'fp32 oracle':>20s} {'restatement out-A':>18s} {'omega max':>10s}")
+          f"{'control':>22s} {'>1':>4s} {'>2':>4s} | {'rel err p90/p99 engine':>24s} {'fp32 oracle':>20s} {'restatement out-A':>18s} {'omega max':>10s} {'fp32 oracle':>11s} {'vs fp32 sys':>11s}")
     for r in rows:
         n_e = r["robots"] - r["outside_A"] + (r["outside_A"] - r["E_ratio_gt_2"])
         print(f"{r['fleet'][:44]:44s} {r['A_vs_f64']:5d} {r['B_omega_le_2e5']:5d} {n_e:5d} {r['passes_gate']:5d} {r['outside_A']:5d} | "
               f"{f3(r['E_ratio_engine_over_envelope17_pcts']):>24s} {r['E_ratio_gt_1']:4d} {r['E_ratio_gt_2']:4d} | "
               f"{f3(r['control_ratio_c32_over_envelope16_pcts']):>22s} {r['control_gt_1']:4d} {r['control_gt_2']:4d} | "
-              f"{f3(r['rel_err_all_robots_pcts_engine'][1:3]):>24s} {f3(r['rel_err_all_robots_pcts_c32'][1:3]):>20s} {r['ref32_outside_A']:18d} {r['omega_max_all']:10.2e}")
+              f"{f3(r['rel_err_all_robots_pcts_engine'][1:3]):>24s} {f3(r['rel_err_all_robots_pcts_c32'][1:3]):>20s} {r['ref32_outside_A']:18d} {r['omega_exact_max']:10.2e} {r['omega_exact_max_of_the_fp32_oracle']:11.2e} {r['omega_max_all']:11.2e}")
 
 
 if __name__ == "__main__":
