@@ -321,6 +321,13 @@ constexpr bool kTripAhead = RMP2_TRIP_AHEAD != 0;
 #define RMP2_BATCHED_TESTS 1
 #endif
 constexpr bool kBatchedTests = RMP2_BATCHED_TESTS != 0;
+#ifndef RMP2_TEST_BATCH
+#define RMP2_TEST_BATCH 4
+#endif
+#ifndef RMP2_BATCHED_ROW_RECS
+#define RMP2_BATCHED_ROW_RECS 1
+#endif
+constexpr bool kBatchedRowRecs = RMP2_BATCHED_ROW_RECS != 0;
 __host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
 // quad mapping: capsule tables keep only the four-float range-test records in LDS (bounding sphere of the capsule); the
 // capsule itself (8 floats) is fetched from global memory by the lanes that evaluate an in-range pair -- 512 B for 32
@@ -384,13 +391,18 @@ __device__ __forceinline__ void pair_loop_culled(const float* tab, int n_tab, co
     if (kBatchedTests && !RAGGED && base + 32 <= count) {
       // a full chunk of a table (count is the table's size here: wave-uniform): all records read, THEN all tests -- one LDS round
       // trip per chunk instead of one per slot (the slot-wise form below puts every read in its own basic block behind a branch)
-      float4 a[kTests];
+      constexpr int kBatch = kTests < RMP2_TEST_BATCH ? kTests : RMP2_TEST_BATCH;   // records in flight at a time (4 registers each)
 #pragma unroll
-      for (int i = 0; i < kTests; ++i) a[i] = aux[base + sub + W * i];
+      for (int i0 = 0; i0 < kTests; i0 += kBatch) {
+        if (i0 > 0) asm volatile("" ::: "memory");   // (this batch's reads stay behind the previous batch's tests: kBatch records in flight)
+        float4 a[kBatch];
 #pragma unroll
-      for (int i = 0; i < kTests; ++i) {
-        const float t = fmaf(P3[0], a[i].x, fmaf(P3[1], a[i].y, fmaf(P3[2], a[i].z, a[i].w)));
-        m |= !(t > npp) ? (1u << (W * i)) : 0u;
+        for (int i = 0; i < kBatch; ++i) a[i] = aux[base + sub + W * (i0 + i)];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          const float t = fmaf(P3[0], a[i].x, fmaf(P3[1], a[i].y, fmaf(P3[2], a[i].z, a[i].w)));
+          m |= !(t > npp) ? (1u << (W * (i0 + i))) : 0u;
+        }
       }
     } else {
 #pragma unroll
@@ -2188,16 +2200,27 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
         if (li == 0) {
           // the columns of MY rows, z_i x (p - o_i) resp. z_i, from the row-joint records read once per pass; rows
           // whose dof does not move the frame get a zero column, so everything below is branch-free
+          if (!kRowRecsInRegs && kBatchedRowRecs) {
+            // (the 128-register build re-reads the row-joint records per frame: ALL rows' records first, one LDS round trip -- inside
+            //  the per-row branches below every read sits in its own basic block with its own wait; a row block that does not move
+            //  the frame reads a valid record it does not use)
+#pragma unroll
+            for (int m = 0; m < ROWS; ++m) {
+              const float4 j0 = rjs[m][0], j2 = rjs[m][2];
+              rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
+              rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
+            }
+          }
 #pragma unroll
           for (int m = 0; m < ROWS; ++m) {
             if (MINW >= 2 && ((op.anc_mask >> (kQuad * m)) & 0xfu) == 0u) {  // wave-uniform: no dof of this row block moves
-              mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;                 // the frame (nor is its record read)
+              mycol[m][0] = mycol[m][1] = mycol[m][2] = 0.f;                 // the frame (nor is its record used)
               continue;
             }
             // (bits >= n_dof are never set; bit 16 + j: the frame's origin lies on joint j's axis for every q, its column is
             //  exactly zero in the reference -- rmp2_hip.hip structural_lever_zeros -- and here too, instead of rounding noise)
             const bool act = ((op.anc_mask & ~(op.anc_mask >> 16)) >> (sub + kQuad * m)) & 1u;
-            if (!kRowRecsInRegs) {
+            if (!kRowRecsInRegs && !kBatchedRowRecs) {
               const float4 j0 = rjs[m][0], j2 = rjs[m][2];
               rjz[m][0] = j2.y, rjz[m][1] = j2.z, rjz[m][2] = j2.w;
               rjo[m][0] = j0.x, rjo[m][1] = j0.y, rjo[m][2] = j0.z;
