@@ -325,7 +325,7 @@ constexpr bool kBatchedTests = RMP2_BATCHED_TESTS != 0;
 #define RMP2_TEST_BATCH 4
 #endif
 #ifndef RMP2_BATCHED_ROW_RECS
-#define RMP2_BATCHED_ROW_RECS 1
+#define RMP2_BATCHED_ROW_RECS 0   // measured: 41.9 against 41.7 us on config 3 (with the identity leaves' tile rows batched as well) -- no gain, off
 #endif
 constexpr bool kBatchedRowRecs = RMP2_BATCHED_ROW_RECS != 0;
 __host__ __device__ constexpr int sphere_lds_floats(bool cap, int k) { return cap ? 8 * k : ((5 * k + 3) & ~3); }
