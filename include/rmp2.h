@@ -192,8 +192,9 @@ typedef struct rmp2_obstacles {
                                               rmp2_closest_points_links + EXPLICIT_PAIRS (d = |p_link - p_obs| and unit normal; as
                                               there, the derivative moves the point with the frame origin, taskmap.py:124-129).
                                               FUSED into the step for tables of at most 256 spheres / capsules, robots with at
-                                              most 9 dofs and an inertia leaf, solve = AUTO or a certifying PINV (shared tables,
-                                              ragged lists, rollouts); a plain step over a SHARED table beyond those limits --
+                                              most 9 dofs and an inertia leaf, solve = AUTO or a certifying PINV, and 2-dof robots
+                                              with either resolve (their closed-form 2 x 2 resolve is the pseudo-inverse) -- shared
+                                              tables, ragged lists, rollouts; a plain step over a SHARED table beyond those limits --
                                               more dofs, the all-Jacobi PINV, bigger tables, CYLINDER tables -- runs as the stage
                                               into a buffer of the handle followed by the explicit-pair step (two launches, same
                                               numbers as calling the two entry points).  Rollouts and ragged lists beyond the

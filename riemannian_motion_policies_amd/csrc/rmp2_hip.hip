@@ -2027,7 +2027,8 @@ static int prepare_step(rmp2_handle* h, const float* q, const float* qd, const f
         return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: SHARED_SPHERES / RAGGED_SPHERES tables of at most 256 primitives "
                                              "(otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
       // (sets with attached-point leaves resolve as they do on explicit arrays: the rank-deficient ones through the careful pass)
-      if ((!h->has_point && ((h->strict && !quad_certifies_strict(h)) || (h->likely_singular && h->n_template != 2))) ||
+      // (2-dof robots: the quad mapping's closed-form 2 x 2 resolve IS the pseudo-inverse with TensorFlow's cutoff, for every robot)
+      if ((!h->has_point && (((h->strict && !quad_certifies_strict(h)) || h->likely_singular) && h->n_template != 2)) ||
           (h->has_point && h->strict && !quad_certifies_strict(h) && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)
         return fail(h, RMP2_ERR_UNSUPPORTED, "link_capsules: robots with at most 9 dofs; solve = pinv only where the quad mapping "
                                              "certifies or computes it (otherwise: rmp2_closest_points_links + EXPLICIT_PAIRS)");
@@ -2073,7 +2074,7 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   rmp2_obstacles staged;
   if (obs && obs->link_capsules && obs->mode == RMP2_OBS_SHARED_SPHERES && !h->has_point && ro.n_iters == 1 && ro.substeps == 0 &&
       obs->n_spheres > 0 && !h->distance_leaves.empty() &&
-      (obs->n_spheres > kLdsSpheres || obs->primitive == RMP2_PRIM_CYLINDER || (h->strict && !quad_certifies_strict(h)) ||
+      (obs->n_spheres > kLdsSpheres || obs->primitive == RMP2_PRIM_CYLINDER || (h->strict && !quad_certifies_strict(h) && h->n_template != 2) ||
        (h->likely_singular && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)) {
     const size_t P = h->distance_leaves.size() * (size_t)obs->n_spheres;
     const size_t need = (size_t)R * P * 3;

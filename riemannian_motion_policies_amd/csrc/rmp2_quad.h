@@ -324,6 +324,13 @@ constexpr bool kBatchedTests = RMP2_BATCHED_TESTS != 0;
 #ifndef RMP2_TEST_BATCH
 #define RMP2_TEST_BATCH 4
 #endif
+#ifndef RMP2_LINK_TRIP_AHEAD
+#define RMP2_LINK_TRIP_AHEAD 0   // measured with batches of eight: 79.2 against 78.7 us on config 3l -- off
+#endif
+constexpr bool kLinkTripAhead = RMP2_LINK_TRIP_AHEAD != 0;   // (the link-geometry loop runs at two or three waves per SIMD)
+#ifndef RMP2_LINK_TEST_BATCH
+#define RMP2_LINK_TEST_BATCH 4
+#endif
 #ifndef RMP2_BATCHED_ROW_RECS
 #define RMP2_BATCHED_ROW_RECS 0   // measured: 41.9 against 41.7 us on config 3 (with the identity leaves' tile rows batched as well) -- no gain, off
 #endif
@@ -564,13 +571,7 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
   const float inv_aa = aa > 0.f ? 1.0f / aa : 0.f;
   for (int base = 0; base < count; base += 32) {  // wave-uniform (shared table)
     uint32_t m = 0u;
-#pragma unroll
-    for (int i = 0; i < kTests; ++i) {
-      if (SKIP && base + W * i >= count) continue;
-      const int pos = base + sub + W * i;
-      const bool valid = pos < count;
-      const int sidx = valid ? pos : 0;
-      const float4 a = aux[sidx];
+    auto in_range = [&](const float4 a, const float rad_c0) __attribute__((always_inline)) {
       const float c[3] = {-0.5f * a.x, -0.5f * a.y, -0.5f * a.z};
       // r + c0 of the record: kept next to it for spheres, recovered from the record for capsules' bounding spheres
       float thr;
@@ -578,14 +579,41 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
         const float cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
         thr = sqrtf(fmaxf(cc - a.w, 0.f)) * 1.00001f;  // (= sqrt(slack) (r + c0) up to rounding: widened, never under-covers)
       } else {
-        thr = fmaxf(rad[sidx] + c0, 0.f);
+        thr = fmaxf(rad_c0, 0.f);
       }
       const float w[3] = {c[0] - LA[0], c[1] - LA[1], c[2] - LA[2]};
       const float sl = fminf(fmaxf(dot3(w, d1) * inv_aa, 0.f), 1.f);
       const float xc[3] = {fmaf(-sl, d1[0], w[0]), fmaf(-sl, d1[1], w[1]), fmaf(-sl, d1[2], w[2])};  // c - X
       const float lim = thr + lr;
-      const bool keep = valid && !(dot3(xc, xc) > kCullSlack * lim * lim);
-      m |= keep ? (1u << (W * i)) : 0u;
+      return !(dot3(xc, xc) > kCullSlack * lim * lim);
+    };
+    if (kBatchedTests && base + 32 <= count) {
+      // a full chunk: the records (and radii) of four slots read together, then their tests -- one LDS round trip per batch instead
+      // of one per slot behind a branch each (pair_loop_culled, where this was measured)
+      constexpr int kBatch = kTests < RMP2_LINK_TEST_BATCH ? kTests : RMP2_LINK_TEST_BATCH;
+#pragma unroll
+      for (int i0 = 0; i0 < kTests; i0 += kBatch) {
+        if (i0 > 0) asm volatile("" ::: "memory");
+        float4 a[kBatch];
+        float rc[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          a[i] = aux[base + sub + W * (i0 + i)];
+          rc[i] = CAPS ? 0.f : rad[base + sub + W * (i0 + i)] + c0;
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) m |= in_range(a[i], rc[i]) ? (1u << (W * (i0 + i))) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kTests; ++i) {
+        if (SKIP && base + W * i >= count) continue;
+        const int pos = base + sub + W * i;
+        const bool valid = pos < count;
+        const int sidx = valid ? pos : 0;
+        const bool keep = valid && in_range(aux[sidx], CAPS ? 0.f : rad[sidx] + c0);
+        m |= keep ? (1u << (W * i)) : 0u;
+      }
     }
     m <<= sub;
     m |= dppu<kXor1>(m);
@@ -610,18 +638,27 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
       take(on_n, sidx_n);
       ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
       cb_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n + 1];
+    } else if (kLinkTripAhead) {  // (sphere tables: the staged record and radius of the next trip, read from LDS a trip ahead)
+      take(on_n, sidx_n);
+      ca_n = aux[sidx_n];
+      cb_n.x = rad[sidx_n];
     }
     while (true) {
       bool on;
       int sidx;
       float4 ca, cb;
-      if (CAPS) {
+      if (CAPS || kLinkTripAhead) {
         on = on_n, sidx = sidx_n, ca = ca_n, cb = cb_n;
       } else {
         take(on, sidx);
       }
       if (!__any(on)) break;
       float X[3], Y[3], r;
+      if (!CAPS && kLinkTripAhead) {
+        take(on_n, sidx_n);
+        ca_n = aux[sidx_n];
+        cb_n.x = rad[sidx_n];
+      }
       if (CAPS) {
         take(on_n, sidx_n);
         ca_n = reinterpret_cast<const float4*>(caps)[2 * sidx_n];
@@ -643,8 +680,8 @@ __device__ __forceinline__ void pair_loop_link(const float* tab, int n_tab, int 
         Y[0] = fmaf(to, d2v[0], ca.x), Y[1] = fmaf(to, d2v[1], ca.y), Y[2] = fmaf(to, d2v[2], ca.z);
         r = ca.w;
       } else {
-        const float4 a = aux[sidx];
-        r = rad[sidx];
+        const float4 a = kLinkTripAhead ? ca : aux[sidx];
+        r = kLinkTripAhead ? cb.x : rad[sidx];
         Y[0] = -0.5f * a.x, Y[1] = -0.5f * a.y, Y[2] = -0.5f * a.z;  // the centre, exactly
         const float w[3] = {Y[0] - LA[0], Y[1] - LA[1], Y[2] - LA[2]};
         const float sl = fminf(fmaxf(dot3(w, d1) * inv_aa, 0.f), 1.f);
