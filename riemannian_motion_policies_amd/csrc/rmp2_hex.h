@@ -24,6 +24,8 @@
 // Numerics as in rmp2_quad.h: fp32 kinematics / leaves / pull-back products, fp64 accumulation and resolve,
 // certification + careful fall-through (pivoted LU, then the pseudo-inverse) for (near-)singular robots.
 #pragma once
+#include <utility>
+
 #include "rmp2_quad.h"
 
 namespace rmp2 {
@@ -75,6 +77,29 @@ __device__ __forceinline__ void hex_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A robot's sixteen lanes are one DPP row: lane K's value to every lane of the row (v_mov_b32_dpp row_newbcast:K), two moves per
+// double -- the pivot rows of the resolve travel this way, without an LDS round trip (RMP2_HEX_DPP_PIVOTS; measured against the LDS
+// exchange, profiles/r05_hex_resolve_ab.txt).
+#ifndef RMP2_HEX_DPP_PIVOTS
+#define RMP2_HEX_DPP_PIVOTS 1
+#endif
+template <int K>
+__device__ __forceinline__ double hex_row_bcast(double v) {
+  static_assert(K >= 0 && K < 16, "a lane of the robot's row");
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float hex_row_bcastf(float v) {
+  static_assert(K >= 0 && K < 16, "a lane of the robot's row");
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, false));
+}
+template <int... Is, class F>
+__device__ __forceinline__ void hex_static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
 }
 
 // Per-robot LDS regions are padded to a stride of 8 (mod 32) floats: the four robots of a wave touch the same element
@@ -930,12 +955,19 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
           wsc = expf(-vn / 3.0f);
         }
         if (!row_ok) zeta_i = xdd_i = cw_i = 0.f;
-        XCH[s] = make_float4(zeta_i, xdd_i, cw_i, 0.f);
-        hex_sync();
         const float omb = 1.0f - beta;
-        float4 xch[N];  // all triples first (one batch of LDS reads), then one branch-free loop per leaf kind
+        float4 xch[N];  // all triples first, then one branch-free loop per leaf kind
+        if (RMP2_HEX_DPP_PIVOTS) {  // (dof j's triple from lane j of the robot's DPP row: no LDS round trip)
+          hex_static_for(std::make_integer_sequence<int, N>{}, [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            xch[j] = make_float4(hex_row_bcastf<j>(zeta_i), hex_row_bcastf<j>(xdd_i), hex_row_bcastf<j>(cw_i), 0.f);
+          });
+        } else {
+          XCH[s] = make_float4(zeta_i, xdd_i, cw_i, 0.f);
+          hex_sync();
 #pragma unroll
-        for (int j = 0; j < N; ++j) xch[j] = XCH[j];  // padded dofs hold (0, 0, 0): their columns come out as exact zeros
+          for (int j = 0; j < N; ++j) xch[j] = XCH[j];  // padded dofs hold (0, 0, 0): their columns come out as exact zeros
+        }
         float fi = 0.f;
         if (kind == RMP2_LEAF_JOINT_VELOCITY_CAP) {
 #pragma unroll
@@ -965,7 +997,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
           }
         }
         fv += (double)fi;
-        hex_sync();  // XCH is rewritten by the next dense leaf
+        if (!RMP2_HEX_DPP_PIVOTS) hex_sync();  // XCH is rewritten by the next dense leaf
       }
     }
   }
@@ -1044,28 +1076,39 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
     // -- half the dependent LDS round trips of one pivot per exchange.
     double* const ROW0 = reinterpret_cast<double*>(&wl[HexLds<N>::kRow + g * 2 * HexLds<N>::kRowStride]);
     double* const ROW1 = ROW0 + HexLds<N>::kRowStride / 2;
+    hex_static_for(std::make_integer_sequence<int, N / 2>{}, [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = 2 * decltype(kc)::value;
+      constexpr int k1 = k + 1;
+      double r0[N], r1[N], b0, b1;
+      if (RMP2_HEX_DPP_PIVOTS) {
+        // rows k and k + 1 as their owners hold them NOW (row k + 1 before step k: every lane applies it to its copy, below)
 #pragma unroll
-    for (int k = 0; k + 1 < N; k += 2) {
-      const int k1 = k + 1;
-      if (s == k) {
+        for (int j = k; j < N; ++j) {
+          r0[j] = hex_row_bcast<k>(A[j]);
+          r1[j] = hex_row_bcast<k1>(A[j]);
+        }
+        b0 = hex_row_bcast<k>(fv);
+        b1 = hex_row_bcast<k1>(fv);
+      } else {
+        if (s == k) {
 #pragma unroll
-        for (int j = k; j < N; ++j) ROW0[j] = A[j];
-        ROW0[N] = fv;
+          for (int j = k; j < N; ++j) ROW0[j] = A[j];
+          ROW0[N] = fv;
+        }
+        if (s == k1) {
+#pragma unroll
+          for (int j = k; j < N; ++j) ROW1[j] = A[j];
+          ROW1[N] = fv;
+        }
+        hex_sync();
+#pragma unroll
+        for (int j = k; j < N; ++j) {
+          r0[j] = ROW0[j];
+          r1[j] = ROW1[j];
+        }
+        b0 = ROW0[N];
+        b1 = ROW1[N];
       }
-      if (s == k1) {
-#pragma unroll
-        for (int j = k; j < N; ++j) ROW1[j] = A[j];
-        ROW1[N] = fv;
-      }
-      hex_sync();
-      double r0[N], r1[N];
-#pragma unroll
-      for (int j = k; j < N; ++j) {
-        r0[j] = ROW0[j];
-        r1[j] = ROW1[j];
-      }
-      const double b0 = ROW0[N];
-      double b1 = ROW1[N];
       const bool bad0 = !(fabs(r0[k]) > tiny);
       const double inv0 = bad0 ? 0.0 : rcpd(r0[k]);
       const double m10 = r1[k] * inv0;  // step k applied to the published copy of row k + 1
@@ -1094,16 +1137,22 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       for (int j = k1 + 1; j < N; ++j) A[j] = fma(-l1, r1[j], A[j]);
       fv = fma(-l1, b1, fv);
       lmax_hi = max(lmax_hi, max((s > k) ? (__double2hiint(l0) & 0x7fffffff) : 0, (s > k1) ? (__double2hiint(l1) & 0x7fffffff) : 0));
-      hex_sync();  // the next pair of pivot rows overwrites ROW0 / ROW1
-    }
+      if (!RMP2_HEX_DPP_PIVOTS) hex_sync();  // the next pair of pivot rows overwrites ROW0 / ROW1
+    });
     if (N & 1) {  // the last pivot of an odd system on its own
       constexpr int k = N - 1;
-      if (s == k) {
-        ROW0[k] = A[k];
-        ROW0[N] = fv;
+      double pk, bk;
+      if (RMP2_HEX_DPP_PIVOTS) {
+        pk = hex_row_bcast<k>(A[k]);
+        bk = hex_row_bcast<k>(fv);
+      } else {
+        if (s == k) {
+          ROW0[k] = A[k];
+          ROW0[N] = fv;
+        }
+        hex_sync();
+        pk = ROW0[k], bk = ROW0[N];
       }
-      hex_sync();
-      const double pk = ROW0[k], bk = ROW0[N];
       const bool bad = !(fabs(pk) > tiny);
       flagged = flagged || bad;
       const double inv = bad ? 0.0 : rcpd(pk);
@@ -1115,7 +1164,7 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       }
       const double l = (s != k) ? A[k] * inv : 0.0;
       fv = fma(-l, bk, fv);
-      hex_sync();
+      if (!RMP2_HEX_DPP_PIVOTS) hex_sync();
     }
     lmax_hi = hex_maxi(lmax_hi);
     flagged = flagged || !(lmax_hi <= __double2hiint(1e4));  // multiplier growth > 1e4 (NaN / Inf compare above it)
@@ -1128,11 +1177,20 @@ rmp2_step_hex_kernel(const uint4* __restrict__ blob, int blob16, QuadHdr hdr, co
       const float rt = __builtin_sqrtf((float)(d_own / scale)) * 1.000001f + 1e-30f;  // an UPPER bound of sqrt(d / scale)
       double rhs = symset ? scale * (double)rt : scale;
       double tmax = 0.0;
+      if (RMP2_HEX_DPP_PIVOTS) {  // (lane i's t_i to the robot's row by DPP: nine dependent steps without an LDS round trip each)
+        hex_static_for(std::make_integer_sequence<int, N>{}, [&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = N - 1 - decltype(ic)::value;
+          const double ti = hex_row_bcast<i>(rhs * fabs(inv_own));
+          tmax = fmax(tmax, ti);
+          rhs = (s < i) ? fma(fabs(Urow[i]), ti, rhs) : rhs;
+        });
+      } else {
 #pragma unroll
-      for (int i = N - 1; i >= 0; --i) {
-        const double ti = __shfl(rhs * fabs(inv_own), i, kHex);
-        tmax = fmax(tmax, ti);
-        rhs = (s < i) ? fma(fabs(Urow[i]), ti, rhs) : rhs;
+        for (int i = N - 1; i >= 0; --i) {
+          const double ti = __shfl(rhs * fabs(inv_own), i, kHex);
+          tmax = fmax(tmax, ti);
+          rhs = (s < i) ? fma(fabs(Urow[i]), ti, rhs) : rhs;
+        }
       }
       const double lmax = __hiloint2double(lmax_hi, 0) * 1.0000002;  // (the high word rounds down: nudged back up)
       const double umax = __hiloint2double(hex_maxi(umax_hi), 0) * 1.0000002;
