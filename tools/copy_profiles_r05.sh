@@ -6,7 +6,7 @@ S=gpurun_out/r05/final
 for f in $S/bench_*.json $S/rehearsal_2ranks_*.json $S/fuzz_parity*.json $S/*_kernel_stats.csv $S/sq_counters_*.txt; do
   [ -f "$f" ] && cp "$f" profiles/r05_$(basename $f)
 done
-for f in accuracy_survey stamps; do [ -f $S/$f.txt ] && cp $S/$f.txt profiles/r05_$f.txt; done
+for f in accuracy_survey stamps dropin_latency; do [ -f $S/$f.txt ] && cp $S/$f.txt profiles/r05_$f.txt; done
 for f in traffic_config2 traffic_config3 traffic_config3b executed_config3; do [ -f $S/$f.json ] && cp $S/$f.json profiles/$f.json; done
 # interface B: the round's four measurement files in one
 B=gpurun_out/r05

@@ -7,6 +7,8 @@ timeout -k 10 900 python -m pytest tests -q -m gpu > $O/gpu_suite.log 2>&1; rc=$
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 600 python tools/accuracy_survey.py 2048 $O/accuracy_survey > $O/accuracy_survey.txt 2> $O/accuracy_survey.err || { tail -5 $O/accuracy_survey.err; exit 1; }
 tail -16 $O/accuracy_survey.txt | cut -c1-330
+(python tools/dropin_latency.py 7 300; python tools/dropin_latency.py 32 300) > $O/dropin_latency.txt 2> /dev/null || true
+python __graft_entry__.py smoke > $O/smoke.txt 2>&1 || { tail -3 $O/smoke.txt; exit 1; }
 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_style_steps20.json 2> /dev/null || exit 1
 for wl in config3b config3c config3l config2 config4 config5; do
