@@ -1660,7 +1660,11 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
   // mapping carries the strict pseudo-inverse through its careful path at any fleet size
   const bool strict_rollout = h->strict && rollout && !quad_certifies;
   // (the hex mapping certifies too since round 4 -- its Gauss-Jordan keeps the pivot rows --: strict small fleets take it like AUTO ones)
-  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max && (!quad_certifies || hex_certifies_strict(h)))) &&
+  // (2-dof robots under solve = PINV without a certificate -- sets without an inertia leaf, e.g. the TwoJoint half of config 5: the hex
+  //  mapping resolves every robot through its careful path, the quad mapping by its closed-form 2 x 2 pseudo-inverse -- measured 14.3 us
+  //  against ~12 at 4 096 robots (profiles/r05_cost_calibration.json): such calls take the quad mapping at every fleet size)
+  const bool quad_closed_form = N == 2 && h->strict && !hex_certifies_strict(h) && !rollout;
+  if (hex_ok && (h->kernel_choice == 3 || strict_rollout || (h->kernel_choice == 0 && R <= hex_max && !quad_closed_form && (!quad_certifies || hex_certifies_strict(h)))) &&
       (N == 2 ? launch_hex_n2 : launch_hex_n9)(h, q, qd, goal, gs, o, out, ro, R, s))
     return RMP2_OK;
   if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (an uncertifying quad resolve would be AUTO: never a silent change of semantics)

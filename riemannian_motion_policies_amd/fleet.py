@@ -462,8 +462,9 @@ class MixedFleetShard:
     DEFAULT_CURVES = None   # filled below the class (measured on MI355X)
 
     @staticmethod
-    def calibrate_curves(device: int, sizes=None, seed: int = 5, steps: int = 120):
-        """Measure {type: (sizes, us per step)} on `device` with ragged lists k ~ U{0..K} (the fleet's distribution)."""
+    def calibrate_curves(device: int, sizes=None, seed: int = 5, steps: int = 120, solve: str = "pinv"):
+        """Measure {type: (sizes, us per step)} on `device` with ragged lists k ~ U{0..K} (the fleet's distribution); solve: the
+        resolve the fleet will run (bench.py's default, the reference's: pinv)."""
         import numpy as np
         from . import configs as Cf
         from .engine import Engine
@@ -472,7 +473,7 @@ class MixedFleetShard:
         out = {}
         for key, builder, sampler, first in (("two_joint", Cf.config5_two_joint, Cf.sample_two_joint_states, 0),
                                              ("panda", Cf.config3, Cf.sample_panda_states, 1)):
-            _, desc = builder("auto")
+            _, desc = builder(solve)
             eng = Engine(desc, device)
             sph = Cf.sample_spheres(np.random.default_rng([seed, first]))
             if key == "two_joint":
@@ -817,7 +818,9 @@ class MixedFleetShard:
 
 
 # measured on one MI355X (profiles/r03_cost_calibration.json: tools/calibrate_costs.py, kernels of round 3)
+# (round 5: measured with solve = pinv -- bench.py's default, the reference's resolve -- on the round's kernels, tools/calibrate_costs.py,
+#  profiles/r05_cost_calibration.json; round 3's curves, solve = auto: profiles/r03_cost_calibration.json)
 MixedFleetShard.DEFAULT_CURVES = {
-    "two_joint": (list(MixedFleetShard.CURVE_SIZES), [8.98, 11.73, 10.24, 11.87, 12.08, 12.34, 11.89, 12.27, 12.4, 12.45, 12.94, 13.65, 13.81, 15.7, 16.45, 17.91, 24.7, 28.58]),
-    "panda": (list(MixedFleetShard.CURVE_SIZES), [20.41, 20.89, 24.82, 32.5, 32.76, 33.11, 34.09, 35.42, 35.57, 36.14, 39.3, 40.86, 41.84, 47.91, 65.8, 70.76, 78.2, 90.65]),
+    "two_joint": (list(MixedFleetShard.CURVE_SIZES), [12.06, 12.1, 12.7, 12.71, 12.94, 13.16, 11.95, 12.38, 12.45, 12.61, 13.39, 14.17, 14.37, 15.8, 17.2, 19.08, 25.53, 29.84]),
+    "panda": (list(MixedFleetShard.CURVE_SIZES), [22.43, 22.97, 26.89, 35.22, 35.47, 35.66, 32.73, 34.65, 34.75, 35.39, 38.81, 40.99, 41.75, 48.14, 63.71, 69.31, 76.88, 89.16]),
 }

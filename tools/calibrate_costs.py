@@ -1,13 +1,14 @@
 """Measure the config-5 cost model that fleet.MixedFleetShard.plan cuts the mixed fleet with: kernel time curves per robot type
 (us per step at a ladder of fleet sizes, ragged lists k ~ U{0..32}).  Prints one JSON object; the tracked copy is
-profiles/r03_cost_calibration.json and the constants in fleet.MixedFleetShard.DEFAULT_CURVES.
-usage: calibrate_costs.py"""
+profiles/r05_cost_calibration.json (round 3: r03_cost_calibration.json, solve = auto) and the constants in fleet.MixedFleetShard.DEFAULT_CURVES.
+usage: calibrate_costs.py [pinv|auto]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from riemannian_motion_policies_amd.fleet import MixedFleetShard
-c = MixedFleetShard.calibrate_curves(0)
-out = {"unit": "us per control step of the type's engine (kernel time, HIP events, 120 launches)",
+solve = sys.argv[1] if len(sys.argv) > 1 else "pinv"
+c = MixedFleetShard.calibrate_curves(0, solve=solve)
+out = {"solve": solve, "unit": "us per control step of the type's engine (kernel time, HIP events, 120 launches)",
        "lists": "ragged, k_r ~ U{0..32} into a 32-sphere table (config 5)",
        "curves": {k: {"robots": list(v[0]), "us": [round(x, 2) for x in v[1]]} for k, v in c.items()}}
 print(json.dumps(out, indent=1))

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 S=gpurun_out/r05/final
-for f in $S/bench_*.json $S/rehearsal_2ranks_*.json $S/fuzz_parity*.json $S/*_kernel_stats.csv $S/sq_counters_*.txt; do
+for f in $S/bench_*.json $S/emulated_scaling_*.json $S/rehearsal_2ranks_*.json $S/fuzz_parity*.json $S/*_kernel_stats.csv $S/sq_counters_*.txt; do
   [ -f "$f" ] && cp "$f" profiles/r05_$(basename $f)
 done
 for f in accuracy_survey stamps dropin_latency; do [ -f $S/$f.txt ] && cp $S/$f.txt profiles/r05_$f.txt; done
