@@ -15,6 +15,9 @@ for wl in config3b config3c config3l config2 config4 config5; do
   python bench.py --workload $wl --no-cpu-baseline --no-secondary > $O/bench_$wl.json 2> $O/bench_$wl.err || { tail -5 $O/bench_$wl.err; exit 1; }
 done
 python bench.py --workload config3 --solve auto --no-cpu-baseline --no-secondary > $O/bench_config3_auto.json 2> /dev/null || exit 1
+python bench.py --workload config5 --link-geometry --no-cpu-baseline > $O/bench_config5_link_geometry.json 2> /dev/null || exit 1
+python bench.py --workload config4 --emulate-world 8 --no-cpu-baseline > $O/emulated_scaling_config4.json 2> /dev/null || exit 1
+python bench.py --workload config5 --emulate-world 8 --no-cpu-baseline > $O/emulated_scaling_config5.json 2> /dev/null || exit 1
 timeout -k 10 400 python bench.py --gpus 2 --rehearse-one-gpu --steps 200 --warmup 20 --rank-timeout 300 --no-cpu-baseline --no-secondary > $O/rehearsal_2ranks_config4.json 2> $O/rehearsal_2ranks_config4.err || { tail -5 $O/rehearsal_2ranks_config4.err; exit 1; }
 timeout -k 10 400 python bench.py --gpus 2 --rehearse-one-gpu --workload config5 --steps 200 --warmup 20 --rank-timeout 300 --no-cpu-baseline > $O/rehearsal_2ranks_config5.json 2> $O/rehearsal_2ranks_config5.err || { tail -5 $O/rehearsal_2ranks_config5.err; exit 1; }
 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse-one-gpu --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $O/rehearsal_2ranks_config4_torchrun.json 2> $O/rehearsal_2ranks_config4_torchrun.err || { tail -5 $O/rehearsal_2ranks_config4_torchrun.err; exit 1; }
