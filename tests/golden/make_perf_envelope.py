@@ -41,6 +41,17 @@ N_NEAR = 64
 CLEAR_LO, CLEAR_HI = 0.005, 0.05
 
 
+# The 8-rank cut of the mixed fleet the committed vectors were generated under: the time curves of round 3 (profiles/r03_cost_calibration.json).
+# fleet.MixedFleetShard.DEFAULT_CURVES is re-measured as the kernels change (round 5: solve = pinv) and moves the cut -- and with it which
+# robots are "the first 2 048 of rank 0 / rank 7"; the fixtures name robots, so their cut is pinned here (_fixture_cut).
+def _fixture_cut():
+    from riemannian_motion_policies_amd.fleet import MixedFleetShard
+    sz = list(MixedFleetShard.CURVE_SIZES)
+    return {"curves": {
+        "two_joint": (sz, [8.98, 11.73, 10.24, 11.87, 12.08, 12.34, 11.89, 12.27, 12.4, 12.45, 12.94, 13.65, 13.81, 15.7, 16.45, 17.91, 24.7, 28.58]),
+        "panda": (sz, [20.41, 20.89, 24.82, 32.5, 32.76, 33.11, 34.09, 35.42, 35.57, 36.14, 39.3, 40.86, 41.84, 47.91, 65.8, 70.76, 78.2, 90.65])}}
+
+
 def perf_fleets(n=N_PERF):
     """{name: dict(robot, desc builder name, q, qd, goal, table (or None), csr_offset / csr_index (or None))}: the first n robots
     of each perf fleet, drawn exactly as bench.py / tools/accuracy_survey.py / fleet.MixedFleetShard draw them."""
@@ -55,7 +66,7 @@ def perf_fleets(n=N_PERF):
     out["config3"] = dict(robot="panda", set="config3", table=sph, **{k: v[:n] for k, v in s3.items()})
     out["config3c"] = dict(robot="panda", set="config3", table=caps, **{k: v[:n] for k, v in s3.items()})
     for rank, key, name in ((0, "two_joint", "config5_two_joint"), (7, "panda", "config5_panda")):
-        hp = MixedFleetShard.synthetic_host(262144, 8, rank)[key]
+        hp = MixedFleetShard.synthetic_host(262144, 8, rank, cost=_fixture_cut())[key]
         m = min(n, hp["n"])
         off = hp["csr_offset"][: m + 1]
         out[name] = dict(robot=key, set="config5_two_joint" if key == "two_joint" else "config3", table=hp["spheres"],

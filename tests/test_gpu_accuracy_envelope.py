@@ -119,7 +119,7 @@ def test_perf_fleets_inside_the_fp32_envelope(torch_mod):
     del eng
     # config 5: rank 0 (131 072 TwoJoint robots) and rank 7 (~18.7 k Pandas) of the 8-rank cut, ragged lists
     for rank, key, name in ((0, "two_joint", "config5_two_joint"), (7, "panda", "config5_panda")):
-        shard = MixedFleetShard.synthetic(262144, 8, rank, 0, solve="pinv")
+        shard = MixedFleetShard.synthetic(262144, 8, rank, 0, solve="pinv", cost=E._fixture_cut())
         shard.step()
         torch.cuda.synchronize()
         part, fl = shard.parts[key], fleets[name]

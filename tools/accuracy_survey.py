@@ -161,7 +161,7 @@ def main():
         del eng
         # ---- config 5: rank 0 (TwoJoint) and rank 7 (Panda) of the 8-rank cut ----
         for rank, key, name in ((0, "two_joint", "config5_two_joint"), (7, "panda", "config5_panda")):
-            shard = MixedFleetShard.synthetic(262144, 8, rank, 0, solve=solve)
+            shard = MixedFleetShard.synthetic(262144, 8, rank, 0, solve=solve, cost=E._fixture_cut())
             shard.step()
             torch.cuda.synchronize()
             part = shard.parts[key]
