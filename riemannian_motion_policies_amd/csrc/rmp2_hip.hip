@@ -1863,7 +1863,11 @@ int rmp2_create(const rmp2_desc* desc, int device, rmp2_handle** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       h->n_simd = 4 * prop.multiProcessorCount;
-    if (!h->quad_latency_set) h->quad_latency_blocks = h->n_simd;  // the latency build serves grids of at most one wave per SIMD
+    // The latency build (program staged in LDS, all registers; made for grids of at most one wave per SIMD) is retired from the
+    // dispatch: on the round-5 kernels the throughput build is faster on every such grid -- config 3, 1 024 .. 16 384 robots: 27.1 ..
+    // 29.4 us against 31.4 .. 33.4; config 2: 12.5 .. 13.5 against 13.6 .. 14.7 (profiles/r05_quad_latency_build_ab.txt).  It stays
+    // compiled for the tuning builds' A/B (RMP2_QUAD_LATENCY_BLOCKS).
+    if (!h->quad_latency_set) h->quad_latency_blocks = 0;
   }
   h->n_fk_leaves = P.n_fk_leaves;
   h->hex_is_chain = P.hex.is_chain;

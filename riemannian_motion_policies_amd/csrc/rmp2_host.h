@@ -47,7 +47,7 @@ struct rmp2_handle {
   bool symmetric = false;      // no leaf with a non-symmetric metric (JointLimitAvoidance, quirk Q2) in the set
   int prio_tail = -1;          // env RMP2_PRIO_TAIL=0..3 pins the priority of the phases after the frame loop (A/B only)
   bool quad_latency_set = false;   // RMP2_QUAD_LATENCY_BLOCKS given (tuning builds)
-  int quad_latency_blocks = 1024;  // grids up to this many waves take the latency build (env RMP2_QUAD_LATENCY_BLOCKS, A/B only)
+  int quad_latency_blocks = 0;     // grids up to this many waves take the latency build: none since round 5 (tuning builds: env RMP2_QUAD_LATENCY_BLOCKS)
   int n_fk_leaves = 0;
   int hex_is_chain = 0;
   void* d_hex_blob = nullptr;  // the staged program of the hex kernel, laid out exactly as it sits in LDS

@@ -2706,7 +2706,11 @@ __device__ __forceinline__ void quad_step_body(const DevProgram* __restrict__ pr
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
       const int i = sub + kQuad * m;
-      if (i < n_dof) {
+      // (live: the quads beyond the fleet's tail alias the LAST live robot's tile row (gi) -- with ITS inputs only in the staged
+      //  builds; in the scalar-cache builds they read robot 0's goal and an empty list, resolve to another qdd, and -- the highest
+      //  lane winning an LDS write -- advanced the last robot of a partial wave with it.  Found when the latency build left the
+      //  dispatch (round 5): rollout == step loop is tested on small fleets, where it had always run.)
+      if (i < n_dof && live) {
         const float acc = my_out[i];
         float qi_ = qw[i], qdi = qdw[i];
         for (int t = 0; t < ro.substeps; ++t) {

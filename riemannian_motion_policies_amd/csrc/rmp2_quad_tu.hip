@@ -148,7 +148,10 @@ void launch_quad(const rmp2_handle* h, const float* q, const float* qd, const fl
       }
 #undef RMP2_QUAD_LINK_SYM
 #undef RMP2_QUAD_LINK
-      h->last_kernel = "rmp2_step_quad_kernel (4 lanes per robot; link geometry, lean build: segments formed in the walk)";
+      h->last_kernel = quad_certifies_strict(h)
+                           ? "rmp2_step_quad_kernel (4 lanes per robot; link geometry, lean build: segments formed in the walk; strict: full rank "
+                             "certified per robot, Jacobi pseudo-inverse for the rest)"
+                           : "rmp2_step_quad_kernel (4 lanes per robot; link geometry, lean build: segments formed in the walk)";
       return;
     }
   }

@@ -486,3 +486,49 @@ def test_rollout_with_moving_obstacles(hip_lib, golden_dir, kernel, prim):
     assert (qf - q1).abs().max().item() > 1e-4, "the moving tables must change the trajectory"
     with pytest.raises(ValueError, match="tables"):
         eng.rollout(qf, qdf, goal, obstacles=eng.obstacle_trajectory(tt), n_control_steps=K + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config2", "config3", "config3_ragged"])
+def test_fused_rollout_last_robot_of_a_partial_wave_at_fleet_size(hip_lib, workload):
+    """The throughput builds of the quad mapping (fleets beyond 8 192 robots; every quad grid since the latency build left the
+    dispatch) let the quads beyond the fleet's tail alias the LAST live robot's tile row -- with robot 0's goal and an empty list.
+    Until round 5 such a quad also advanced that row in the fused rollout, and, the highest lane winning an LDS write, the last robot
+    of a partial wave moved with another robot's acceleration (undetected: rollout(K) == K x rollout(1) holds for a deterministic
+    error, and the rollout == step-loop test ran on small fleets, i.e. on the staged build whose tail quads read the aliased row's
+    own goal).  Here: 20 001 robots = 1 250 full waves + one robot, per-robot goals, the fused rollout against the step loop."""
+    import torch
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2() if workload == "config2" else Cf.config3()
+    eng = Engine(desc, 0)
+    R, sub, dt, K = 20001, 4, 0.01, 3
+    rng = np.random.default_rng(19)
+    s = Cf.sample_panda_states(rng, R)
+    obs = None
+    if workload != "config2":
+        sph = Cf.sample_spheres(rng)
+        sph[:, 2] += 1.5  # spheres above the workspace: mild repulsion, no contact (a closed loop near contact amplifies roundings)
+        kw = dict(spheres=torch.from_numpy(sph))
+        if workload == "config3_ragged":
+            off, idx = Cf.sample_ragged(rng, R)
+            kw.update(csr_offset=torch.from_numpy(off), csr_index=torch.from_numpy(idx))
+        obs = eng.obstacles(**kw)
+    goal = torch.from_numpy(s["goal"]).cuda()
+    q0, qd0 = torch.from_numpy(s["q"]).cuda(), torch.from_numpy(s["qd"]).cuda()
+    q, qd = q0.clone(), qd0.clone()
+    for _ in range(K):
+        qdd = eng.step(q, qd, goal, obstacles=obs)
+        assert "quad" in eng.last_kernel()
+        for _ in range(sub):
+            qd = qd + dt * qdd
+            q = q + dt * qd
+    qf, qdf = q0.clone(), qd0.clone()
+    eng.rollout(qf, qdf, goal, obstacles=obs, n_control_steps=K, substeps=sub, dt=dt)
+    torch.cuda.synchronize()
+    assert "quad" in eng.last_kernel()
+    ok = torch.isfinite(qf).all(dim=1) & torch.isfinite(q).all(dim=1)
+    err = (qf - q).abs().max(dim=1).values
+    scale = 1.0 + q.abs().max(dim=1).values
+    assert ok[-1] and ok.float().mean() > 0.99
+    assert (err[ok] <= 2e-5 * scale[ok]).all(), f"worst {float((err / scale)[ok].max()):.2e} at robot {int(torch.argmax(torch.where(ok, err / scale, torch.zeros_like(err))))} of {R}"
