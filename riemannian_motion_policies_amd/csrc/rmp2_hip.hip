@@ -1669,8 +1669,12 @@ int dispatch_solve(const rmp2_handle* h, const float* q, const float* qd, const 
     return RMP2_OK;
   if (strict_rollout) return RMP2_ERR_UNSUPPORTED;  // (an uncertifying quad resolve would be AUTO: never a silent change of semantics)
   // (attached-point leaves: hex up to 20 480 robots, the quad mapping beyond -- round 3; the lane mapping on request)
+  // (lane-per-robot beyond 49 152 robots without distance leaves -- round 5, config 2, us per step, quad | lane: 32 784 robots 16.5 | 21.8,
+  //  65 536: 25.4 | 22.6, 131 072: 43.8 | 41.8 (profiles/r05_dispatch_lane_quad.txt) --, and only for solve = AUTO: a solve = PINV handle
+  //  that reaches this point is one the quad mapping certifies, and the lane kernel's plain elimination would be AUTO's resolve under a
+  //  PINV handle -- the same numbers on full-rank robots, but not what was asked for; until round 5 such fleets silently took it)
   const bool lane = !rollout && !o.link_caps && (h->kernel_choice == 1 ||
-                                 (h->kernel_choice == 0 && !h->has_distance && !h->has_point && R > 32768));
+                                 (h->kernel_choice == 0 && !h->has_distance && !h->has_point && !h->strict && R > 49152));
   if (lane) return dispatch_slots<N, false>(h, q, qd, goal, gs, o, out, R, s);
   switch (h->n_slots) {
     case 0: (N == 2 ? launch_quad_n2_s0 : launch_quad_n9_s0)(h, q, qd, goal, gs, o, out, ro, R, s); return RMP2_OK;

@@ -1,6 +1,6 @@
 """Default dispatch at awkward fleet sizes: block tails (R not a multiple of the robots per wave / block), the cuts between
-the three mappings (dispatch_solve, csrc/rmp2_hip.hip: hex up to 8 192 robots, quad beyond, lane beyond 32 768 for sets
-without distance leaves) and between the quad kernel's register caps (two / three waves per SIMD by fleet size).  Against
+the three mappings (dispatch_solve, csrc/rmp2_hip.hip: hex up to 8 192 robots, quad beyond, lane beyond 49 152 for sets
+without distance leaves under solve = auto) and between the quad kernel's register caps (two / three waves per SIMD by fleet size).  Against
 the oracle on the first and last robots of the fleet and a random sample in between; the kernel that ran is asserted, so a
 moved cut shows up here and not only in a benchmark."""
 import numpy as np
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 SIZES = {
     # R: (kernel of config 2, kernel of config 3)
     1: ("hex", "hex"), 17: ("hex", "hex"), 4097: ("hex", "hex"), 8192: ("hex", "hex"), 8193: ("quad", "quad"),
-    20481: ("quad", "quad"), 32768: ("quad", "quad"), 32769: ("one lane", "quad"), 49153: ("one lane", "quad"),
+    20481: ("quad", "quad"), 32769: ("quad", "quad"), 49152: ("quad", "quad"), 49153: ("one lane", "quad"),
     70001: ("one lane", "quad"),
 }
 
@@ -43,6 +43,27 @@ def test_awkward_fleet_sizes_default_dispatch(hip_lib, name):
         tol = 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))     # the tolerance of tests/test_gpu_parity.py
         assert (err <= tol).all(), f"{name} R={R}: worst {err.max():.3e} ({eng.last_kernel()})"
         assert int((st != 0).sum()) == 0
+
+
+def test_a_pinv_handle_never_takes_the_plain_elimination_of_the_lane_kernel(hip_lib):
+    """solve = pinv without distance leaves beyond the lane cut: the quad mapping's certifying step, not the lane-per-robot kernel's
+    AUTO resolve (which fleets beyond 32 768 robots silently took until round 5: the same numbers on full-rank robots, but not the
+    resolve the handle asks for)."""
+    import torch
+    import oracle as O
+    from riemannian_motion_policies_amd import configs as Cf
+    from riemannian_motion_policies_amd.engine import Engine
+    _, desc = Cf.config2("pinv")
+    eng = Engine(desc, 0)
+    R = 70001
+    s = Cf.sample_panda_states(np.random.default_rng(R), R)
+    out = eng.step(torch.from_numpy(s["q"]), torch.from_numpy(s["qd"]), torch.from_numpy(s["goal"]))
+    torch.cuda.synchronize()
+    assert "quad" in eng.last_kernel() and "certified" in eng.last_kernel(), eng.last_kernel()
+    sub = np.concatenate([np.arange(64), np.arange(R - 64, R)])
+    ref = O.step(desc, s["q"][sub], s["qd"][sub], s["goal"][sub])["qdd64"]
+    err = np.abs(out.cpu().numpy()[sub] - ref).max(axis=1)
+    assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref).max(axis=1))).all()
 
 
 @pytest.mark.parametrize("rank", [0, 7])
