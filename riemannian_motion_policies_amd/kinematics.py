@@ -31,6 +31,18 @@ def _f32(a) -> np.ndarray:
     return np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
 
 
+def reduce_matrix_prod(all_T) -> HostTensor:
+    """all_T [N,4,4] -> T_0 @ T_1 @ ... @ T_{N-1} (kinematics.py:11-20: how the reference's FK chains a frame's transforms; the
+    device walk multiplies along the kinematic tree itself)."""
+    A = _f32(all_T)
+    if A.ndim != 3 or A.shape[-2:] != (4, 4):
+        raise ValueError(f"expected [N,4,4], got {A.shape}")
+    m = np.eye(4, dtype=np.float32)
+    for k in range(A.shape[0]):
+        m = (m @ A[k]).astype(np.float32)
+    return _host(m)
+
+
 def _axis_rotation(angle, axis: int) -> HostTensor:
     a = _f32(angle)
     if a.ndim != 2 or a.shape[1] != 1:

@@ -28,7 +28,8 @@ def K():
 def test_every_name_the_reference_imports_from_kinematics_is_there(K):
     # experiments/*/*.py and tests/*.py of the reference: `from kinematics import ...`
     for name in ("UrdfForwardKinematic", "R_x", "R_y", "R_z", "rotation_matrix_from_rotation_vector", "homogenous_transformation",
-                 "euler_from_rotation_matrix", "get_H_forEulerXYZ", "rotation_matrix_from_rpy", "rotation_matrix_from_quaternions"):
+                 "euler_from_rotation_matrix", "get_H_forEulerXYZ", "rotation_matrix_from_rpy", "rotation_matrix_from_quaternions",
+                 "reduce_matrix_prod"):
         assert callable(getattr(K, name)), name
 
 
@@ -58,6 +59,15 @@ def test_homogenous_transformation(K):
         assert np.max(np.abs(T - got)) <= 1e-5
     with pytest.raises(ValueError):
         K.homogenous_transformation(R=np.zeros((2, 3, 3)), t=np.zeros((2, 3, 1)))
+
+
+def test_reduce_matrix_prod_is_the_ordered_product(K):
+    rng = np.random.default_rng(11)
+    rot = spatial.transform.Rotation.random(5, random_state=3).as_matrix()
+    T = K.homogenous_transformation(R=rot, t=rng.uniform(-1, 1, size=(5, 3))).numpy()
+    want = np.linalg.multi_dot([t.astype(np.float64) for t in T])
+    assert np.max(np.abs(K.reduce_matrix_prod(T).numpy() - want)) <= 1e-5
+    assert np.array_equal(K.reduce_matrix_prod(np.zeros((0, 4, 4), dtype=np.float32)).numpy(), np.eye(4, dtype=np.float32))
 
 
 def test_rotation_matrix_from_rotation_vector(K):
