@@ -194,11 +194,15 @@ typedef struct rmp2_obstacles {
                                               FUSED into the step for tables of at most 256 spheres / capsules, robots with at
                                               most 9 dofs and an inertia leaf, solve = AUTO or a certifying PINV, and 2-dof robots
                                               with either resolve (their closed-form 2 x 2 resolve is the pseudo-inverse) -- shared
-                                              tables, ragged lists, rollouts; a plain step over a SHARED table beyond those limits --
-                                              more dofs, the all-Jacobi PINV, bigger tables, CYLINDER tables -- runs as the stage
-                                              into a buffer of the handle followed by the explicit-pair step (two launches, same
-                                              numbers as calling the two entry points).  Rollouts and ragged lists beyond the
-                                              fused limits: RMP2_ERR_UNSUPPORTED. */
+                                              tables, ragged lists, rollouts; a plain step beyond those limits -- more dofs, the
+                                              all-Jacobi PINV, bigger tables, CYLINDER tables -- runs as the stage into a buffer of
+                                              the handle followed by the explicit-pair step (two launches, same numbers as calling
+                                              the two entry points).  RAGGED lists take that route with one more launch (one pair per
+                                              list entry, a repeated index counted twice as in the fused form, filler pairs 1e9 m
+                                              away up to the fleet's longest list); the list lengths are read back from csr_offset,
+                                              so that form synchronises the stream and is refused inside a stream capture.
+                                              Rollouts beyond the fused limits, and sets with attached-point leaves over ragged
+                                              lists: RMP2_ERR_UNSUPPORTED. */
 } rmp2_obstacles;
 
 /* ---- outputs ----------------------------------------------------------------------- */

@@ -2056,6 +2056,34 @@ static bool needs_system_buffer(const rmp2_handle* h) {
   return (h->strict || h->likely_singular) && !quad_certifies_strict(h) && h->n_template == 9;
 }
 
+// Link geometry over RAGGED lists beyond the fused limits (step_impl): the closest-point stage has written, per robot, the pairs of
+// every distance leaf with EVERY primitive of the table (leaf i owns pairs [i K, (i + 1) K)); this kernel lays out what the robot's
+// list asks for -- one pair per LIST ENTRY, so that an index a list repeats counts twice, as the fused list walk counts it -- at L
+// slots per leaf, L = the longest list of the fleet.  Slots beyond a robot's list (and entries outside the table) hold a filler
+// pair: the leaf's first control point and an obstacle point 1e9 m from it -- beyond any avoidance radius, metric exactly 0,
+// every other term finite (what tests/test_gpu_capsules.py's oracle pairs use, a kilometre away).
+constexpr float kFillerDistance = 1.0e9f;
+__global__ void __launch_bounds__(kWave) rmp2_gather_list_pairs_kernel(const float* __restrict__ pl_all, const float* __restrict__ po_all,
+                                                                      const int32_t* __restrict__ csr_offset,
+                                                                      const int32_t* __restrict__ csr_index, float* __restrict__ pl_out,
+                                                                      float* __restrict__ po_out, int n_dist, int K, int L, int R) {
+  const int r = blockIdx.x;
+  if (r >= R) return;
+  const int off = csr_offset[r], len = csr_offset[r + 1] - off;
+  const size_t in0 = (size_t)r * n_dist * K, out0 = (size_t)r * n_dist * L;
+  for (int t = threadIdx.x; t < n_dist * L; t += kWave) {
+    const int i = t / L, e = t - i * L;
+    const int k = e < len ? csr_index[off + e] : -1;
+    const bool member = k >= 0 && k < K;
+    const size_t src = (in0 + (size_t)i * K + (member ? k : 0)) * 3, dst = (out0 + t) * 3;
+    const float a0 = pl_all[src], a1 = pl_all[src + 1], a2 = pl_all[src + 2];
+    pl_out[dst] = a0, pl_out[dst + 1] = a1, pl_out[dst + 2] = a2;
+    po_out[dst] = member ? po_all[src] : a0 + kFillerDistance;
+    po_out[dst + 1] = member ? po_all[src + 1] : a1;
+    po_out[dst + 2] = member ? po_all[src + 2] : a2;
+  }
+}
+
 static int grow_system_buffer(rmp2_handle* h, int32_t R) {
   if (h->d_system) HIP_TRY(h, hipFree(h->d_system));
   h->d_system = nullptr;
@@ -2081,19 +2109,43 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
   // more than nine dofs, solve = pinv where the quad mapping does not certify it, sets without an inertia leaf, tables beyond 256
   // primitives, CYLINDER tables -- whose segment-cylinder closed form is an iteration): the step runs as the reference's own data
   // flow instead (simulation.py:462-484 -> data_management.py:22-37 -> taskmap.py:115-138) -- the closest-point stage into a buffer
-  // of the handle, then the explicit-pair step on it.  Same pairs, same semantics; two launches.  (Plain control steps over a shared
-  // table; rollouts and ragged lists keep the fused forms' limits.)
+  // of the handle, then the explicit-pair step on it.  Same pairs, same semantics; two launches.  (Plain control steps; rollouts keep
+  // the fused forms' limits.)  RAGGED lists take the same route through one more launch: the stage over the whole table, then
+  // rmp2_gather_list_pairs_kernel lays out one pair per list entry at L = the fleet's longest list slots per leaf -- L is read back
+  // from csr_offset, so this form synchronises the stream and is refused inside a stream capture.
   rmp2_obstacles staged;
-  if (obs && obs->link_capsules && obs->mode == RMP2_OBS_SHARED_SPHERES && !h->has_point && ro.n_iters == 1 && ro.substeps == 0 &&
-      obs->n_spheres > 0 && !h->distance_leaves.empty() &&
+  const bool ragged_lists = obs && obs->mode == RMP2_OBS_RAGGED_SPHERES;
+  if (obs && obs->link_capsules && (obs->mode == RMP2_OBS_SHARED_SPHERES || ragged_lists) && !h->has_point && ro.n_iters == 1 &&
+      ro.substeps == 0 && obs->n_spheres > 0 && obs->spheres && !h->distance_leaves.empty() &&
       (obs->n_spheres > kLdsSpheres || obs->primitive == RMP2_PRIM_CYLINDER || (h->strict && !quad_certifies_strict(h) && h->n_template != 2) ||
        (h->likely_singular && h->n_template != 2) || h->n_template > 9 || h->goal_floats > 16)) {
-    const size_t P = h->distance_leaves.size() * (size_t)obs->n_spheres;
-    const size_t need = (size_t)R * P * 3;
+    const size_t n_dist = h->distance_leaves.size();
+    const size_t P_all = n_dist * (size_t)obs->n_spheres;   // the stage's pairs per robot: every leaf with every primitive
     hipStream_t s0 = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = s0 && hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    size_t L = 0;
+    if (ragged_lists) {
+      if (!obs->csr_offset || !obs->csr_index) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "RAGGED_SPHERES needs csr_offset / csr_index");
+      if (capturing)
+        return fail(h, RMP2_ERR_UNSUPPORTED, "link geometry over ragged lists as stage + explicit-pair step reads the list lengths back: "
+                                             "not inside a stream capture");
+      if (int rc = use_device(h)) return rc;
+      HIP_TRY(h, hipStreamSynchronize(s0));   // (the lists may have been written on this stream)
+      std::vector<int32_t> offs((size_t)R + 1);
+      HIP_TRY(h, hipMemcpy(offs.data(), obs->csr_offset, sizeof(int32_t) * offs.size(), hipMemcpyDeviceToHost));
+      for (int32_t r = 0; r < R; ++r) {
+        if (offs[r + 1] < offs[r]) return fail(h, RMP2_ERR_INVALID_ARGUMENT, "csr_offset must not decrease");
+        L = std::max(L, (size_t)(offs[r + 1] - offs[r]));
+      }
+      L = std::max<size_t>(L, 1);   // (every list empty: one filler pair per leaf)
+      if (n_dist * L > (size_t)INT32_MAX / 4) return fail(h, RMP2_ERR_UNSUPPORTED, "ragged lists too long for the explicit-pair step");
+    }
+    const size_t P = ragged_lists ? n_dist * L : P_all;     // pairs per robot handed to the explicit-pair step
+    const size_t need_all = (size_t)R * P_all * 3;
+    const size_t need = need_all + (ragged_lists ? (size_t)R * P * 3 : 0);
     if (need > h->pairs_floats) {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (s0 && hipStreamIsCapturing(s0, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      if (capturing)
         return fail(h, RMP2_ERR_UNSUPPORTED, "link geometry as stage + explicit-pair step: the handle's pair buffer must grow -- step once "
                                              "outside the capture first");
       if (int rc = use_device(h)) return rc;
@@ -2106,12 +2158,30 @@ static int step_impl(rmp2_handle* h, const float* q, const float* qd, const floa
     float* const po = h->d_pairs + h->pairs_floats;
     rmp2_obstacles table = *obs;
     table.link_capsules = nullptr;
+    table.mode = RMP2_OBS_SHARED_SPHERES;   // (the stage pairs every leaf with every primitive; a ragged fleet's lists pick below)
+    table.csr_offset = table.csr_index = nullptr;
     if (int rc = rmp2_closest_points_links(h, q, &table, obs->link_capsules, pl, po, R, stream)) return rc;
     std::memset(&staged, 0, sizeof(staged));
     staged.mode = RMP2_OBS_EXPLICIT_PAIRS;
     staged.n_pairs = (int32_t)P;
-    staged.p_link = pl, staged.p_obs = po;
-    for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) staged.pair_begin[l] = h->h_pair_begin[l];   // (as the stage laid the pairs out)
+    if (ragged_lists) {
+      float* const pl_out = pl + need_all;
+      float* const po_out = po + need_all;
+      hipLaunchKernelGGL(rmp2_gather_list_pairs_kernel, dim3(R), dim3(kWave), 0, s0, pl, po, obs->csr_offset, obs->csr_index, pl_out, po_out,
+                         (int)n_dist, (int)obs->n_spheres, (int)L, (int)R);
+      HIP_TRY(h, hipGetLastError());
+      staged.p_link = pl_out, staged.p_obs = po_out;
+      // leaf ranges at L slots per distance leaf (the stage's were K per leaf; prepare_step uploads the new ones -- after the stage's
+      // own upload on the same stream, each from pageable memory, i.e. read before the call returns)
+      int acc = 0;
+      for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) {
+        staged.pair_begin[l] = acc;
+        if (l < h->n_leaves && std::find(h->distance_leaves.begin(), h->distance_leaves.end(), l) != h->distance_leaves.end()) acc += (int)L;
+      }
+    } else {
+      staged.p_link = pl, staged.p_obs = po;
+      for (int l = 0; l <= RMP2_MAX_LEAVES; ++l) staged.pair_begin[l] = h->h_pair_begin[l];   // (as the stage laid the pairs out)
+    }
     obs = &staged;
   }
   ObsArgs o;
