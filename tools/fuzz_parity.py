@@ -403,6 +403,7 @@ def round5_extras(c, eng, obstacles, got, torch, O, what):
             from riemannian_motion_policies_amd import _native
             if not (isinstance(e, _native.Rmp2Error) and e.code == _native.ERR_UNSUPPORTED):
                 return f"bind / graph capture: {type(e).__name__}: {e}"
+            done.append("bind + graph REFUSED (RMP2_ERR_UNSUPPORTED): " + str(e)[:80])   # (counted in the log, not a silent skip)
     ek = c["eng_kw"]
     if side.random() < 0.25 and set(ek) == {"spheres"} and ek["spheres"].shape[1] == 4 and not dead.any():
         # the native obstacle exchange (rmp2_exchange_*: RCCL all-gather of the table + step, one call per control step) with the real
@@ -771,7 +772,7 @@ def main():
     assert torch.cuda.is_available(), "the fuzz campaign needs a HIP device"
     t0 = time.time()
     counts = {"passed": 0, "declined": 0, "failed": 0}
-    by_kernel, by_obstacles, declined_why, failures = {}, {}, {}, []
+    by_kernel, by_obstacles, by_extra, declined_why, failures = {}, {}, {}, {}, []
     robots = 0
     log = open(args.log, "w") if args.log else None
     last_note = t0
@@ -792,6 +793,9 @@ def main():
             by_kernel[k] = by_kernel.get(k, 0) + 1
             o = what["obstacles"].split(" ")[0] if "obstacles" in what else ("ragged" if what.get("ragged") else "spheres")
             by_obstacles[o] = by_obstacles.get(o, 0) + 1
+            for x in what.get("round5_extras", []):   # the side checks that ran (and the ones the library refused)
+                x = x.split(":")[0].rstrip("0123456789 ") if not x.startswith("bind + graph REFUSED") else "bind + graph REFUSED"
+                by_extra[x] = by_extra.get(x, 0) + 1
         elif outcome == "declined":
             w = what["why"][:90]
             declined_why[w] = declined_why.get(w, 0) + 1
@@ -807,7 +811,7 @@ def main():
             print(f"[{time.time() - t0:5.0f} s] {done} cases: {counts}", flush=True)
             last_note = time.time()
     summary = dict(cases=done, seeds=[args.seeds[0], args.seeds[0] + done], seconds=round(time.time() - t0, 1), robots_checked=robots, **counts,
-                   passed_by_kernel=by_kernel, passed_by_obstacle_interface=by_obstacles, declined_reasons=declined_why,
+                   passed_by_kernel=by_kernel, passed_by_obstacle_interface=by_obstacles, side_checks=by_extra, declined_reasons=declined_why,
                    failed_seeds=[f.get("seed") for f in failures])
     print(json.dumps(summary, indent=1))
     if log:
